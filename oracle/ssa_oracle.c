@@ -1,0 +1,864 @@
+/*
+ * ssa_oracle.c -- CPU restatement of ssa-gym's per-step hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle: a plain-C,
+ * scalar, one-object-at-a-time restatement of the reference's algorithm that
+ * follows the reference's own order of operations.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the
+ * product (ssa-gym_amd/, include/) never links, imports or executes it.
+ *
+ * Pinning (see DESIGN.md "Oracle"):
+ *   - propagator, geometry, means/residuals, jittered Cholesky: pinned against
+ *     golden vectors produced by the reference's own Python source
+ *     (tests/golden/gen_golden.py, run in the build container);
+ *   - UKF algebra (filterpy, a third-party dependency absent from the
+ *     reference tree and from this image): restated from the published
+ *     Merwe scaled-sigma-point UKF with filterpy 1.4.5's conventions; pinned
+ *     only through composite goldens (numpy restatement driven by the
+ *     reference's real fx/hx/mean/residual/msqrt callbacks) and the reference's
+ *     tests.py Test 6/7 thresholds -> "UKF parity otherwise unpinned".
+ *
+ * Build twice (oracle/Makefile): REAL=double  -> libssa_oracle.so
+ *                                REAL=long double (-DORC_LONG) -> libssa_oracle_ld.so
+ * The long-double build evaluates the same formulas in x87 80-bit arithmetic
+ * and is the conditioning witness for the fp64 rounding floor of the Merwe
+ * weights ("hard parts").  All entry points take and
+ * return IEEE doubles in both builds.
+ *
+ * All citations are file:line under /root/reference.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef ORC_LONG
+typedef long double real;
+#define F(name) name##l
+#define PI_R 3.141592653589793238462643383279502884L
+#else
+typedef double real;
+#define F(name) name
+#define PI_R 3.141592653589793
+#endif
+
+#define NX 6
+#define NZ 3
+#define NS 13
+
+/* ------------------------------------------------------------------ helpers */
+
+static real dot3(const real *a, const real *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static real norm3(const real *a) { return F(sqrt)(dot3(a, a)); }
+static void cross3(const real *a, const real *b, real *c)
+{
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+/* Python / numpy float `%`: result takes the sign of the divisor. */
+static real pymod(real a, real b)
+{
+    real m = F(fmod)(a, b);
+    if (m != 0 && ((m < 0) != (b < 0))) m += b;
+    return m;
+}
+static real sign_r(real x) { return (x > 0) - (x < 0); }
+
+/* ------------------------------------------- P3/P4 anomaly conversions */
+/* envs/farnocchia.py:436 nu_to_E, :508 E_to_nu, :472 nu_to_F, :544 F_to_nu, :656 E_to_M ... */
+static real nu_to_E(real nu, real ecc) { return 2 * F(atan)(F(sqrt)((1 - ecc) / (1 + ecc)) * F(tan)(nu / 2)); }
+static real E_to_nu(real E, real ecc) { return 2 * F(atan)(F(sqrt)((1 + ecc) / (1 - ecc)) * F(tan)(E / 2)); }
+static real nu_to_F(real nu, real ecc) { return 2 * F(atanh)(F(sqrt)((ecc - 1) / (ecc + 1)) * F(tan)(nu / 2)); }
+static real F_to_nu(real Fh, real ecc) { return 2 * F(atan)(F(sqrt)((ecc + 1) / (ecc - 1)) * F(tanh)(Fh / 2)); }
+static real E_to_M(real E, real ecc) { return E - ecc * F(sin)(E); }
+static real F_to_M(real Fh, real ecc) { return ecc * F(sinh)(Fh) - Fh; }
+static real nu_to_D(real nu) { return F(tan)(nu / 2); }
+static real D_to_nu(real D) { return 2 * F(atan)(D); }
+static real D_to_M(real D) { return D + D * D * D / 3; }
+/* envs/farnocchia.py:605 M_to_D */
+static real M_to_D(real M)
+{
+    real B = 3 * M / 2;
+    real A = F(pow)(B + F(sqrt)(1 + B * B), (real)2 / 3);
+    return 2 * A * B / (1 + A + A * A);
+}
+
+/* envs/farnocchia.py:337 newton (elliptic / hyperbolic regimes), tol 1.48e-8,
+ * NaN on non-convergence (:353). */
+static real newton_kepler(int hyperbolic, real x0, real M, real ecc, int maxiter)
+{
+    real p0 = x0;
+    for (int i = 0; i < maxiter; ++i) {
+        real fval, fder;
+        if (hyperbolic) {
+            fval = F_to_M(p0, ecc) - M;
+            fder = ecc * F(cosh)(p0) - 1;
+        } else {
+            fval = E_to_M(p0, ecc) - M;
+            fder = 1 - ecc * F(cos)(p0);
+        }
+        real p = p0 - fval / fder;
+        if (F(fabs)(p - p0) < (real)1.48e-08) return p;
+        p0 = p;
+    }
+    return NAN;
+}
+/* envs/farnocchia.py:573 M_to_E : E0 = M if ecc < 0.8 else pi*sign(M) */
+static real M_to_E(real M, real ecc)
+{
+    real E0 = (ecc < (real)0.8) ? M : PI_R * sign_r(M);
+    return newton_kepler(0, E0, M, ecc, 50);
+}
+/* envs/farnocchia.py:605 M_to_F */
+static real M_to_F(real M, real ecc) { return newton_kepler(1, F(asinh)(M / ecc), M, ecc, 100); }
+
+/* near-parabolic series, envs/farnocchia.py:692-843 (dead for the catalogue, ecc <= 0.737) */
+static real S_x(real ecc, real x)
+{
+    real S = 0, xk = 1;
+    for (int k = 0; k < 100000; ++k) {
+        real S_old = S;
+        S += (ecc - (real)1 / (2 * k + 3)) * xk;
+        xk *= x;
+        if (F(fabs)(S - S_old) < (real)1e-12) return S;
+    }
+    return NAN;
+}
+static real dS_x_alt(real ecc, real x)
+{
+    real S = 0, xk = 1;
+    for (int k = 0; k < 100000; ++k) {
+        real S_old = S;
+        S += (ecc - (real)1 / (2 * k + 3)) * (2 * k + 3) * xk;
+        xk *= x;
+        if (F(fabs)(S - S_old) < (real)1e-12) return S;
+    }
+    return NAN;
+}
+static real D_to_M_near_parabolic(real D, real ecc)
+{
+    real x = (ecc - 1) / (ecc + 1) * (D * D);
+    real S = S_x(ecc, x);
+    return F(sqrt)(2 / (1 + ecc)) * D + F(sqrt)(2 / ((1 + ecc) * (1 + ecc) * (1 + ecc))) * (D * D * D) * S;
+}
+static real M_to_D_near_parabolic(real M, real ecc)
+{
+    real D0 = M_to_D(M);
+    for (int i = 0; i < 50; ++i) {
+        real fval = D_to_M_near_parabolic(D0, ecc) - M;
+        real x = (ecc - 1) / (ecc + 1) * (D0 * D0);
+        real S = dS_x_alt(ecc, x);
+        real fder = F(sqrt)(2 / (1 + ecc)) + F(sqrt)(2 / ((1 + ecc) * (1 + ecc) * (1 + ecc))) * (D0 * D0) * S;
+        real D = D0 - fval / fder;
+        if (F(fabs)(D - D0) < (real)1.48e-08) return D;
+        D0 = D;
+    }
+    return NAN;
+}
+
+/* envs/farnocchia.py:847 delta_t_from_nu */
+static real delta_t_from_nu(real nu, real ecc, real k, real q)
+{
+    const real delta = (real)1e-2;
+    real M, n;
+    if (ecc < 1 - delta) { /* strong elliptic (:871-875) */
+        real E = nu_to_E(nu, ecc);
+        M = E_to_M(E, ecc);
+        n = F(sqrt)(k * (1 - ecc) * (1 - ecc) * (1 - ecc) / (q * q * q));
+    } else if (1 - delta <= ecc && ecc < 1) {
+        real E = nu_to_E(nu, ecc);
+        if (delta <= 1 - ecc * F(cos)(E)) {
+            M = E_to_M(E, ecc);
+            n = F(sqrt)(k * (1 - ecc) * (1 - ecc) * (1 - ecc) / (q * q * q));
+        } else {
+            real D = nu_to_D(nu);
+            M = D_to_M_near_parabolic(D, ecc);
+            n = F(sqrt)(k / (2 * q * q * q));
+        }
+    } else if (ecc == 1) {
+        real D = nu_to_D(nu);
+        M = D_to_M(D);
+        n = F(sqrt)(k / (2 * q * q * q));
+    } else if (1 + ecc * F(cos)(nu) < 0) {
+        return NAN;
+    } else if (1 < ecc && ecc <= 1 + delta) {
+        real Fh = nu_to_F(nu, ecc);
+        if (delta <= ecc * F(cosh)(Fh) - 1) {
+            M = F_to_M(Fh, ecc);
+            n = F(sqrt)(k * (ecc - 1) * (ecc - 1) * (ecc - 1) / (q * q * q));
+        } else {
+            real D = nu_to_D(nu);
+            M = D_to_M_near_parabolic(D, ecc);
+            n = F(sqrt)(k / (2 * q * q * q));
+        }
+    } else if (1 + delta < ecc) {
+        real Fh = nu_to_F(nu, ecc);
+        M = F_to_M(Fh, ecc);
+        n = F(sqrt)(k * (ecc - 1) * (ecc - 1) * (ecc - 1) / (q * q * q));
+    } else {
+        return NAN; /* RuntimeError in the reference (NaN ecc) */
+    }
+    return M / n;
+}
+
+/* envs/farnocchia.py:925 nu_from_delta_t */
+static real nu_from_delta_t(real delta_t, real ecc, real k, real q)
+{
+    const real delta = (real)1e-2;
+    real nu;
+    if (ecc < 1 - delta) { /* strong elliptic (:946-954) */
+        real n = F(sqrt)(k * (1 - ecc) * (1 - ecc) * (1 - ecc) / (q * q * q));
+        real M = n * delta_t;
+        real E = M_to_E(pymod(M + PI_R, 2 * PI_R) - PI_R, ecc);
+        nu = E_to_nu(E, ecc);
+    } else if (1 - delta <= ecc && ecc < 1) {
+        real E_delta = F(acos)((1 - delta) / ecc);
+        real n = F(sqrt)(k * (1 - ecc) * (1 - ecc) * (1 - ecc) / (q * q * q));
+        real M = n * delta_t;
+        if (E_to_M(E_delta, ecc) <= F(fabs)(M)) {
+            real E = M_to_E(pymod(M + PI_R, 2 * PI_R) - PI_R, ecc);
+            nu = E_to_nu(E, ecc);
+        } else {
+            n = F(sqrt)(k / (2 * q * q * q));
+            M = n * delta_t;
+            nu = D_to_nu(M_to_D_near_parabolic(M, ecc));
+        }
+    } else if (ecc == 1) {
+        real n = F(sqrt)(k / (2 * q * q * q));
+        nu = D_to_nu(M_to_D(n * delta_t));
+    } else if (1 < ecc && ecc <= 1 + delta) {
+        real F_delta = F(acosh)((1 + delta) / ecc);
+        real n = F(sqrt)(k * (ecc - 1) * (ecc - 1) * (ecc - 1) / (q * q * q));
+        real M = n * delta_t;
+        if (F_to_M(F_delta, ecc) <= F(fabs)(M)) {
+            nu = F_to_nu(M_to_F(M, ecc), ecc);
+        } else {
+            n = F(sqrt)(k / (2 * q * q * q));
+            M = n * delta_t;
+            nu = D_to_nu(M_to_D_near_parabolic(M, ecc));
+        }
+    } else {
+        real n = F(sqrt)(k * (ecc - 1) * (ecc - 1) * (ecc - 1) / (q * q * q));
+        real M = n * delta_t;
+        nu = F_to_nu(M_to_F(M, ecc), ecc);
+    }
+    return nu;
+}
+
+/* ---------------------------------------------------------------- P2 rv2coe */
+/* envs/farnocchia.py:165-313.  coe = (p, ecc, inc, raan, argp, nu). */
+static void rv2coe(real k, const real *r, const real *v, real *coe)
+{
+    const real tol = (real)1e-8;
+    const real two_pi = 2 * PI_R;
+    real h[3], n[3], e[3], z[3] = {0, 0, 1}, t[3];
+    cross3(r, v, h);
+    cross3(z, h, n);
+    real rn = norm3(r), vv = dot3(v, v), rv = dot3(r, v);
+    for (int i = 0; i < 3; ++i) e[i] = ((vv - k / rn) * r[i] - rv * v[i]) / k;
+    real ecc = norm3(e);
+    real p = dot3(h, h) / k;
+    real hn = norm3(h);
+    real inc = F(acos)(h[2] / hn);
+    int circular = ecc < tol;
+    int equatorial = F(fabs)(inc) < tol;
+    real raan, argp, nu;
+    if (equatorial && !circular) {
+        raan = 0;
+        argp = pymod(F(atan2)(e[1], e[0]), two_pi);
+        cross3(e, r, t);
+        nu = F(atan2)(dot3(h, t) / hn, dot3(r, e));
+    } else if (!equatorial && circular) {
+        raan = pymod(F(atan2)(n[1], n[0]), two_pi);
+        argp = 0;
+        cross3(h, n, t);
+        nu = F(atan2)(dot3(r, t) / hn, dot3(r, n));
+    } else if (equatorial && circular) {
+        raan = 0;
+        argp = 0;
+        nu = pymod(F(atan2)(r[1], r[0]), two_pi);
+    } else {
+        real a = p / (1 - ecc * ecc);
+        real ka = k * a;
+        if (a > 0) {
+            real e_se = rv / F(sqrt)(ka);
+            real e_ce = rn * vv / k - 1;
+            nu = E_to_nu(F(atan2)(e_se, e_ce), ecc);
+        } else {
+            real e_sh = rv / F(sqrt)(-ka);
+            real vn = norm3(v);
+            real e_ch = rn * (vn * vn) / k - 1;
+            nu = F_to_nu(F(log)((e_ch + e_sh) / (e_ch - e_sh)) / 2, ecc);
+        }
+        raan = pymod(F(atan2)(n[1], n[0]), two_pi);
+        real px = dot3(r, n);
+        cross3(h, n, t);
+        real py = dot3(r, t) / hn;
+        argp = pymod(F(atan2)(py, px) - nu, two_pi);
+    }
+    nu = pymod(nu + PI_R, two_pi) - PI_R;
+    coe[0] = p; coe[1] = ecc; coe[2] = inc; coe[3] = raan; coe[4] = argp; coe[5] = nu;
+}
+
+/* ---------------------------------------------------------------- P5 coe2rv */
+/* envs/farnocchia.py:101 coe2rv, :15 rv_pqw, :91 coe_rotation_matrix, :77 rotation_matrix */
+static void matmul3(const real *A, const real *B, real *C)
+{
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            real s = 0;
+            for (int l = 0; l < 3; ++l) s += A[i * 3 + l] * B[l * 3 + j];
+            C[i * 3 + j] = s;
+        }
+}
+static void rot_axis(real angle, int axis, real *R)
+{
+    real c = F(cos)(angle), s = F(sin)(angle);
+    if (axis == 0) {
+        real M[9] = {1, 0, 0, 0, c, -s, 0, s, c};
+        memcpy(R, M, sizeof M);
+    } else { /* axis == 2 (axis 1 is never used by coe_rotation_matrix) */
+        real M[9] = {c, -s, 0, s, c, 0, 0, 0, 1};
+        memcpy(R, M, sizeof M);
+    }
+}
+static void coe2rv(real k, const real *coe, real *rv)
+{
+    real p = coe[0], ecc = coe[1], inc = coe[2], raan = coe[3], argp = coe[4], nu = coe[5];
+    real cn = F(cos)(nu), sn = F(sin)(nu);
+    real fr = p / (1 + ecc * cn), fv = F(sqrt)(k / p);
+    real pqw[6] = {cn * fr, sn * fr, 0 * fr, -sn * fv, (ecc + cn) * fv, 0 * fv};
+    real R1[9], R2[9], R3[9], T[9], rm[9];
+    rot_axis(raan, 2, R1);
+    rot_axis(inc, 0, R2);
+    rot_axis(argp, 2, R3);
+    matmul3(R1, R2, T);
+    matmul3(T, R3, rm);
+    for (int a = 0; a < 2; ++a)
+        for (int i = 0; i < 3; ++i) {
+            real s = 0;
+            for (int j = 0; j < 3; ++j) s += pqw[a * 3 + j] * rm[i * 3 + j];
+            rv[a * 3 + i] = s;
+        }
+}
+
+/* ------------------------------------------------------------- P1 farnocchia */
+/* envs/farnocchia.py:1010 farnocchia, :1054 fx_xyz_farnocchia (k hard-coded :1060) */
+#define MU_EARTH ((real)398600441800000.0)
+static void fx_farnocchia(const real *x, real tof, real *out)
+{
+    real coe[6];
+    rv2coe(MU_EARTH, x, x + 3, coe);
+    real q = coe[0] / (1 + coe[1]);
+    real delta_t0 = delta_t_from_nu(coe[5], coe[1], MU_EARTH, q);
+    real delta_t = delta_t0 + tof;
+    coe[5] = nu_from_delta_t(delta_t, coe[1], MU_EARTH, q);
+    coe2rv(MU_EARTH, coe, out);
+}
+
+/* ------------------------------------------------------- H1 / H3 / H4 / T2 */
+/* envs/transformations.py:330 ecef2aer */
+static void ecef2aer(const real *obs_lla, const real *sat, const real *obs, real *aer)
+{
+    real lat = obs_lla[0], lon = obs_lla[1];
+    real sl = F(sin)(lat), cl = F(cos)(lat), so = F(sin)(lon), co = F(cos)(lon);
+    real T[9] = {-sl * co, -so, cl * co, -sl * so, co, cl * so, cl, 0, sl};
+    real d[3] = {sat[0] - obs[0], sat[1] - obs[1], sat[2] - obs[2]};
+    real R[3];
+    for (int j = 0; j < 3; ++j) R[j] = T[0 * 3 + j] * d[0] + T[1 * 3 + j] * d[1] + T[2 * 3 + j] * d[2];
+    real r = F(sqrt)(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    real az = F(atan2)(R[1], R[0]);
+    if (az < 0) az = az + 2 * PI_R;
+    aer[0] = az;
+    aer[1] = F(asin)(R[2] / r);
+    aer[2] = r;
+}
+/* envs/dynamics.py:219 hx_aer_erfa */
+static void hx_aer(const real *x, const real *M, const real *obs_lla, const real *obs_itrs, real *z)
+{
+    real xi[3];
+    for (int i = 0; i < 3; ++i) xi[i] = M[i * 3] * x[0] + M[i * 3 + 1] * x[1] + M[i * 3 + 2] * x[2];
+    ecef2aer(obs_lla, xi, obs_itrs, z);
+}
+/* envs/transformations.py:284 aer2uvw, :301 uvw2aer */
+static void aer2uvw(const real *aer, real *uvw)
+{
+    real az = aer[0], el = aer[1], r = aer[2];
+    uvw[0] = r * F(cos)(el) * F(cos)(az);
+    uvw[1] = r * F(cos)(el) * F(sin)(az);
+    uvw[2] = r * F(sin)(el);
+}
+static void uvw2aer(const real *uvw, real *aer)
+{
+    real r = F(sqrt)(uvw[0] * uvw[0] + uvw[1] * uvw[1] + uvw[2] * uvw[2]);
+    real az = F(atan2)(uvw[1], uvw[0]);
+    if (az < 0) az = az + 2 * PI_R;
+    aer[0] = az;
+    aer[1] = F(asin)(uvw[2] / r);
+    aer[2] = r;
+}
+/* envs/dynamics.py:343 mean_z_uvw; centred=0: np.dot(Wm, uvw) in index order;
+ * centred=1: s0 + sum_{i>=1} Wm[i] (s_i - s0)  (same mathematics since sum(Wm)=1) */
+static void weighted_mean(const real *pts, int npts, int dim, const real *Wm, int centred, real *mean)
+{
+    for (int c = 0; c < dim; ++c) {
+        real s;
+        if (centred) {
+            s = 0;
+            for (int i = 1; i < npts; ++i) s += Wm[i] * (pts[i * dim + c] - pts[c]);
+            s = pts[c] + s;
+        } else {
+            s = 0;
+            for (int i = 0; i < npts; ++i) s += Wm[i] * pts[i * dim + c];
+        }
+        mean[c] = s;
+    }
+}
+static void mean_z_uvw(const real *sig, int npts, const real *Wm, int centred, real *zp)
+{
+    real *uvw = (real *)malloc(sizeof(real) * 3 * (size_t)npts), m[3];
+    for (int i = 0; i < npts; ++i) aer2uvw(sig + 3 * i, uvw + 3 * i);
+    weighted_mean(uvw, npts, 3, Wm, centred, m);
+    uvw2aer(m, zp);
+    free(uvw);
+}
+/* envs/dynamics.py:260 residual_z_aer */
+static void residual_z_aer(const real *a, const real *b, real *c)
+{
+    real d = a[0] - b[0];
+    c[0] = F(atan2)(F(sin)(d), F(cos)(d));
+    c[1] = a[1] - b[1];
+    c[2] = a[2] - b[2];
+}
+/* envs/transformations.py:217 lla2ecef, WGS84 constants :11-13 (a, f from erfa.eform(1)) */
+static void lla2ecef(const real *lla, real *ecef)
+{
+    const real a = (real)6378137.0, f = (real)0.0033528106647474805;
+    real e = F(sqrt)(f * (2 - f));
+    real lat = lla[0], lon = lla[1], alt = lla[2];
+    real sl = F(sin)(lat);
+    real N = a / F(sqrt)(1 - e * e * sl * sl);
+    ecef[0] = (N + alt) * F(cos)(lat) * F(cos)(lon);
+    ecef[1] = (N + alt) * F(cos)(lat) * F(sin)(lon);
+    ecef[2] = (N * (1 - e * e) + alt) * sl;
+}
+
+/* ----------------------------------------------------------- U2 Cholesky */
+/* LAPACK dpotf2('U') order: for each column j, ajj = a_jj - sum_i<j u_ij^2;
+ * fail if ajj <= 0 or NaN; then row j.  Returns 0 or the failing order (1-based). */
+static int cholesky_upper(const real *A, real *U, int n)
+{
+    memset(U, 0, sizeof(real) * n * n);
+    for (int j = 0; j < n; ++j) {
+        real ajj = A[j * n + j];
+        for (int i = 0; i < j; ++i) ajj -= U[i * n + j] * U[i * n + j];
+        if (!(ajj > 0)) return j + 1;
+        ajj = F(sqrt)(ajj);
+        U[j * n + j] = ajj;
+        for (int c = j + 1; c < n; ++c) {
+            real s = A[j * n + c];
+            for (int i = 0; i < j; ++i) s -= U[i * n + j] * U[i * n + c];
+            U[j * n + c] = s / ajj;
+        }
+    }
+    return 0;
+}
+/* envs/dynamics.py:402 robust_cholesky: plain factorisation, then a + 10^i I,
+ * i = -6..9 (first success wins), else LinAlgError.  scipy's check_finite makes
+ * any NaN/inf input fail every attempt.  *rung: -1 no jitter, 0..15 ladder index,
+ * 16 = LinAlgError.  Returns 0 on success. */
+static const double JITTER[16] = {1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1.0, 10.0, 100.0, 1e3,
+                                  1e4, 1e5, 1e6, 1e7, 1e8, 1e9};
+static int robust_cholesky(const real *A, real *U, int n, int *rung)
+{
+    int finite = 1;
+    for (int i = 0; i < n * n; ++i)
+        if (!isfinite(A[i])) finite = 0;
+    if (finite) {
+        if (cholesky_upper(A, U, n) == 0) { *rung = -1; return 0; }
+        real B[NX * NX];
+        for (int t = 0; t < 16; ++t) {
+            memcpy(B, A, sizeof(real) * n * n);
+            for (int i = 0; i < n; ++i) B[i * n + i] += (real)JITTER[t];
+            if (cholesky_upper(B, U, n) == 0) { *rung = t; return 0; }
+        }
+    }
+    *rung = 16;
+    return 1;
+}
+
+/* ------------------------------------------------------------ U1 sigma points */
+/* filterpy MerweScaledSigmaPoints.sigma_points: U = msqrt((n+lambda) P) (upper);
+ * sigma_0 = x; sigma_{k+1} = x + U[k] (ROW k); sigma_{n+k+1} = x - U[k]. */
+static int sigma_points(const real *x, const real *P, real scale, real *sig, int *rung)
+{
+    real A[NX * NX], U[NX * NX];
+    for (int i = 0; i < NX * NX; ++i) A[i] = scale * P[i];
+    if (robust_cholesky(A, U, NX, rung)) return 1;
+    for (int c = 0; c < NX; ++c) sig[c] = x[c];
+    for (int k = 0; k < NX; ++k)
+        for (int c = 0; c < NX; ++c) {
+            sig[(k + 1) * NX + c] = x[c] - (-U[k * NX + c]);
+            sig[(NX + k + 1) * NX + c] = x[c] - U[k * NX + c];
+        }
+    return 0;
+}
+
+/* --------------------------------------------------- U3 unscented transform */
+/* filterpy unscented_transform with residual np.subtract (vectorised path):
+ * x = dot(Wm, sigmas); y = sigmas - x; P = y^T (diag(Wc) y) + noise. */
+static void unscented_transform6(const real *sig, const real *Wm, const real *Wc, const real *Q,
+                                 int centred, real *x, real *P)
+{
+    weighted_mean(sig, NS, NX, Wm, centred, x);
+    for (int a = 0; a < NX; ++a)
+        for (int b = 0; b < NX; ++b) {
+            real s = 0;
+            for (int i = 0; i < NS; ++i) s += (sig[i * NX + a] - x[a]) * (Wc[i] * (sig[i * NX + b] - x[b]));
+            P[a * NX + b] = s + Q[a * NX + b];
+        }
+}
+
+/* status codes shared with the device library (include/ssa_hip.h) */
+#define ST_OK 0
+#define ST_PREDICT_NAN 1
+#define ST_PREDICT_LINALG 2
+#define ST_UPDATE_NAN 3
+#define ST_UPDATE_LINALG 4
+
+/* filterpy UnscentedKalmanFilter.predict (ssa_tasker_simple_2.py:275): returns status,
+ * x/P overwritten with the prior, sigmas_f kept for update(). */
+static int ukf_predict(real *x, real *P, const real *Q, real dt, real scale, const real *Wm, const real *Wc,
+                       int centred, real *sigmas_f)
+{
+    real sig[NS * NX];
+    int rung;
+    if (sigma_points(x, P, scale, sig, &rung)) return ST_PREDICT_LINALG;
+    for (int i = 0; i < NS; ++i) fx_farnocchia(sig + i * NX, dt, sigmas_f + i * NX);
+    unscented_transform6(sigmas_f, Wm, Wc, Q, centred, x, P);
+    for (int c = 0; c < NX; ++c)
+        if (isnan(x[c])) return ST_PREDICT_NAN;
+    return ST_OK;
+}
+
+/* 3x3 inverse (numpy.linalg.inv -> LAPACK getrf/getri; here by cofactors).
+ * returns 1 if singular / non-finite. */
+static int inv3(const real *S, real *SI)
+{
+    real c00 = S[4] * S[8] - S[5] * S[7], c01 = S[5] * S[6] - S[3] * S[8], c02 = S[3] * S[7] - S[4] * S[6];
+    real det = S[0] * c00 + S[1] * c01 + S[2] * c02;
+    if (det == 0 || !isfinite(det)) return 1;
+    SI[0] = c00 / det;
+    SI[1] = (S[2] * S[7] - S[1] * S[8]) / det;
+    SI[2] = (S[1] * S[5] - S[2] * S[4]) / det;
+    SI[3] = c01 / det;
+    SI[4] = (S[0] * S[8] - S[2] * S[6]) / det;
+    SI[5] = (S[2] * S[3] - S[0] * S[5]) / det;
+    SI[6] = c02 / det;
+    SI[7] = (S[1] * S[6] - S[0] * S[7]) / det;
+    SI[8] = (S[0] * S[4] - S[1] * S[3]) / det;
+    return 0;
+}
+
+/* filterpy UnscentedKalmanFilter.update (ssa_tasker_simple_2.py:301).
+ * obs_type 0 = 'aer' (hx_aer_erfa, mean_z_uvw, residual_z_aer), 1 = 'xyz'
+ * (hx_xyz, mean_xyz, residual_xyz).  resample != 0 redraws sigmas_f from the
+ * prior (x, P) first (filterpy-master predict() semantics). */
+static int ukf_update(real *x, real *P, real *sigmas_f, const real *z, const real *R, const real *Wm,
+                      const real *Wc, real scale, int obs_type, int centred, int resample, const real *M,
+                      const real *obs_lla, const real *obs_itrs, real *y_out, real *S_out, real *sigmas_h)
+{
+    if (resample) {
+        int rung;
+        if (sigma_points(x, P, scale, sigmas_f, &rung)) return ST_UPDATE_LINALG;
+    }
+    real zp[NZ], S[NZ * NZ], SI[NZ * NZ], Pxz[NX * NZ], K[NX * NZ], rz[NS * NZ];
+    for (int i = 0; i < NS; ++i) {
+        if (obs_type == 0)
+            hx_aer(sigmas_f + i * NX, M, obs_lla, obs_itrs, sigmas_h + i * NZ);
+        else
+            for (int c = 0; c < NZ; ++c) sigmas_h[i * NZ + c] = sigmas_f[i * NX + c];
+    }
+    if (obs_type == 0)
+        mean_z_uvw(sigmas_h, NS, Wm, centred, zp);
+    else
+        weighted_mean(sigmas_h, NS, NZ, Wm, centred, zp);
+    for (int i = 0; i < NS; ++i) {
+        if (obs_type == 0)
+            residual_z_aer(sigmas_h + i * NZ, zp, rz + i * NZ);
+        else
+            for (int c = 0; c < NZ; ++c) rz[i * NZ + c] = sigmas_h[i * NZ + c] - zp[c];
+    }
+    for (int a = 0; a < NZ; ++a)
+        for (int b = 0; b < NZ; ++b) {
+            real s = 0;
+            for (int i = 0; i < NS; ++i) s += Wc[i] * (rz[i * NZ + a] * rz[i * NZ + b]);
+            S[a * NZ + b] = s + R[a * NZ + b];
+        }
+    if (inv3(S, SI)) return ST_UPDATE_LINALG;
+    for (int a = 0; a < NX; ++a)
+        for (int b = 0; b < NZ; ++b) {
+            real s = 0;
+            for (int i = 0; i < NS; ++i) s += Wc[i] * ((sigmas_f[i * NX + a] - x[a]) * rz[i * NZ + b]);
+            Pxz[a * NZ + b] = s;
+        }
+    for (int a = 0; a < NX; ++a)
+        for (int b = 0; b < NZ; ++b) {
+            real s = 0;
+            for (int l = 0; l < NZ; ++l) s += Pxz[a * NZ + l] * SI[l * NZ + b];
+            K[a * NZ + b] = s;
+        }
+    real y[NZ];
+    if (obs_type == 0)
+        residual_z_aer(z, zp, y);
+    else
+        for (int c = 0; c < NZ; ++c) y[c] = z[c] - zp[c];
+    for (int a = 0; a < NX; ++a) {
+        real s = 0;
+        for (int l = 0; l < NZ; ++l) s += K[a * NZ + l] * y[l];
+        x[a] = x[a] + s;
+    }
+    real SKt[NZ * NX]; /* S @ K^T */
+    for (int a = 0; a < NZ; ++a)
+        for (int b = 0; b < NX; ++b) {
+            real s = 0;
+            for (int l = 0; l < NZ; ++l) s += S[a * NZ + l] * K[b * NZ + l];
+            SKt[a * NX + b] = s;
+        }
+    for (int a = 0; a < NX; ++a)
+        for (int b = 0; b < NX; ++b) {
+            real s = 0;
+            for (int l = 0; l < NZ; ++l) s += K[a * NZ + l] * SKt[l * NX + b];
+            P[a * NX + b] = P[a * NX + b] - s;
+        }
+    for (int c = 0; c < NZ; ++c) y_out[c] = y[c];
+    for (int c = 0; c < NZ * NZ; ++c) S_out[c] = S[c];
+    for (int c = 0; c < NX; ++c)
+        if (isnan(x[c])) return ST_UPDATE_NAN;
+    return ST_OK;
+}
+
+/* ======================================================== exported C entry points
+ * (double in / double out in both builds; loops over objects on one host thread) */
+static void ld(const double *s, real *d, int n) { for (int i = 0; i < n; ++i) d[i] = (real)s[i]; }
+static void st(const real *s, double *d, int n) { for (int i = 0; i < n; ++i) d[i] = (double)s[i]; }
+
+void orc_propagate(const double *x_in, double *x_out, long n, double dt)
+{
+    for (long j = 0; j < n; ++j) {
+        real x[6], o[6];
+        ld(x_in + 6 * j, x, 6);
+        fx_farnocchia(x, (real)dt, o);
+        st(o, x_out + 6 * j, 6);
+    }
+}
+/* coe (p, ecc, inc, raan, argp, nu0) and (delta_t0, nu_after) -> inter[n][8] */
+void orc_kepler_intermediates(const double *x_in, double *inter, long n, double dt)
+{
+    for (long j = 0; j < n; ++j) {
+        real x[6], coe[6];
+        ld(x_in + 6 * j, x, 6);
+        rv2coe(MU_EARTH, x, x + 3, coe);
+        real q = coe[0] / (1 + coe[1]);
+        real dt0 = delta_t_from_nu(coe[5], coe[1], MU_EARTH, q);
+        real nu = nu_from_delta_t(dt0 + (real)dt, coe[1], MU_EARTH, q);
+        st(coe, inter + 8 * j, 6);
+        inter[8 * j + 6] = (double)dt0;
+        inter[8 * j + 7] = (double)nu;
+    }
+}
+int orc_robust_cholesky(const double *A, double *U, int *rung)
+{
+    real a[36], u[36];
+    ld(A, a, 36);
+    int rc = robust_cholesky(a, u, NX, rung);
+    st(u, U, 36);
+    return rc;
+}
+int orc_sigma_points(const double *x, const double *P, double scale, double *sig)
+{
+    real xx[6], pp[36], ss[NS * NX];
+    int rung;
+    ld(x, xx, 6); ld(P, pp, 36);
+    memset(ss, 0, sizeof ss);
+    int rc = sigma_points(xx, pp, (real)scale, ss, &rung);
+    st(ss, sig, NS * NX);
+    return rc;
+}
+void orc_hx_aer(const double *x, const double *M, const double *obs_lla, const double *obs_itrs, double *z, long n)
+{
+    real m[9], l[3], o[3];
+    ld(M, m, 9); ld(obs_lla, l, 3); ld(obs_itrs, o, 3);
+    for (long j = 0; j < n; ++j) {
+        real xx[3], zz[3];
+        ld(x + 6 * j, xx, 3);
+        hx_aer(xx, m, l, o, zz);
+        st(zz, z + 3 * j, 3);
+    }
+}
+void orc_ecef2aer(const double *obs_lla, const double *sat, const double *obs, double *aer)
+{
+    real l[3], s[3], o[3], a[3];
+    ld(obs_lla, l, 3); ld(sat, s, 3); ld(obs, o, 3);
+    ecef2aer(l, s, o, a);
+    st(a, aer, 3);
+}
+void orc_lla2ecef(const double *lla, double *ecef)
+{
+    real l[3], e[3];
+    ld(lla, l, 3);
+    lla2ecef(l, e);
+    st(e, ecef, 3);
+}
+void orc_mean_z_uvw(const double *sig, int npts, const double *Wm, int centred, double *zp)
+{
+    real *s = (real *)malloc(sizeof(real) * 3 * (size_t)npts);
+    real *w = (real *)malloc(sizeof(real) * (size_t)npts), z[3];
+    ld(sig, s, 3 * npts); ld(Wm, w, npts);
+    mean_z_uvw(s, npts, w, centred, z);
+    st(z, zp, 3);
+    free(s); free(w);
+}
+void orc_residual_z_aer(const double *a, const double *b, double *c, long n)
+{
+    for (long j = 0; j < n; ++j) {
+        real aa[3], bb[3], cc[3];
+        ld(a + 3 * j, aa, 3); ld(b + 3 * j, bb, 3);
+        residual_z_aer(aa, bb, cc);
+        st(cc, c + 3 * j, 3);
+    }
+}
+
+/* one filter: predict (status returned; x, P, sigmas_f overwritten) */
+int orc_ukf_predict(double *x, double *P, const double *Q, double dt, double scale, const double *Wm,
+                    const double *Wc, int centred, double *sigmas_f)
+{
+    real xx[6], pp[36], qq[36], wm[NS], wc[NS], sf[NS * NX];
+    ld(x, xx, 6); ld(P, pp, 36); ld(Q, qq, 36); ld(Wm, wm, NS); ld(Wc, wc, NS);
+    memset(sf, 0, sizeof sf);
+    int rc = ukf_predict(xx, pp, qq, (real)dt, (real)scale, wm, wc, centred, sf);
+    st(xx, x, 6); st(pp, P, 36); st(sf, sigmas_f, NS * NX);
+    return rc;
+}
+int orc_ukf_update(double *x, double *P, double *sigmas_f, const double *z, const double *R, const double *Wm,
+                   const double *Wc, double scale, int obs_type, int centred, int resample, const double *M,
+                   const double *obs_lla, const double *obs_itrs, double *y, double *S, double *sigmas_h)
+{
+    real xx[6], pp[36], sf[NS * NX], zz[3], rr[9], wm[NS], wc[NS], m[9], l[3], o[3], yy[3], ss[9], sh[NS * NZ];
+    ld(x, xx, 6); ld(P, pp, 36); ld(sigmas_f, sf, NS * NX); ld(z, zz, 3); ld(R, rr, 9);
+    ld(Wm, wm, NS); ld(Wc, wc, NS); ld(M, m, 9); ld(obs_lla, l, 3); ld(obs_itrs, o, 3);
+    memset(yy, 0, sizeof yy); memset(ss, 0, sizeof ss); memset(sh, 0, sizeof sh);
+    int rc = ukf_update(xx, pp, sf, zz, rr, wm, wc, (real)scale, obs_type, centred, resample, m, l, o, yy, ss, sh);
+    st(xx, x, 6); st(pp, P, 36); st(sf, sigmas_f, NS * NX); st(yy, y, 3); st(ss, S, 9); st(sh, sigmas_h, NS * NZ);
+    return rc;
+}
+
+/* O1/O2: observations + error (envs/results.py:61, :37).  metrics = [delta_pos | delta_vel |
+ * sigma_pos | sigma_vel], each of length m. */
+void orc_observe(const double *x_true, const double *x, const double *P, double *obs, double *metrics, long m)
+{
+    for (long j = 0; j < m; ++j) {
+        for (int c = 0; c < 6; ++c) {
+            obs[12 * j + c] = x[6 * j + c];
+            obs[12 * j + 6 + c] = P[36 * j + 7 * c];
+        }
+        real dp = 0, dv = 0, sp = 0, sv = 0;
+        for (int c = 0; c < 3; ++c) {
+            real a = (real)obs[12 * j + c] - (real)x_true[6 * j + c];
+            real b = (real)obs[12 * j + 3 + c] - (real)x_true[6 * j + 3 + c];
+            dp += a * a; dv += b * b;
+            sp += (real)obs[12 * j + 6 + c];
+            sv += (real)obs[12 * j + 9 + c];
+        }
+        metrics[j] = (double)F(sqrt)(dp);
+        metrics[m + j] = (double)F(sqrt)(dv);
+        metrics[2 * m + j] = (double)F(sqrt)(sp);
+        metrics[3 * m + j] = (double)F(sqrt)(sv);
+    }
+}
+
+/* E1: one whole env step for m objects (ssa_tasker_simple_2.py:243-367), the unit the
+ * CPU baseline times.  status[m] persists across steps (0 = healthy).
+ * action < 0 or do_update == 0 -> no update this step.
+ * upd_out[0]=obs_taken, [1..3]=z_true, [4..6]=y, [7..15]=S ; sigmas_h_out[13*3].
+ * x_failed / P_failed sentinels :157-158. */
+void orc_env_step(const double *x_true_in, double *x_true_out, const double *x_in, const double *P_in,
+                  double *x_out, double *P_out, int *status, long m, double dt, const double *Q, const double *R,
+                  double scale, const double *Wm, const double *Wc, int centred, int resample, int obs_type,
+                  long action, int do_update, const double *M, const double *obs_lla, const double *obs_itrs,
+                  double obs_limit, const double *z_noise3, double *obs, double *metrics, double *upd_out,
+                  double *sigmas_h_out)
+{
+    static const double XF[6] = {1e20, 1e20, 1e20, 1e12, 1e12, 1e12};
+    real qq[36], rr[9], wm[NS], wc[NS], mm[9], ll[3], oo[3];
+    ld(Q, qq, 36); ld(R, rr, 9); ld(Wm, wm, NS); ld(Wc, wc, NS); ld(M, mm, 9); ld(obs_lla, ll, 3); ld(obs_itrs, oo, 3);
+    for (int c = 0; c < 16; ++c) upd_out[c] = (c == 0) ? 0.0 : NAN;
+    for (long j = 0; j < m; ++j) { /* propagate next true state (:265-266) */
+        real x[6], o[6];
+        ld(x_true_in + 6 * j, x, 6);
+        fx_farnocchia(x, (real)dt, o);
+        st(o, x_true_out + 6 * j, 6);
+    }
+    for (long j = 0; j < m; ++j) { /* perform predictions (:271-287) */
+        real x[6], P[36], sf[NS * NX];
+        ld(x_in + 6 * j, x, 6); ld(P_in + 36 * j, P, 36);
+        int fail = status[j];
+        if (!fail) {
+            int rc = ukf_predict(x, P, qq, (real)dt, (real)scale, wm, wc, centred, sf);
+            if (rc != ST_OK) { status[j] = rc; fail = 1; }
+        }
+        if (!fail && do_update && j == action) { /* update with observation (:292-315) */
+            real xt[6], zt[3], z[3], y[3], S[9], sh[NS * NZ];
+            ld(x_true_out + 6 * j, xt, 6);
+            real aer[3];
+            hx_aer(xt, mm, ll, oo, aer);
+            if (obs_type == 0) { zt[0] = aer[0]; zt[1] = aer[1]; zt[2] = aer[2]; }
+            else { zt[0] = xt[0]; zt[1] = xt[1]; zt[2] = xt[2]; }
+            st(zt, upd_out + 1, 3);
+            if (aer[1] >= (real)obs_limit) { /* object_visible (:418-425) uses the true elevation */
+                for (int c = 0; c < 3; ++c) z[c] = (real)((double)zt[c] + z_noise3[c]);
+                int rc = ukf_update(x, P, sf, z, rr, wm, wc, (real)scale, obs_type, centred, resample, mm, ll, oo, y, S, sh);
+                if (rc == ST_OK || rc == ST_UPDATE_NAN) {
+                    upd_out[0] = 1.0;
+                    st(y, upd_out + 4, 3); st(S, upd_out + 7, 9); st(sh, sigmas_h_out, NS * NZ);
+                }
+                if (rc != ST_OK) { status[j] = rc; fail = 1; }
+            }
+        }
+        if (fail) {
+            for (int a = 0; a < 6; ++a) {
+                x_out[6 * j + a] = XF[a];
+                for (int b = 0; b < 6; ++b) P_out[36 * j + 6 * a + b] = (a == b) ? XF[a] : 0.0;
+            }
+        } else {
+            st(x, x_out + 6 * j, 6); st(P, P_out + 36 * j, 36);
+        }
+    }
+    orc_observe(x_true_out, x_out, P_out, obs, metrics, m);
+}
+
+/* O4 aer_obs (ssa_tasker_simple_2.py:834-840): [hx(x_filter[:3]) , trace(P)], NaN/inf -> 0.001 */
+void orc_aer_obs(const double *x, const double *P, const double *M, const double *obs_lla,
+                 const double *obs_itrs, double *out, long m)
+{
+    real mm[9], ll[3], oo[3];
+    ld(M, mm, 9); ld(obs_lla, ll, 3); ld(obs_itrs, oo, 3);
+    for (long j = 0; j < m; ++j) {
+        real xx[3], z[3], tr = 0;
+        ld(x + 6 * j, xx, 3);
+        hx_aer(xx, mm, ll, oo, z);
+        for (int c = 0; c < 6; ++c) tr += (real)P[36 * j + 7 * c];
+        double v[4] = {(double)z[0], (double)z[1], (double)z[2], (double)tr};
+        for (int c = 0; c < 4; ++c) out[4 * j + c] = isfinite(v[c]) ? v[c] : 0.001;
+    }
+}
+
+int orc_is_long_double(void)
+{
+#ifdef ORC_LONG
+    return 1;
+#else
+    return 0;
+#endif
+}
