@@ -1,0 +1,165 @@
+/*
+ * ssa_hip.h -- C ABI of libssa_hip.so: the MI355X (gfx950) implementation of
+ * ssa-gym's per-step hot path (propagate -> UKF predict -> one UKF update ->
+ * observation / error metrics / reward statistics).
+ *
+ * The reference (AshHarvey/ssa-gym) is pure Python and has no FFI of its own;
+ * the boundary it exposes is the gym.Env class plus the operator callables in
+ * its env_config dict (envs/__init__.py:23-28).  This library sits directly
+ * below that class: every entry point replaces the per-object Python loop or
+ * numba/filterpy/LAPACK call cited next to it (file:line under the reference
+ * root).  INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (hipMalloc / torch.Tensor.data_ptr())
+ *     unless the parameter name ends in _host;
+ *   - arrays are float64, C-contiguous, array-of-structures exactly as the
+ *     reference's numpy arrays: states [n][6] (m, m/s, GCRS), covariances
+ *     [n][6][6], observations [n][12], measurements [n][3];
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *     launches are asynchronous, nothing synchronises;
+ *   - every function returns 0 on success or a negative SSA_E_* code; no
+ *     exceptions, no allocation, no host<->device copies -> all entry points
+ *     are hipGraph-capturable.
+ */
+#ifndef SSA_HIP_H
+#define SSA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSA_ABI_VERSION 1
+
+/* error codes */
+#define SSA_OK 0
+#define SSA_E_INVALID (-1) /* bad size / null pointer / unknown flag */
+#define SSA_E_LAUNCH (-2)  /* hipGetLastError() != hipSuccess after launch */
+
+/* per-object filter status (int32), persists across steps.
+ * ssa_tasker_simple_2.py:271-285, 300-313, 369-382 (filter_error): a failed filter is
+ * overwritten with the sentinels x_failed / P_failed (:157-158) and skipped afterwards. */
+#define SSA_ST_OK 0
+#define SSA_ST_PREDICT_NAN 1    /* ', predict returned nan. ' */
+#define SSA_ST_PREDICT_LINALG 2 /* robust_cholesky ladder exhausted -> LinAlgError */
+#define SSA_ST_UPDATE_NAN 3     /* ', update returned nan. ' */
+#define SSA_ST_UPDATE_LINALG 4  /* inv(S) singular -> LinAlgError */
+
+/* observation model of the update (env_config['obs_type'], ssa_tasker_simple_2.py:98-107) */
+#define SSA_OBS_AER 0 /* hx_aer_erfa + mean_z_uvw + residual_z_aer (dynamics.py:219,343,260) */
+#define SSA_OBS_XYZ 1 /* hx_xyz + mean_xyz + residual_xyz/np.subtract (dynamics.py:207,276,271) */
+
+/* two-body propagator variant; both evaluate envs/farnocchia.py:1010 farnocchia() */
+#define SSA_PROP_ELEMENTS 0 /* rv2coe -> delta_t_from_nu -> nu_from_delta_t -> coe2rv, operation by operation */
+#define SSA_PROP_FG 1       /* strong-elliptic branch reduced algebraically to Lagrange f,g in the
+                               eccentric-anomaly difference; every other branch falls back to ELEMENTS */
+
+/* flags of ssa_step_params.flags */
+#define SSA_FLAG_RESAMPLE 1u /* redraw sigma points from the prior before update() (filterpy-master predict()) */
+
+/* layout of the per-env update record written by ssa_env_step_f64 (doubles) */
+#define SSA_UPD_STRIDE 64
+#define SSA_UPD_OBS_TAKEN 0 /* 1.0 if filters[a].update() ran (obs_taken[i], :305) */
+#define SSA_UPD_Z_TRUE 1    /* [3] hx(x_true[i][a])                      (:298) */
+#define SSA_UPD_Y 4         /* [3] innovation                            (:302) */
+#define SSA_UPD_S 7         /* [3][3] innovation covariance              (:303) */
+#define SSA_UPD_SIGMAS_H 16 /* [13][3] measurement sigma points          (:304) */
+#define SSA_UPD_VISIBLE 55  /* 1.0 if object_visible([a])                (:299) */
+#define SSA_UPD_ACTION 56   /* the action this record belongs to (as double), -1 = no update attempted */
+
+/* layout of the per-env reward statistics written by ssa_reward_stats_f64 (doubles) */
+#define SSA_STAT_STRIDE 8
+#define SSA_STAT_MAX_DPOS 0   /* np.max(delta_pos[i])  (NaN-propagating)        (:325-343) */
+#define SSA_STAT_CNT_LT_1E4 1 /* count(delta_pos < 1e4)  } results.py:432        */
+#define SSA_STAT_CNT_LT_1E7 2 /* count(delta_pos < 1e7)  } reward_proportional_trinary_true */
+#define SSA_STAT_ARGMAX_SPOS 3 /* np.argmax(sigma_pos[i]) (first max; 'shaped' uses it next step, :346) */
+#define SSA_STAT_N_FAILED 4   /* number of objects with status != 0 */
+#define SSA_STAT_MAX_SPOS 5   /* np.max(sigma_pos[i]) */
+
+/* Constants of one environment family; built on the host, passed by value. */
+typedef struct ssa_consts {
+    double Q[36];       /* process noise, Q_discrete_white_noise (ssa_tasker_simple_2.py:110) */
+    double R[9];        /* measurement noise (:128-131) */
+    double Wm0, Wc0, Wi; /* Merwe weights: Wm[0], Wc[0], Wm[i]=Wc[i] (i>=1) (filterpy, :211-214) */
+    double sum_wm_m1;   /* sum(Wm) - 1 evaluated exactly from the double weights */
+    double sum_wc;      /* sum(Wc) evaluated exactly from the double weights */
+    double scale;       /* n + lambda */
+    double dt;          /* time_step [s] */
+    double obs_limit;   /* elevation mask [rad] (:86) */
+    double enu[9];      /* ecef2aer's trans_uvw_ecef matrix for the observer (transformations.py:341-343) */
+    double obs_itrs[3]; /* lla2ecef(observer) (transformations.py:217) */
+    int32_t obs_type;   /* SSA_OBS_* */
+    int32_t propagator; /* SSA_PROP_* */
+    uint32_t flags;     /* SSA_FLAG_* */
+    int32_t update_interval; /* env_config['update_interval'] (:292) */
+} ssa_consts;
+
+/* One env step for n_env independent environments of n_obj objects each
+ * (object g = e * n_obj + j).  Replaces SSA_Tasker_Env.step() lines 265-322. */
+typedef struct ssa_step_params {
+    int64_t n_obj; /* m */
+    int32_t n_env; /* E (1 for the plain gym env) */
+    int32_t time_offset; /* added to env_time[e] (lets a captured / looped launch advance time) */
+    const double *x_true_in; double *x_true_out; /* [E*m][6]  x_true[i-1] -> x_true[i]   (:265-266) */
+    const double *x_in;      double *x_out;      /* [E*m][6]  filters[j].x               (:275,286) */
+    const double *P_in;      double *P_out;      /* [E*m][6][6] filters[j].P             (:275,287) */
+    int32_t *status;                             /* [E*m] in/out, SSA_ST_*               (:272,293) */
+    double *obs;     /* [E*m][12]  observations(x, P)                     (results.py:61)  */
+    double *metrics; /* [E][4][m]  delta_pos | delta_vel | sigma_pos | sigma_vel (results.py:37) */
+    double *upd;     /* [E][SSA_UPD_STRIDE] update record, may be NULL */
+    const double *trans;       /* [n_time][3][3] GCRS->ITRS matrices (trans_matrix, :137) */
+    const int32_t *env_time;   /* [E] time index i of this step per env (after the increment of :259) */
+    const int32_t *actions;    /* [E] object chosen per env, < 0 = no update */
+    const double *z_noise;     /* measurement noise; element (e, i, a) at
+                                  z_noise + e*zn_stride_env + i*zn_stride_time + a*3   (:219-221) */
+    int64_t zn_stride_env, zn_stride_time;
+    int32_t n_time;            /* rows in `trans` (bounds check: i % n_time) */
+    int32_t reserved;
+} ssa_step_params;
+
+/* ---------------------------------------------------------------- fused hot path */
+int ssa_env_step_f64(const ssa_consts *c_host, const ssa_step_params *p_host, void *stream);
+
+/* O3: per-env reductions over metrics[E][4][m] and status -> stats[E][SSA_STAT_STRIDE]
+ * (ssa_tasker_simple_2.py:324-354, results.py:432). */
+int ssa_reward_stats_f64(const double *metrics, const int32_t *status, double *stats, int64_t n_obj,
+                         int32_t n_env, void *stream);
+
+/* ----------------------------------------------------- single operators (rows of SURVEY 8a) */
+/* P1-P5  fx_xyz_farnocchia(x, dt) for n states (farnocchia.py:1054). */
+int ssa_propagate_f64(const double *x_in, double *x_out, int64_t n, double dt, int32_t propagator, void *stream);
+/* P2-P4 diagnostics: coe[n][8] = p, ecc, inc, raan, argp, nu0, delta_t0, nu(dt)  (farnocchia.py:165,847,925). */
+int ssa_kepler_elements_f64(const double *x_in, double *coe, int64_t n, double dt, void *stream);
+/* U2  robust_cholesky(A) for n 6x6 matrices: U upper (zeros below), rung[n] = -1 (no jitter),
+ * 0..15 (10^(rung-6) added), 16 = LinAlgError (dynamics.py:402). */
+int ssa_robust_cholesky6_f64(const double *A, double *U, int32_t *rung, int64_t n, void *stream);
+/* U1  MerweScaledSigmaPoints.sigma_points(x, P): sig[n][13][6], fail[n] (0 / SSA_ST_PREDICT_LINALG). */
+int ssa_sigma_points_f64(const double *x, const double *P, double scale, double *sig, int32_t *fail,
+                         int64_t n, void *stream);
+/* H1  hx_aer_erfa for n states sharing one matrix M[9] (device pointer) (dynamics.py:219). */
+int ssa_hx_aer_f64(const double *x, int64_t x_stride, const double *M, const ssa_consts *c_host, double *z,
+                   int64_t n, void *stream);
+/* H3  mean_z_uvw(sigmas[n][13][3], Wm) with the Merwe weights of c_host (dynamics.py:343). */
+int ssa_mean_z_uvw_f64(const double *sigmas, const ssa_consts *c_host, double *zp, int64_t n, void *stream);
+/* H4  residual_z_aer(a[n][3], b[n][3]) (dynamics.py:260). */
+int ssa_residual_z_aer_f64(const double *a, const double *b, double *c, int64_t n, void *stream);
+/* V1  object_visibility(): mask[n] = elevation(x_true) >= obs_limit; el[n] optional (:418-434). */
+int ssa_visible_mask_f64(const double *x_true, const double *M, const ssa_consts *c_host, uint8_t *mask,
+                         double *el, int64_t n, void *stream);
+/* O1/O2  observations() + error() for n objects of one env (results.py:61,37); metrics[4][n]. */
+int ssa_observe_f64(const double *x_true, const double *x, const double *P, double *obs, double *metrics,
+                    int64_t n, void *stream);
+/* O4  aer_obs(): out[n][4] = hx(x_filter), trace(P); NaN/inf -> 0.001 (ssa_tasker_simple_2.py:834). */
+int ssa_aer_obs_f64(const double *x, const double *P, const double *M, const ssa_consts *c_host, double *out,
+                    int64_t n, void *stream);
+
+/* library identification */
+int ssa_abi_version(void);
+const char *ssa_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSA_HIP_H */

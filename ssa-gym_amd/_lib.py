@@ -1,0 +1,98 @@
+"""ctypes binding of libssa_hip.so (include/ssa_hip.h).
+
+There is NO CPU fallback: if the library is missing or a call fails this module
+raises.  Use `_build.build_library()` (or `python __graft_entry__.py`) to build it.
+"""
+import ctypes as C
+import os
+
+from . import _build
+
+c_dp = C.c_void_p  # device pointers travel as integers
+
+
+class ssa_consts(C.Structure):
+    _fields_ = [
+        ("Q", C.c_double * 36), ("R", C.c_double * 9),
+        ("Wm0", C.c_double), ("Wc0", C.c_double), ("Wi", C.c_double),
+        ("sum_wm_m1", C.c_double), ("sum_wc", C.c_double), ("scale", C.c_double),
+        ("dt", C.c_double), ("obs_limit", C.c_double),
+        ("enu", C.c_double * 9), ("obs_itrs", C.c_double * 3),
+        ("obs_type", C.c_int32), ("propagator", C.c_int32), ("flags", C.c_uint32),
+        ("update_interval", C.c_int32),
+    ]
+
+
+class ssa_step_params(C.Structure):
+    _fields_ = [
+        ("n_obj", C.c_int64), ("n_env", C.c_int32), ("time_offset", C.c_int32),
+        ("x_true_in", c_dp), ("x_true_out", c_dp), ("x_in", c_dp), ("x_out", c_dp),
+        ("P_in", c_dp), ("P_out", c_dp), ("status", c_dp), ("obs", c_dp), ("metrics", c_dp),
+        ("upd", c_dp), ("trans", c_dp), ("env_time", c_dp), ("actions", c_dp), ("z_noise", c_dp),
+        ("zn_stride_env", C.c_int64), ("zn_stride_time", C.c_int64),
+        ("n_time", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+# constants of include/ssa_hip.h
+ABI_VERSION = 1
+ST_OK, ST_PREDICT_NAN, ST_PREDICT_LINALG, ST_UPDATE_NAN, ST_UPDATE_LINALG = range(5)
+OBS_AER, OBS_XYZ = 0, 1
+PROP_ELEMENTS, PROP_FG = 0, 1
+FLAG_RESAMPLE = 1
+UPD_STRIDE, UPD_OBS_TAKEN, UPD_Z_TRUE, UPD_Y, UPD_S, UPD_SIGMAS_H, UPD_VISIBLE, UPD_ACTION = 64, 0, 1, 4, 7, 16, 55, 56
+STAT_STRIDE, STAT_MAX_DPOS, STAT_CNT_LT_1E4, STAT_CNT_LT_1E7, STAT_ARGMAX_SPOS, STAT_N_FAILED, STAT_MAX_SPOS = 8, 0, 1, 2, 3, 4, 5
+
+# every symbol the header declares, with its ctypes signature
+SIGNATURES = {
+    "ssa_abi_version": (C.c_int, []),
+    "ssa_build_info": (C.c_char_p, []),
+    "ssa_env_step_f64": (C.c_int, [C.POINTER(ssa_consts), C.POINTER(ssa_step_params), c_dp]),
+    "ssa_reward_stats_f64": (C.c_int, [c_dp, c_dp, c_dp, C.c_int64, C.c_int32, c_dp]),
+    "ssa_propagate_f64": (C.c_int, [c_dp, c_dp, C.c_int64, C.c_double, C.c_int32, c_dp]),
+    "ssa_kepler_elements_f64": (C.c_int, [c_dp, c_dp, C.c_int64, C.c_double, c_dp]),
+    "ssa_robust_cholesky6_f64": (C.c_int, [c_dp, c_dp, c_dp, C.c_int64, c_dp]),
+    "ssa_sigma_points_f64": (C.c_int, [c_dp, c_dp, C.c_double, c_dp, c_dp, C.c_int64, c_dp]),
+    "ssa_hx_aer_f64": (C.c_int, [c_dp, C.c_int64, c_dp, C.POINTER(ssa_consts), c_dp, C.c_int64, c_dp]),
+    "ssa_mean_z_uvw_f64": (C.c_int, [c_dp, C.POINTER(ssa_consts), c_dp, C.c_int64, c_dp]),
+    "ssa_residual_z_aer_f64": (C.c_int, [c_dp, c_dp, c_dp, C.c_int64, c_dp]),
+    "ssa_visible_mask_f64": (C.c_int, [c_dp, c_dp, C.POINTER(ssa_consts), c_dp, c_dp, C.c_int64, c_dp]),
+    "ssa_observe_f64": (C.c_int, [c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int64, c_dp]),
+    "ssa_aer_obs_f64": (C.c_int, [c_dp, c_dp, c_dp, C.POINTER(ssa_consts), c_dp, C.c_int64, c_dp]),
+}
+
+_lib = None
+
+
+class SsaHipError(RuntimeError):
+    pass
+
+
+def library_path():
+    return _build.LIB
+
+
+def load():
+    """dlopen libssa_hip.so and bind every declared symbol; raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise SsaHipError(
+            "libssa_hip.so is not built (%s). The ssa-gym hot path has no CPU fallback: run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc)." % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ssa_abi_version() != ABI_VERSION:
+        raise SsaHipError("libssa_hip.so ABI %d != binding %d: rebuild" % (lib.ssa_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SsaHipError("%s failed with code %d" % (what, rc))

@@ -1,0 +1,998 @@
+// ssa_kernels.hip -- gfx950 kernels + C ABI (include/ssa_hip.h) for the ssa-gym hot path.
+//
+// Mapping (DESIGN.md "Kernel"): one 16-lane DPP row of a wavefront owns one object:
+//   lane 0      sigma_0 = x
+//   lanes 1-6   x + U[k]        lanes 7-12  x - U[k]       (U = robust_cholesky((n+lambda) P), rows)
+//   lane 13     the TRUE state of the same object (x_true[i-1] -> x_true[i])
+//   lanes 14-15 idle
+// so one wavefront advances 4 objects and every Kepler solve of the step (13 m sigma points
+// + m true states) runs in its own lane.  State / covariance tiles are staged through LDS
+// with block-contiguous (fully coalesced) global loads and stores; the 13-point mean is a
+// DPP row reduction; the covariance outer products run from LDS.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ssa_hip.h"
+#include "ssa_math.hpp"
+
+namespace ssa {
+
+// ------------------------------------------------------------------------------------------
+// Complete farnocchia() restatement (all conic branches).  Scalar, out of line.
+// farnocchia.py:165-313 (rv2coe), :847-921 (delta_t_from_nu), :925-1006 (nu_from_delta_t),
+// :337-353 (newton), :692-843 (near-parabolic series), :101-161 (coe2rv).
+namespace gen {
+__device__ static double pymod(double a, double b)
+{
+    double m = fmod(a, b);
+    if (m != 0.0 && ((m < 0.0) != (b < 0.0))) m += b;
+    return m;
+}
+__device__ static double newton(bool hyper, double x0, double M, double ecc, int maxiter)
+{
+    double p0 = x0;
+    for (int i = 0; i < maxiter; ++i) {
+        double fval, fder;
+        if (hyper) {
+            fval = (ecc * sinh(p0) - p0) - M;
+            fder = ecc * cosh(p0) - 1.0;
+        } else {
+            fval = (p0 - ecc * sin(p0)) - M;
+            fder = 1.0 - ecc * cos(p0);
+        }
+        double p = p0 - fval / fder;
+        if (fabs(p - p0) < NEWTON_TOL) return p;
+        p0 = p;
+    }
+    return __builtin_nan("");
+}
+__device__ static double S_x(double ecc, double x, bool alt)
+{
+    double S = 0.0, xk = 1.0;
+    for (int k = 0; k < 100000; ++k) {
+        double S_old = S;
+        double term = (ecc - 1.0 / (2 * k + 3)) * xk;
+        S += alt ? term * (2 * k + 3) : term;
+        xk *= x;
+        if (fabs(S - S_old) < 1e-12) return S;
+    }
+    return __builtin_nan("");
+}
+__device__ static double D_to_M_np(double D, double ecc)
+{
+    double x = (ecc - 1.0) / (ecc + 1.0) * (D * D);
+    double S = S_x(ecc, x, false);
+    double ope = 1.0 + ecc;
+    return sqrt(2.0 / ope) * D + sqrt(2.0 / (ope * ope * ope)) * (D * D * D) * S;
+}
+__device__ static double M_to_D(double M)
+{
+    double B = 3.0 * M / 2.0;
+    double A = pow(B + sqrt(1.0 + B * B), 2.0 / 3.0);
+    return 2.0 * A * B / (1.0 + A + A * A);
+}
+__device__ static double M_to_D_np(double M, double ecc)
+{
+    double D0 = M_to_D(M);
+    double ope = 1.0 + ecc;
+    for (int i = 0; i < 50; ++i) {
+        double fval = D_to_M_np(D0, ecc) - M;
+        double x = (ecc - 1.0) / ope * (D0 * D0);
+        double S = S_x(ecc, x, true);
+        double fder = sqrt(2.0 / ope) + sqrt(2.0 / (ope * ope * ope)) * (D0 * D0) * S;
+        double D = D0 - fval / fder;
+        if (fabs(D - D0) < NEWTON_TOL) return D;
+        D0 = D;
+    }
+    return __builtin_nan("");
+}
+__device__ static double E_to_nu(double E, double ecc) { return 2.0 * atan(sqrt((1.0 + ecc) / (1.0 - ecc)) * tan(E / 2.0)); }
+__device__ static double nu_to_E(double nu, double ecc) { return 2.0 * atan(sqrt((1.0 - ecc) / (1.0 + ecc)) * tan(nu / 2.0)); }
+__device__ static double F_to_nu(double F, double ecc) { return 2.0 * atan(sqrt((ecc + 1.0) / (ecc - 1.0)) * tanh(F / 2.0)); }
+__device__ static double nu_to_F(double nu, double ecc) { return 2.0 * atanh(sqrt((ecc - 1.0) / (ecc + 1.0)) * tan(nu / 2.0)); }
+
+__device__ static double delta_t_from_nu(double nu, double ecc, double k, double q)
+{
+    const double delta = 1e-2;
+    double M, n;
+    double q3 = q * q * q;
+    if (ecc < 1.0 - delta) {
+        double E = nu_to_E(nu, ecc);
+        M = E - ecc * sin(E);
+        n = sqrt(k * (1.0 - ecc) * (1.0 - ecc) * (1.0 - ecc) / q3);
+    } else if (1.0 - delta <= ecc && ecc < 1.0) {
+        double E = nu_to_E(nu, ecc);
+        if (delta <= 1.0 - ecc * cos(E)) {
+            M = E - ecc * sin(E);
+            n = sqrt(k * (1.0 - ecc) * (1.0 - ecc) * (1.0 - ecc) / q3);
+        } else {
+            M = D_to_M_np(tan(nu / 2.0), ecc);
+            n = sqrt(k / (2.0 * q3));
+        }
+    } else if (ecc == 1.0) {
+        double D = tan(nu / 2.0);
+        M = D + D * D * D / 3.0;
+        n = sqrt(k / (2.0 * q3));
+    } else if (1.0 + ecc * cos(nu) < 0.0) {
+        return __builtin_nan("");
+    } else if (1.0 < ecc && ecc <= 1.0 + delta) {
+        double F = nu_to_F(nu, ecc);
+        if (delta <= ecc * cosh(F) - 1.0) {
+            M = ecc * sinh(F) - F;
+            n = sqrt(k * (ecc - 1.0) * (ecc - 1.0) * (ecc - 1.0) / q3);
+        } else {
+            M = D_to_M_np(tan(nu / 2.0), ecc);
+            n = sqrt(k / (2.0 * q3));
+        }
+    } else if (1.0 + delta < ecc) {
+        double F = nu_to_F(nu, ecc);
+        M = ecc * sinh(F) - F;
+        n = sqrt(k * (ecc - 1.0) * (ecc - 1.0) * (ecc - 1.0) / q3);
+    } else {
+        return __builtin_nan("");
+    }
+    return M / n;
+}
+__device__ static double M_to_E(double M, double ecc)
+{
+    double E0 = (ecc < 0.8) ? M : PI * ((M > 0.0) - (M < 0.0));
+    return newton(false, E0, M, ecc, 50);
+}
+__device__ static double nu_from_delta_t(double delta_t, double ecc, double k, double q)
+{
+    const double delta = 1e-2;
+    double q3 = q * q * q;
+    if (ecc < 1.0 - delta) {
+        double n = sqrt(k * (1.0 - ecc) * (1.0 - ecc) * (1.0 - ecc) / q3);
+        double M = n * delta_t;
+        return E_to_nu(M_to_E(pymod(M + PI, TWO_PI) - PI, ecc), ecc);
+    } else if (1.0 - delta <= ecc && ecc < 1.0) {
+        double E_delta = acos((1.0 - delta) / ecc);
+        double n = sqrt(k * (1.0 - ecc) * (1.0 - ecc) * (1.0 - ecc) / q3);
+        double M = n * delta_t;
+        if (E_delta - ecc * sin(E_delta) <= fabs(M))
+            return E_to_nu(M_to_E(pymod(M + PI, TWO_PI) - PI, ecc), ecc);
+        n = sqrt(k / (2.0 * q3));
+        return 2.0 * atan(M_to_D_np(n * delta_t, ecc));
+    } else if (ecc == 1.0) {
+        double n = sqrt(k / (2.0 * q3));
+        return 2.0 * atan(M_to_D(n * delta_t));
+    } else if (1.0 < ecc && ecc <= 1.0 + delta) {
+        double F_delta = acosh((1.0 + delta) / ecc);
+        double n = sqrt(k * (ecc - 1.0) * (ecc - 1.0) * (ecc - 1.0) / q3);
+        double M = n * delta_t;
+        if (ecc * sinh(F_delta) - F_delta <= fabs(M))
+            return F_to_nu(newton(true, asinh(M / ecc), M, ecc, 100), ecc);
+        n = sqrt(k / (2.0 * q3));
+        return 2.0 * atan(M_to_D_np(n * delta_t, ecc));
+    } else {
+        double n = sqrt(k * (ecc - 1.0) * (ecc - 1.0) * (ecc - 1.0) / q3);
+        double M = n * delta_t;
+        return F_to_nu(newton(true, asinh(M / ecc), M, ecc, 100), ecc);
+    }
+}
+}  // namespace gen
+
+__device__ __noinline__ void kepler_general(const double* x, double tof, double* out, double* diag)
+{
+    const double tol = 1e-8;
+    const double* r = x;
+    const double* v = x + 3;
+    double h[3] = {r[1] * v[2] - r[2] * v[1], r[2] * v[0] - r[0] * v[2], r[0] * v[1] - r[1] * v[0]};
+    double n[3] = {-h[1], h[0], 0.0};
+    double rn = sqrt(dot3(r, r)), vv = dot3(v, v), rv = dot3(r, v);
+    double c1 = vv - MU / rn;
+    double e[3] = {(c1 * r[0] - rv * v[0]) / MU, (c1 * r[1] - rv * v[1]) / MU, (c1 * r[2] - rv * v[2]) / MU};
+    double ecc = sqrt(dot3(e, e));
+    double p = dot3(h, h) / MU;
+    double hn = sqrt(dot3(h, h));
+    double inc = acos(h[2] / hn);
+    bool circular = ecc < tol, equatorial = fabs(inc) < tol;
+    double raan, argp, nu;
+    if (equatorial && !circular) {
+        raan = 0.0;
+        argp = gen::pymod(atan2(e[1], e[0]), TWO_PI);
+        double t[3] = {e[1] * r[2] - e[2] * r[1], e[2] * r[0] - e[0] * r[2], e[0] * r[1] - e[1] * r[0]};
+        nu = atan2(dot3(h, t) / hn, dot3(r, e));
+    } else if (!equatorial && circular) {
+        raan = gen::pymod(atan2(n[1], n[0]), TWO_PI);
+        argp = 0.0;
+        double t[3] = {h[1] * n[2] - h[2] * n[1], h[2] * n[0] - h[0] * n[2], h[0] * n[1] - h[1] * n[0]};
+        nu = atan2(dot3(r, t) / hn, dot3(r, n));
+    } else if (equatorial && circular) {
+        raan = 0.0;
+        argp = 0.0;
+        nu = gen::pymod(atan2(r[1], r[0]), TWO_PI);
+    } else {
+        double a = p / (1.0 - ecc * ecc);
+        double ka = MU * a;
+        if (a > 0.0) {
+            double e_se = rv / sqrt(ka);
+            double e_ce = rn * vv / MU - 1.0;
+            nu = gen::E_to_nu(atan2(e_se, e_ce), ecc);
+        } else {
+            double e_sh = rv / sqrt(-ka);
+            double e_ch = rn * vv / MU - 1.0;
+            nu = gen::F_to_nu(log((e_ch + e_sh) / (e_ch - e_sh)) / 2.0, ecc);
+        }
+        raan = gen::pymod(atan2(n[1], n[0]), TWO_PI);
+        double t[3] = {h[1] * n[2] - h[2] * n[1], h[2] * n[0] - h[0] * n[2], h[0] * n[1] - h[1] * n[0]};
+        double px = dot3(r, n), py = dot3(r, t) / hn;
+        argp = gen::pymod(atan2(py, px) - nu, TWO_PI);
+    }
+    nu = gen::pymod(nu + PI, TWO_PI) - PI;
+    double q = p / (1.0 + ecc);
+    double dt0 = gen::delta_t_from_nu(nu, ecc, MU, q);
+    double nu1 = gen::nu_from_delta_t(dt0 + tof, ecc, MU, q);
+    coe2rv(p, ecc, inc, raan, argp, nu1, out);
+    if (diag) {
+        diag[0] = p; diag[1] = ecc; diag[2] = inc; diag[3] = raan; diag[4] = argp; diag[5] = nu;
+        diag[6] = dt0; diag[7] = nu1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fused env step
+struct StepK {
+    ssa_consts c;
+    ssa_step_params p;
+};
+
+constexpr int OBJ_PER_WAVE = 4;
+constexpr double X_FAILED_POS = 1e20, X_FAILED_VEL = 1e12;  // ssa_tasker_simple_2.py:157-158
+
+template <int PROP>
+__global__ void __launch_bounds__(64) step_kernel(const StepK k)
+{
+    __shared__ double sP[OBJ_PER_WAVE * 36];       // P_in tile, later P_out tile
+    __shared__ double sX[OBJ_PER_WAVE * 6];        // x_in tile, later x_out tile
+    __shared__ double sT[OBJ_PER_WAVE * 6];        // x_true_in tile, later x_true_out tile
+    __shared__ double sU[OBJ_PER_WAVE * 36];       // Cholesky factor rows
+    __shared__ double sD[OBJ_PER_WAVE * 13 * 6];   // centred propagated sigma points d_i
+    __shared__ double sM[OBJ_PER_WAVE * 12];       // s = Wi sum d_i | m' = mean - sigma_0
+    __shared__ double sObs[OBJ_PER_WAVE * 12];
+    __shared__ double sMet[OBJ_PER_WAVE * 4];
+    __shared__ int sSt[OBJ_PER_WAVE];
+
+    const ssa_consts& C = k.c;
+    const ssa_step_params& p = k.p;
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, l = lane & 15;
+    const int64_t total = (int64_t)p.n_env * p.n_obj;
+    const int64_t base = (int64_t)blockIdx.x * OBJ_PER_WAVE;
+    const int64_t obj = base + g;
+    const bool valid = obj < total;
+
+    // ---- coalesced tile loads (block-contiguous in the reference's own AoS layout)
+    for (int t = lane; t < OBJ_PER_WAVE * 36; t += 64) {
+        int64_t gi = base * 36 + t;
+        sP[t] = gi < total * 36 ? p.P_in[gi] : 0.0;
+    }
+    if (lane < 24) {
+        int64_t gi = base * 6 + lane;
+        sX[lane] = gi < total * 6 ? p.x_in[gi] : 0.0;
+    } else if (lane >= 32 && lane < 56) {
+        int64_t gi = base * 6 + (lane - 32);
+        sT[lane - 32] = gi < total * 6 ? p.x_true_in[gi] : 0.0;
+    } else if (lane >= 56 && lane < 60) {
+        int64_t gi = base + (lane - 56);
+        sSt[lane - 56] = gi < total ? p.status[gi] : SSA_ST_PREDICT_NAN;
+    }
+    __syncthreads();
+
+    const int st_in = sSt[g];
+    const bool active = valid && st_in == SSA_ST_OK;
+    const int e = valid ? (int)(obj / p.n_obj) : 0;
+    const int64_t j = valid ? obj - (int64_t)e * p.n_obj : 0;
+
+    double xin[6], xt[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        xin[c] = sX[g * 6 + c];
+        xt[c] = sT[g * 6 + c];
+    }
+
+    // ---- U1/U2: sigma points.  Every lane factorises (n+lambda) P redundantly (no divergence,
+    // no cross-lane traffic); lane 0 publishes the rows.
+    int rung;
+    {
+        double A[21], U[21];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int c = i; c < 6; ++c) A[tri(i, c)] = C.scale * sP[g * 36 + i * 6 + c];
+        rung = robust_chol6(A, U);
+        if (l == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) sU[g * 36 + i * 6 + c] = (c >= i) ? U[tri(i, c)] : 0.0;
+        }
+    }
+    __syncthreads();
+    const bool chol_fail = (rung == 16);
+
+    const bool is_sigma = (l <= 12);
+    const bool is_pm = (l >= 1 && l <= 12);
+    double s[6];
+    {
+        const int krow = is_pm ? (l - 1) % 6 : 0;
+        const double sgn = (l >= 1 && l <= 6) ? 1.0 : ((l >= 7 && l <= 12) ? -1.0 : 0.0);
+        const bool use_filter = active && !chol_fail && l != 13;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            double u = sU[g * 36 + krow * 6 + c];
+            // inactive rows (failed / out-of-range objects) propagate the true state instead,
+            // so that their lanes stay on the fast path; their results are discarded.
+            s[c] = use_filter ? (xin[c] + sgn * u) : xt[c];
+        }
+    }
+
+    // ---- P1-P5: one Kepler solve per lane
+    double o[6];
+    kepler_step<PROP>(s, C.dt, o);
+
+    // ---- U3: unscented transform.  Centred form of x = dot(Wm, sigmas_f):
+    //   x = sigma_0' + m',   m' = (sum(Wm) - 1) sigma_0' + Wi sum_{i>=1} (sigma_i' - sigma_0')
+    // which is the reference's sum evaluated without the 1e8-fold cancellation of Wm0 ~ -2e8.
+    double s0[6], d[6], ssum[6], mp[6], xb[6];
+    bool nan_x = false;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        s0[c] = row_bcast(o[c], 0);
+        d[c] = is_pm ? (o[c] - s0[c]) : 0.0;
+        ssum[c] = C.Wi * row_allsum(d[c]);
+        mp[c] = C.sum_wm_m1 * s0[c] + ssum[c];
+        xb[c] = s0[c] + mp[c];
+        nan_x = nan_x || (xb[c] != xb[c]);
+    }
+    if (is_pm) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) sD[(g * 13 + l) * 6 + c] = d[c];
+    }
+    if (l == 0) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            sM[g * 12 + c] = ssum[c];
+            sM[g * 12 + 6 + c] = mp[c];
+            sX[g * 6 + c] = xb[c];
+        }
+    }
+    if (l == 13) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) sT[g * 6 + c] = o[c];  // x_true[i]
+    }
+    __syncthreads();
+    // P = sum Wc_i y_i y_i^T + Q with y_i = sigma_i' - x, expanded around sigma_0':
+    //   P = Wi sum_{i>=1} d_i d_i^T - m' s^T - s m'^T + sum(Wc) m' m'^T + Q
+    for (int idx = l; idx < 21; idx += 16) {
+        int a = 0, rem = idx;
+        while (rem >= 6 - a) { rem -= 6 - a; ++a; }
+        const int b = a + rem;
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 1; i <= 12; ++i) acc = fma(sD[(g * 13 + i) * 6 + a], sD[(g * 13 + i) * 6 + b], acc);
+        const double sa_ = sM[g * 12 + a], sb_ = sM[g * 12 + b];
+        const double ma = sM[g * 12 + 6 + a], mb = sM[g * 12 + 6 + b];
+        double Pab = C.Wi * acc - ma * sb_ - sa_ * mb + C.sum_wc * ma * mb + C.Q[a * 6 + b];
+        sP[g * 36 + a * 6 + b] = Pab;
+        sP[g * 36 + b * 6 + a] = Pab;
+    }
+    __syncthreads();
+
+    int st_new = st_in;
+    if (active) {
+        if (chol_fail) st_new = SSA_ST_PREDICT_LINALG;
+        else if (nan_x) st_new = SSA_ST_PREDICT_NAN;
+    }
+
+    // ---- U5: the one update of this env (ssa_tasker_simple_2.py:292-315), done by the row
+    // that owns object `a`; all cross-lane traffic below is row-level (DPP / bpermute), so the
+    // branch needs no block barrier.
+    const int act = valid ? p.actions[e] : -1;
+    const int tix = valid ? p.env_time[e] + p.time_offset : 0;
+    const bool interval_ok = (C.update_interval <= 1) || (tix % C.update_interval == 0);
+    const bool my_update = valid && act >= 0 && (int64_t)act == j && interval_ok;
+    if (my_update) {
+        double* rec = p.upd ? p.upd + (int64_t)e * SSA_UPD_STRIDE : nullptr;
+        bool taken = false, visible = false;
+        if (st_new == SSA_ST_OK) {
+            const double* M = p.trans + (int64_t)(p.n_time > 0 ? tix % p.n_time : 0) * 9;
+            double Mm[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Mm[i] = M[i];
+            // sigma points handed to update(): the propagated ones or, with
+            // SSA_FLAG_RESAMPLE, a fresh set drawn from the prior
+            double sf[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) sf[c] = o[c];
+            bool rs_fail = false;
+            if (C.flags & SSA_FLAG_RESAMPLE) {
+                double A[21], U[21];
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int c = i; c < 6; ++c) A[tri(i, c)] = C.scale * sP[g * 36 + i * 6 + c];
+                rs_fail = robust_chol6(A, U) == 16;
+                const int krow = is_pm ? (l - 1) % 6 : 0;
+                const double sgn = (l >= 1 && l <= 6) ? 1.0 : ((l >= 7 && l <= 12) ? -1.0 : 0.0);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    double u = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i)
+                        if (c >= i) u = (krow == i) ? U[tri(i, c)] : u;
+                    if (l != 13) sf[c] = xb[c] + sgn * u;
+                }
+            }
+            // H1/H2: measurement of every sigma point (lanes 0-12) and of the true state (lane 13)
+            double aer[3], z[3];
+            hx_aer(sf, Mm, C.enu, C.obs_itrs, aer);
+            if (C.obs_type == SSA_OBS_AER) { z[0] = aer[0]; z[1] = aer[1]; z[2] = aer[2]; }
+            else { z[0] = sf[0]; z[1] = sf[1]; z[2] = sf[2]; }
+            const double el_true = row_bcast(aer[1], 13);
+            visible = el_true >= C.obs_limit;  // object_visible(): elevation of the TRUE state (:418-425)
+            if (rec && l == 13) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) rec[SSA_UPD_Z_TRUE + c] = z[c];
+            }
+            if (visible && rs_fail) {
+                st_new = SSA_ST_UPDATE_LINALG;
+            } else if (visible) {
+                // H3/H5: predicted measurement
+                double zp[3];
+                const double wl = (l == 0) ? C.Wc0 : (is_pm ? C.Wi : 0.0);
+                if (C.obs_type == SSA_OBS_AER) {
+                    double uvw[3], um[3];
+                    aer2uvw(z, uvw);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        double u0 = row_bcast(uvw[c], 0);
+                        double du = is_pm ? (uvw[c] - u0) : 0.0;
+                        um[c] = u0 + (C.sum_wm_m1 * u0 + C.Wi * row_allsum(du));
+                    }
+                    uvw2aer(um, zp);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        double u0 = row_bcast(z[c], 0);
+                        double du = is_pm ? (z[c] - u0) : 0.0;
+                        zp[c] = u0 + (C.sum_wm_m1 * u0 + C.Wi * row_allsum(du));
+                    }
+                }
+                // H4: residuals; lane 13 forms the innovation of the noisy measurement
+                double zin[3], rz[3];
+                if (l == 13) {
+                    const double* zn = p.z_noise + (int64_t)e * p.zn_stride_env + (int64_t)tix * p.zn_stride_time + (int64_t)act * 3;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) zin[c] = z[c] + zn[c];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) zin[c] = z[c];
+                }
+                if (C.obs_type == SSA_OBS_AER) residual_z_aer(zin, zp, rz);
+                else {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) rz[c] = zin[c] - zp[c];
+                }
+                double y[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) y[c] = row_bcast(rz[c], 13);
+                // S = sum Wc rz rz^T + R ; Pxz = sum Wc (sigma_f - x)(rz)^T
+                double S[9], Pxz[18], dx[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) dx[c] = sf[c] - xb[c];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = a; b < 3; ++b) {
+                        double v = row_allsum(wl * (rz[a] * rz[b]));
+                        S[a * 3 + b] = v + C.R[a * 3 + b];
+                        S[b * 3 + a] = v + C.R[b * 3 + a];
+                    }
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) Pxz[a * 3 + b] = row_allsum(wl * (dx[a] * rz[b]));
+                double SI[9];
+                const bool inv_ok = inv3(S, SI);
+                if (!inv_ok) {
+                    st_new = SSA_ST_UPDATE_LINALG;
+                } else {
+                    taken = true;
+                    double K[18];
+#pragma unroll
+                    for (int a = 0; a < 6; ++a)
+#pragma unroll
+                        for (int b = 0; b < 3; ++b)
+                            K[a * 3 + b] = Pxz[a * 3] * SI[b] + Pxz[a * 3 + 1] * SI[3 + b] + Pxz[a * 3 + 2] * SI[6 + b];
+                    double xn[6];
+                    bool nan_u = false;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) {
+                        xn[a] = xb[a] + (K[a * 3] * y[0] + K[a * 3 + 1] * y[1] + K[a * 3 + 2] * y[2]);
+                        nan_u = nan_u || (xn[a] != xn[a]);
+                    }
+                    double SKt[18];  // S K^T  [3][6]
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+#pragma unroll
+                        for (int b = 0; b < 6; ++b)
+                            SKt[a * 6 + b] = S[a * 3] * K[b * 3] + S[a * 3 + 1] * K[b * 3 + 1] + S[a * 3 + 2] * K[b * 3 + 2];
+                    // P -= K (S K^T): lanes 0..5 each own one row of P
+                    if (l < 6) {
+#pragma unroll
+                        for (int b = 0; b < 6; ++b) {
+                            double kr0 = 0.0, kr1 = 0.0, kr2 = 0.0;
+#pragma unroll
+                            for (int a = 0; a < 6; ++a) {
+                                kr0 = (l == a) ? K[a * 3] : kr0;
+                                kr1 = (l == a) ? K[a * 3 + 1] : kr1;
+                                kr2 = (l == a) ? K[a * 3 + 2] : kr2;
+                            }
+                            double corr = kr0 * SKt[b] + kr1 * SKt[6 + b] + kr2 * SKt[12 + b];
+                            sP[g * 36 + l * 6 + b] = sP[g * 36 + l * 6 + b] - corr;
+                        }
+                    }
+                    if (l == 0) {
+#pragma unroll
+                        for (int a = 0; a < 6; ++a) sX[g * 6 + a] = xn[a];
+                    }
+                    if (nan_u) st_new = SSA_ST_UPDATE_NAN;
+                    if (rec) {
+                        if (l == 0) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) rec[SSA_UPD_Y + c] = y[c];
+#pragma unroll
+                            for (int c = 0; c < 9; ++c) rec[SSA_UPD_S + c] = S[c];
+                        }
+                        if (is_sigma) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) rec[SSA_UPD_SIGMAS_H + l * 3 + c] = z[c];
+                        }
+                    }
+                }
+            }
+        }
+        if (rec && l == 0) {
+            rec[SSA_UPD_OBS_TAKEN] = taken ? 1.0 : 0.0;
+            rec[SSA_UPD_VISIBLE] = visible ? 1.0 : 0.0;
+            rec[SSA_UPD_ACTION] = (double)act;
+        }
+    }
+    // envs whose action selects nobody still get a cleared record (written by object 0's row)
+    if (valid && p.upd && j == 0 && l == 0 && !(act >= 0 && interval_ok && (int64_t)act < p.n_obj)) {
+        double* rec = p.upd + (int64_t)e * SSA_UPD_STRIDE;
+        rec[SSA_UPD_OBS_TAKEN] = 0.0;
+        rec[SSA_UPD_VISIBLE] = 0.0;
+        rec[SSA_UPD_ACTION] = -1.0;
+    }
+
+    // ---- F1: failed filters carry the sentinels (ssa_tasker_simple_2.py:157-158, 369-382)
+    if (valid && st_new != SSA_ST_OK && st_in == SSA_ST_OK) {
+        for (int t = l; t < 36; t += 16) {
+            int a = t / 6, b = t - a * 6;
+            sP[g * 36 + t] = (a == b) ? (a < 3 ? X_FAILED_POS : X_FAILED_VEL) : 0.0;
+        }
+        if (l < 6) sX[g * 6 + l] = (l < 3) ? X_FAILED_POS : X_FAILED_VEL;
+    }
+    if (valid && st_in != SSA_ST_OK) {  // already failed: state passes through unchanged
+        for (int t = l; t < 36; t += 16) sP[g * 36 + t] = p.P_in[obj * 36 + t];
+        if (l < 6) sX[g * 6 + l] = xin[l];
+    }
+    if (l == 0) sSt[g] = st_new;
+    __syncthreads();
+
+    // ---- O1/O2: observation row and error metrics (results.py:61, :37)
+    if (l < 12) sObs[g * 12 + l] = (l < 6) ? sX[g * 6 + l] : sP[g * 36 + 7 * (l - 6)];
+    if (l < 4) {
+        const int off = (l & 1) * 3;  // 0: position block, 1: velocity block
+        double v;
+        if (l < 2) {
+            double a0 = sX[g * 6 + off] - sT[g * 6 + off];
+            double a1 = sX[g * 6 + off + 1] - sT[g * 6 + off + 1];
+            double a2 = sX[g * 6 + off + 2] - sT[g * 6 + off + 2];
+            v = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+        } else {
+            v = sqrt(sP[g * 36 + 7 * off] + sP[g * 36 + 7 * (off + 1)] + sP[g * 36 + 7 * (off + 2)]);
+        }
+        sMet[g * 4 + l] = v;
+    }
+    __syncthreads();
+
+    // ---- coalesced tile stores
+    for (int t = lane; t < OBJ_PER_WAVE * 36; t += 64) {
+        int64_t gi = base * 36 + t;
+        if (gi < total * 36) p.P_out[gi] = sP[t];
+    }
+    if (lane < 24) {
+        int64_t gi = base * 6 + lane;
+        if (gi < total * 6) p.x_out[gi] = sX[lane];
+    } else if (lane >= 32 && lane < 56) {
+        int64_t gi = base * 6 + (lane - 32);
+        if (gi < total * 6) p.x_true_out[gi] = sT[lane - 32];
+    } else if (lane >= 56 && lane < 60) {
+        int64_t gi = base + (lane - 56);
+        if (gi < total) p.status[gi] = sSt[lane - 56];
+    }
+    if (lane < 48) {
+        int64_t gi = base * 12 + lane;
+        if (gi < total * 12) p.obs[gi] = sObs[lane];
+    }
+    if (valid && l < 4) p.metrics[((int64_t)e * 4 + l) * p.n_obj + j] = sMet[g * 4 + l];
+}
+
+// ------------------------------------------------------------------------------------------
+// O3: per-env reward statistics
+__global__ void __launch_bounds__(1024) reward_stats_kernel(const double* __restrict__ metrics,
+                                                            const int32_t* __restrict__ status,
+                                                            double* __restrict__ stats, int64_t m)
+{
+    const int e = blockIdx.x;
+    const double* dpos = metrics + ((int64_t)e * 4 + 0) * m;
+    const double* spos = metrics + ((int64_t)e * 4 + 2) * m;
+    const int32_t* st = status + (int64_t)e * m;
+    // NaN ranks above everything (np.max / np.argmax semantics); ties keep the lowest index.
+    double mx = -1.0, sm = -1.0;
+    bool mx_nan = false, sm_nan = false;
+    long long arg = 0x7fffffffffffffffLL;
+    unsigned c4 = 0, c7 = 0, nf = 0;
+    for (int64_t i = threadIdx.x; i < m; i += blockDim.x) {
+        double dp = dpos[i], sp = spos[i];
+        if (dp != dp) mx_nan = true; else mx = fmax(mx, dp);
+        c4 += dp < 1e4;
+        c7 += dp < 1e7;
+        nf += st[i] != 0;
+        bool better = sm_nan ? false : ((sp != sp) ? true : (sp > sm));
+        if (better) { sm = sp; arg = i; sm_nan = (sp != sp); }
+    }
+    __shared__ double s_mx[1024], s_sm[1024];
+    __shared__ long long s_arg[1024];
+    __shared__ unsigned s_c4[1024], s_c7[1024], s_nf[1024];
+    __shared__ unsigned char s_flag[1024];
+    const int t = threadIdx.x;
+    s_mx[t] = mx; s_sm[t] = sm; s_arg[t] = arg; s_c4[t] = c4; s_c7[t] = c7; s_nf[t] = nf;
+    s_flag[t] = (mx_nan ? 1 : 0) | (sm_nan ? 2 : 0);
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (t < w) {
+            s_mx[t] = fmax(s_mx[t], s_mx[t + w]);
+            s_c4[t] += s_c4[t + w]; s_c7[t] += s_c7[t + w]; s_nf[t] += s_nf[t + w];
+            unsigned char fa = s_flag[t], fb = s_flag[t + w];
+            bool a_nan = fa & 2, b_nan = fb & 2;
+            bool take_b;
+            if (a_nan || b_nan) take_b = b_nan && (!a_nan || s_arg[t + w] < s_arg[t]);
+            else take_b = (s_sm[t + w] > s_sm[t]) || (s_sm[t + w] == s_sm[t] && s_arg[t + w] < s_arg[t]);
+            if (take_b) { s_sm[t] = s_sm[t + w]; s_arg[t] = s_arg[t + w]; }
+            s_flag[t] = (unsigned char)(((fa | fb) & 1) | ((a_nan || b_nan) ? 2 : 0));
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        double* o = stats + (int64_t)e * SSA_STAT_STRIDE;
+        o[SSA_STAT_MAX_DPOS] = (s_flag[0] & 1) ? __builtin_nan("") : s_mx[0];
+        o[SSA_STAT_CNT_LT_1E4] = (double)s_c4[0];
+        o[SSA_STAT_CNT_LT_1E7] = (double)s_c7[0];
+        o[SSA_STAT_ARGMAX_SPOS] = (double)s_arg[0];
+        o[SSA_STAT_N_FAILED] = (double)s_nf[0];
+        o[SSA_STAT_MAX_SPOS] = (s_flag[0] & 2) ? __builtin_nan("") : s_sm[0];
+        o[6] = 0.0; o[7] = 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// single-operator kernels (one lane per item)
+template <int PROP>
+__global__ void propagate_kernel(const double* __restrict__ xin, double* __restrict__ xout, int64_t n, double dt)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool ok = i < n;
+    int64_t ii = ok ? i : 0;  // keep the wave convergent for the __all() in the Newton loops
+    double x[6], o[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) x[c] = xin[ii * 6 + c];
+    kepler_step<PROP>(x, dt, o);
+    if (ok) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) xout[i * 6 + c] = o[c];
+    }
+}
+__global__ void elements_kernel(const double* __restrict__ xin, double* __restrict__ coe, int64_t n, double dt)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool ok = i < n;
+    int64_t ii = ok ? i : 0;
+    double x[6], o[6], dg[8];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) x[c] = xin[ii * 6 + c];
+    kepler_elements(x, dt, o, dg);
+    if (ok) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) coe[i * 8 + c] = dg[c];
+    }
+}
+__global__ void cholesky_kernel(const double* __restrict__ A, double* __restrict__ U, int32_t* __restrict__ rung, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a[21], u[21];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c) a[tri(r, c)] = A[i * 36 + r * 6 + c];
+    // scipy.linalg.cholesky checks the WHOLE matrix for non-finite entries
+    bool finite = true;
+    for (int t = 0; t < 36; ++t) finite = finite && (fabs(A[i * 36 + t]) <= 1.79769313486231570e308);
+    int rg = finite ? robust_chol6(a, u) : 16;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) U[i * 36 + r * 6 + c] = (c >= r && rg != 16) ? u[tri(r, c)] : 0.0;
+    rung[i] = rg;
+}
+__global__ void sigma_points_kernel(const double* __restrict__ x, const double* __restrict__ P, double scale,
+                                    double* __restrict__ sig, int32_t* __restrict__ fail, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a[21], u[21];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c) a[tri(r, c)] = scale * P[i * 36 + r * 6 + c];
+    int rg = robust_chol6(a, u);
+    fail[i] = rg == 16 ? SSA_ST_PREDICT_LINALG : SSA_ST_OK;
+    double xx[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        xx[c] = x[i * 6 + c];
+        sig[i * 78 + c] = xx[c];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            double uv = (c >= r && rg != 16) ? u[tri(r, c)] : 0.0;
+            sig[i * 78 + (r + 1) * 6 + c] = xx[c] + uv;
+            sig[i * 78 + (r + 7) * 6 + c] = xx[c] - uv;
+        }
+}
+struct GeoK {
+    double enu[9];
+    double obs[3];
+    double obs_limit;
+    double Wi, sum_wm_m1;
+};
+__global__ void hx_kernel(const double* __restrict__ x, int64_t stride, const double* __restrict__ M, GeoK g,
+                          double* __restrict__ z, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double Mm[9], xx[3], zz[3];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) Mm[c] = M[c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xx[c] = x[i * stride + c];
+    hx_aer(xx, Mm, g.enu, g.obs, zz);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) z[i * 3 + c] = zz[c];
+}
+__global__ void mean_z_kernel(const double* __restrict__ sig, GeoK g, double* __restrict__ zp, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double u0[3], acc[3] = {0.0, 0.0, 0.0}, a[3], um[3], out[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a[c] = sig[i * 39 + c];
+    aer2uvw(a, u0);
+    for (int s = 1; s < 13; ++s) {
+        double u[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a[c] = sig[i * 39 + s * 3 + c];
+        aer2uvw(a, u);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] += u[c] - u0[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) um[c] = u0[c] + (g.sum_wm_m1 * u0[c] + g.Wi * acc[c]);
+    uvw2aer(um, out);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) zp[i * 3 + c] = out[c];
+}
+__global__ void residual_kernel(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ c, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double aa[3] = {a[i * 3], a[i * 3 + 1], a[i * 3 + 2]}, bb[3] = {b[i * 3], b[i * 3 + 1], b[i * 3 + 2]}, cc[3];
+    residual_z_aer(aa, bb, cc);
+    c[i * 3] = cc[0]; c[i * 3 + 1] = cc[1]; c[i * 3 + 2] = cc[2];
+}
+__global__ void visible_kernel(const double* __restrict__ x, const double* __restrict__ M, GeoK g,
+                               uint8_t* __restrict__ mask, double* __restrict__ el, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double Mm[9], xx[3], zz[3];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) Mm[c] = M[c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xx[c] = x[i * 6 + c];
+    hx_aer(xx, Mm, g.enu, g.obs, zz);
+    mask[i] = zz[1] >= g.obs_limit ? 1 : 0;
+    if (el) el[i] = zz[1];
+}
+__global__ void observe_kernel(const double* __restrict__ xt, const double* __restrict__ x, const double* __restrict__ P,
+                               double* __restrict__ obs, double* __restrict__ met, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double xx[6], dg[6], tt[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        xx[c] = x[i * 6 + c];
+        tt[c] = xt[i * 6 + c];
+        dg[c] = P[i * 36 + 7 * c];
+        obs[i * 12 + c] = xx[c];
+        obs[i * 12 + 6 + c] = dg[c];
+    }
+    double a0 = xx[0] - tt[0], a1 = xx[1] - tt[1], a2 = xx[2] - tt[2];
+    double b0 = xx[3] - tt[3], b1 = xx[4] - tt[4], b2 = xx[5] - tt[5];
+    met[i] = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+    met[n + i] = sqrt(b0 * b0 + b1 * b1 + b2 * b2);
+    met[2 * n + i] = sqrt(dg[0] + dg[1] + dg[2]);
+    met[3 * n + i] = sqrt(dg[3] + dg[4] + dg[5]);
+}
+__global__ void aer_obs_kernel(const double* __restrict__ x, const double* __restrict__ P, const double* __restrict__ M,
+                               GeoK g, double* __restrict__ out, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double Mm[9], xx[3], zz[3];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) Mm[c] = M[c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xx[c] = x[i * 6 + c];
+    hx_aer(xx, Mm, g.enu, g.obs, zz);
+    double tr = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) tr += P[i * 36 + 7 * c];
+    double v[4] = {zz[0], zz[1], zz[2], tr};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[i * 4 + c] = (fabs(v[c]) <= 1.79769313486231570e308) ? v[c] : 0.001;
+}
+
+static GeoK make_geo(const ssa_consts* c)
+{
+    GeoK g;
+    for (int i = 0; i < 9; ++i) g.enu[i] = c->enu[i];
+    for (int i = 0; i < 3; ++i) g.obs[i] = c->obs_itrs[i];
+    g.obs_limit = c->obs_limit;
+    g.Wi = c->Wi;
+    g.sum_wm_m1 = c->sum_wm_m1;
+    return g;
+}
+static inline int launch_status() { return hipGetLastError() == hipSuccess ? SSA_OK : SSA_E_LAUNCH; }
+static inline unsigned nblk(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+}  // namespace ssa
+
+// ============================================================================= C ABI
+using namespace ssa;
+
+extern "C" {
+
+int ssa_abi_version(void) { return SSA_ABI_VERSION; }
+const char* ssa_build_info(void) { return "libssa_hip gfx950 fp64 (" __DATE__ " " __TIME__ ")"; }
+
+int ssa_env_step_f64(const ssa_consts* c, const ssa_step_params* p, void* stream)
+{
+    if (!c || !p || p->n_obj <= 0 || p->n_env <= 0) return SSA_E_INVALID;
+    if (!p->x_true_in || !p->x_true_out || !p->x_in || !p->x_out || !p->P_in || !p->P_out || !p->status ||
+        !p->obs || !p->metrics || !p->trans || !p->env_time || !p->actions || !p->z_noise)
+        return SSA_E_INVALID;
+    if (c->obs_type != SSA_OBS_AER && c->obs_type != SSA_OBS_XYZ) return SSA_E_INVALID;
+    StepK k;
+    k.c = *c;
+    k.p = *p;
+    const int64_t total = (int64_t)p->n_env * p->n_obj;
+    dim3 grid(nblk(total, OBJ_PER_WAVE)), block(64);
+    hipStream_t s = (hipStream_t)stream;
+    if (c->propagator == SSA_PROP_FG) hipLaunchKernelGGL(step_kernel<1>, grid, block, 0, s, k);
+    else if (c->propagator == SSA_PROP_ELEMENTS) hipLaunchKernelGGL(step_kernel<0>, grid, block, 0, s, k);
+    else return SSA_E_INVALID;
+    return launch_status();
+}
+
+int ssa_reward_stats_f64(const double* metrics, const int32_t* status, double* stats, int64_t n_obj, int32_t n_env,
+                         void* stream)
+{
+    if (!metrics || !status || !stats || n_obj <= 0 || n_env <= 0) return SSA_E_INVALID;
+    hipLaunchKernelGGL(reward_stats_kernel, dim3(n_env), dim3(1024), 0, (hipStream_t)stream, metrics, status, stats, n_obj);
+    return launch_status();
+}
+
+int ssa_propagate_f64(const double* x_in, double* x_out, int64_t n, double dt, int32_t propagator, void* stream)
+{
+    if (n == 0) return SSA_OK;
+    if (!x_in || !x_out || n < 0) return SSA_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    if (propagator == SSA_PROP_FG) hipLaunchKernelGGL(propagate_kernel<1>, dim3(nblk(n, 64)), dim3(64), 0, s, x_in, x_out, n, dt);
+    else if (propagator == SSA_PROP_ELEMENTS) hipLaunchKernelGGL(propagate_kernel<0>, dim3(nblk(n, 64)), dim3(64), 0, s, x_in, x_out, n, dt);
+    else return SSA_E_INVALID;
+    return launch_status();
+}
+
+int ssa_kepler_elements_f64(const double* x_in, double* coe, int64_t n, double dt, void* stream)
+{
+    if (!x_in || !coe || n < 0) return SSA_E_INVALID;
+    if (n == 0) return SSA_OK;
+    hipLaunchKernelGGL(elements_kernel, dim3(nblk(n, 64)), dim3(64), 0, (hipStream_t)stream, x_in, coe, n, dt);
+    return launch_status();
+}
+
+int ssa_robust_cholesky6_f64(const double* A, double* U, int32_t* rung, int64_t n, void* stream)
+{
+    if (!A || !U || !rung || n < 0) return SSA_E_INVALID;
+    if (n == 0) return SSA_OK;
+    hipLaunchKernelGGL(cholesky_kernel, dim3(nblk(n, 64)), dim3(64), 0, (hipStream_t)stream, A, U, rung, n);
+    return launch_status();
+}
+
+int ssa_sigma_points_f64(const double* x, const double* P, double scale, double* sig, int32_t* fail, int64_t n, void* stream)
+{
+    if (!x || !P || !sig || !fail || n < 0) return SSA_E_INVALID;
+    if (n == 0) return SSA_OK;
+    hipLaunchKernelGGL(sigma_points_kernel, dim3(nblk(n, 64)), dim3(64), 0, (hipStream_t)stream, x, P, scale, sig, fail, n);
+    return launch_status();
+}
+
+int ssa_hx_aer_f64(const double* x, int64_t x_stride, const double* M, const ssa_consts* c, double* z, int64_t n, void* stream)
+{
+    if (!x || !M || !c || !z || n < 0 || x_stride < 3) return SSA_E_INVALID;
+    if (n == 0) return SSA_OK;
+    hipLaunchKernelGGL(hx_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, x, x_stride, M, make_geo(c), z, n);
+    return launch_status();
+}
+
+int ssa_mean_z_uvw_f64(const double* sigmas, const ssa_consts* c, double* zp, int64_t n, void* stream)
+{
+    if (!sigmas || !c || !zp || n < 0) return SSA_E_INVALID;
+    if (n == 0) return SSA_OK;
+    hipLaunchKernelGGL(mean_z_kernel, dim3(nblk(n, 64)), dim3(64), 0, (hipStream_t)stream, sigmas, make_geo(c), zp, n);
+    return launch_status();
+}
+
+int ssa_residual_z_aer_f64(const double* a, const double* b, double* c, int64_t n, void* stream)
+{
+    if (!a || !b || !c || n < 0) return SSA_E_INVALID;
+    if (n == 0) return SSA_OK;
+    hipLaunchKernelGGL(residual_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, c, n);
+    return launch_status();
+}
+
+int ssa_visible_mask_f64(const double* x_true, const double* M, const ssa_consts* c, uint8_t* mask, double* el, int64_t n,
+                         void* stream)
+{
+    if (!x_true || !M || !c || !mask || n < 0) return SSA_E_INVALID;
+    if (n == 0) return SSA_OK;
+    hipLaunchKernelGGL(visible_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, x_true, M, make_geo(c), mask, el, n);
+    return launch_status();
+}
+
+int ssa_observe_f64(const double* x_true, const double* x, const double* P, double* obs, double* metrics, int64_t n, void* stream)
+{
+    if (!x_true || !x || !P || !obs || !metrics || n < 0) return SSA_E_INVALID;
+    if (n == 0) return SSA_OK;
+    hipLaunchKernelGGL(observe_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, x_true, x, P, obs, metrics, n);
+    return launch_status();
+}
+
+int ssa_aer_obs_f64(const double* x, const double* P, const double* M, const ssa_consts* c, double* out, int64_t n, void* stream)
+{
+    if (!x || !P || !M || !c || !out || n < 0) return SSA_E_INVALID;
+    if (n == 0) return SSA_OK;
+    hipLaunchKernelGGL(aer_obs_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, x, P, M, make_geo(c), out, n);
+    return launch_status();
+}
+
+}  // extern "C"

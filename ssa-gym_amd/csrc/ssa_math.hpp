@@ -1,0 +1,362 @@
+// ssa_math.hpp -- per-lane fp64 device math for the ssa-gym hot path (gfx950).
+//
+// Everything here runs in one lane on one state vector; the kernels in
+// ssa_kernels.hip decide which lane works on which sigma point / object.
+// Citations are file:line under the reference root.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ssa {
+
+constexpr double MU = 398600441800000.0;  // farnocchia.py:1060 (k hard-coded)
+constexpr double PI = 3.141592653589793;
+constexpr double TWO_PI = 6.283185307179586;
+constexpr double NEWTON_TOL = 1.48e-08;   // farnocchia.py:337
+
+#define SSA_DEV __device__ __forceinline__
+
+SSA_DEV double dot3(const double* a, const double* b) { return fma(a[2], b[2], fma(a[1], b[1], a[0] * b[0])); }
+
+// Python / numpy `a % (2 pi)` (result in [0, 2 pi)); exact remainder via one FMA.
+SSA_DEV double mod_2pi(double a)
+{
+    double k = floor(a * (1.0 / TWO_PI));
+    double r = fma(-k, TWO_PI, a);
+    if (r < 0.0) r += TWO_PI;
+    if (r >= TWO_PI) r -= TWO_PI;
+    return r;
+}
+// (a + pi) % (2 pi) - pi   (farnocchia.py:311, :953)
+SSA_DEV double wrap_pi(double a) { return mod_2pi(a + PI) - PI; }
+
+// ---------------------------------------------------------------------------
+// Kepler's equation, elliptic: Newton on E - e sin E - M with the reference's
+// starter, step tolerance and iteration cap; NaN when it does not converge
+// (farnocchia.py:337-353, :573-601).
+SSA_DEV double solve_kepler_E(double M, double ecc)
+{
+    double p0 = (ecc < 0.8) ? M : (M > 0.0 ? PI : (M < 0.0 ? -PI : 0.0));
+    double res = __builtin_nan("");
+    bool done = false;
+    for (int it = 0; it < 50; ++it) {
+        double s, c;
+        sincos(p0, &s, &c);
+        double fval = (p0 - ecc * s) - M;
+        double fder = 1.0 - ecc * c;
+        double p = p0 - fval / fder;
+        if (!done && fabs(p - p0) < NEWTON_TOL) { res = p; done = true; }
+        p0 = p;
+        if (__all(done)) break;
+    }
+    return res;
+}
+
+// coe2rv (farnocchia.py:101-161): perifocal state rotated by R3(raan) R1(inc) R3(argp).
+SSA_DEV void coe2rv(double p, double ecc, double inc, double raan, double argp, double nu, double* out)
+{
+    double sn, cn, sO, cO, si, ci, sw, cw;
+    sincos(nu, &sn, &cn);
+    sincos(raan, &sO, &cO);
+    sincos(inc, &si, &ci);
+    sincos(argp, &sw, &cw);
+    double fr = p / (1.0 + ecc * cn), fv = sqrt(MU / p);
+    double px = cn * fr, py = sn * fr, vx = -sn * fv, vy = (ecc + cn) * fv;
+    double r00 = cO * cw - sO * ci * sw, r01 = -cO * sw - sO * ci * cw;
+    double r10 = sO * cw + cO * ci * sw, r11 = -sO * sw + cO * ci * cw;
+    double r20 = si * sw, r21 = si * cw;
+    out[0] = px * r00 + py * r01;
+    out[1] = px * r10 + py * r11;
+    out[2] = px * r20 + py * r21;
+    out[3] = vx * r00 + vy * r01;
+    out[4] = vx * r10 + vy * r11;
+    out[5] = vx * r20 + vy * r21;
+}
+
+// rv2coe (farnocchia.py:165-313), elliptic side of the general branch inline; returns false
+// when the orbit is not a strong-elliptic one (a <= 0 or ecc >= 1 - 1e-2) so that the caller
+// can take the complete restatement below.  coe = p, ecc, inc, raan, argp, nu.
+SSA_DEV bool rv2coe_elliptic(const double* r, const double* v, double* coe)
+{
+    const double tol = 1e-8;
+    double h[3] = {r[1] * v[2] - r[2] * v[1], r[2] * v[0] - r[0] * v[2], r[0] * v[1] - r[1] * v[0]};
+    double n[3] = {-h[1], h[0], 0.0};  // cross([0,0,1], h)
+    double rn = sqrt(dot3(r, r)), vv = dot3(v, v), rv = dot3(r, v);
+    double c1 = vv - MU / rn;
+    double e[3] = {(c1 * r[0] - rv * v[0]) / MU, (c1 * r[1] - rv * v[1]) / MU, (c1 * r[2] - rv * v[2]) / MU};
+    double ecc = sqrt(dot3(e, e));
+    double p = dot3(h, h) / MU;
+    double hn = sqrt(dot3(h, h));
+    double inc = acos(h[2] / hn);
+    bool circular = ecc < tol, equatorial = fabs(inc) < tol;
+    double raan, argp, nu;
+    if (equatorial && !circular) {
+        raan = 0.0;
+        argp = mod_2pi(atan2(e[1], e[0]));
+        double t[3] = {e[1] * r[2] - e[2] * r[1], e[2] * r[0] - e[0] * r[2], e[0] * r[1] - e[1] * r[0]};
+        nu = atan2(dot3(h, t) / hn, dot3(r, e));
+    } else if (!equatorial && circular) {
+        raan = mod_2pi(atan2(n[1], n[0]));
+        argp = 0.0;
+        double t[3] = {h[1] * n[2] - h[2] * n[1], h[2] * n[0] - h[0] * n[2], h[0] * n[1] - h[1] * n[0]};
+        nu = atan2(dot3(r, t) / hn, dot3(r, n));
+    } else if (equatorial && circular) {
+        raan = 0.0;
+        argp = 0.0;
+        nu = mod_2pi(atan2(r[1], r[0]));
+    } else {
+        double a = p / (1.0 - ecc * ecc);
+        if (!(a > 0.0)) return false;
+        double e_se = rv / sqrt(MU * a);
+        double e_ce = rn * vv / MU - 1.0;
+        double E = atan2(e_se, e_ce);
+        nu = 2.0 * atan(sqrt((1.0 + ecc) / (1.0 - ecc)) * tan(0.5 * E));
+        raan = mod_2pi(atan2(n[1], n[0]));
+        double t[3] = {h[1] * n[2] - h[2] * n[1], h[2] * n[0] - h[0] * n[2], h[0] * n[1] - h[1] * n[0]};
+        double px = dot3(r, n), py = dot3(r, t) / hn;
+        argp = mod_2pi(atan2(py, px) - nu);
+    }
+    nu = wrap_pi(nu);
+    coe[0] = p; coe[1] = ecc; coe[2] = inc; coe[3] = raan; coe[4] = argp; coe[5] = nu;
+    return ecc < 1.0 - 1e-2;
+}
+
+// Complete restatement of farnocchia() with every conic branch (parabolic, near-parabolic,
+// hyperbolic): farnocchia.py:847-1050.  Out of line: only objects that have left the
+// strong-elliptic regime (a diverged filter) ever reach it.
+__device__ __noinline__ void kepler_general(const double* x, double tof, double* out, double* diag);
+
+// SSA_PROP_ELEMENTS: farnocchia() for the strong-elliptic regime, operation by operation
+// (rv2coe -> delta_t_from_nu :871-875 -> nu_from_delta_t :946-954 -> coe2rv).
+// diag (optional, 8 doubles): p, ecc, inc, raan, argp, nu0, delta_t0, nu.
+SSA_DEV void kepler_elements(const double* x, double tof, double* out, double* diag)
+{
+    double coe[6];
+    if (!rv2coe_elliptic(x, x + 3, coe)) {
+        kepler_general(x, tof, out, diag);
+        return;
+    }
+    double p = coe[0], ecc = coe[1], nu0 = coe[5];
+    double q = p / (1.0 + ecc);
+    double ome = 1.0 - ecc;
+    double E0 = 2.0 * atan(sqrt(ome / (1.0 + ecc)) * tan(0.5 * nu0));
+    double M0 = E0 - ecc * sin(E0);
+    double nmm = sqrt(MU * ome * ome * ome / (q * q * q));
+    double dt0 = M0 / nmm;
+    double M = nmm * (dt0 + tof);
+    double E = solve_kepler_E(wrap_pi(M), ecc);
+    double nu = 2.0 * atan(sqrt((1.0 + ecc) / ome) * tan(0.5 * E));
+    coe2rv(p, ecc, coe[2], coe[3], coe[4], nu, out);
+    if (diag) {
+        for (int i = 0; i < 6; ++i) diag[i] = coe[i];
+        diag[6] = dt0;
+        diag[7] = nu;
+    }
+}
+
+// SSA_PROP_FG: the same strong-elliptic branch with the element round trip removed
+// algebraically.  With e cos E0 = r0 v^2/mu - 1 and e sin E0 = r.v/sqrt(mu a)
+// (farnocchia.py:295-297) Kepler's equation for x = E - E0 reads
+//     x - (e cos E0) sin x + (e sin E0)(1 - cos x) = n tof              (:871-875, :946-954)
+// and coe2rv(nu(E)) equals the Lagrange combination r' = f r + g v, v' = f' r + g' v.
+// No acos/atan2/tan/atan, no singular elements (circular / equatorial orbits need no
+// special branch).  Falls back to kepler_general outside the strong-elliptic regime.
+SSA_DEV void kepler_fg(const double* x, double tof, double* out)
+{
+    const double* r = x;
+    const double* v = x + 3;
+    double rr = dot3(r, r), vv = dot3(v, v), rv = dot3(r, v);
+    double r0 = sqrt(rr);
+    double alpha = 2.0 / r0 - vv * (1.0 / MU);  // 1/a
+    double ome = r0 * alpha;                    // r0 / a = 1 - e cos E0
+    double ec = 1.0 - ome;                      // e cos E0
+    double sa = sqrt(alpha);
+    const double sqrt_mu = sqrt(MU);            // folded at compile time
+    double es = rv * sa / sqrt_mu;              // e sin E0
+    double ecc2 = ec * ec + es * es;
+    if (!(alpha > 0.0) || !(ecc2 < 0.99 * 0.99)) {
+        kepler_general(x, tof, out, nullptr);
+        return;
+    }
+    double n = sqrt_mu * alpha * sa;            // mean motion
+    double Mt = n * tof;
+    double k = rint(Mt * (1.0 / TWO_PI));
+    double Mr = fma(-k, TWO_PI, Mt);            // in [-pi, pi]
+    // safeguarded Newton on the monotone G(x) = x - ec sin x + es (1 - cos x) - Mr, G' = r/a > 0.
+    double x1 = Mr / ome;
+    double xs = x1 - 0.5 * es * x1 * x1 / ome;  // second-order starter, exact as Mr -> 0
+    double lo = Mr - 2.0, hi = Mr + 2.0;        // |periodic part| <= 2 e < 2
+    double xk = (fabs(Mr) < 0.5 && xs > lo && xs < hi) ? xs : Mr - es;
+    double s = 0.0, c = 1.0;
+    bool done = false;
+    double xres = __builtin_nan("");
+    for (int it = 0; it < 50; ++it) {
+        sincos(xk, &s, &c);
+        double G = (xk - ec * s + es * (1.0 - c)) - Mr;
+        double dG = 1.0 - ec * c + es * s;
+        if (G > 0.0) hi = xk; else lo = xk;
+        double xn = xk - G / dG;
+        if (!(xn >= lo && xn <= hi)) xn = 0.5 * (lo + hi);
+        if (!done && fabs(xn - xk) < 1e-10) { xres = xn; done = true; }
+        xk = xn;
+        if (__all(done)) break;
+    }
+    sincos(xres, &s, &c);
+    double omc = 1.0 - c;
+    double rho = 1.0 - (ec * c - es * s);       // r / a
+    double A = 1.0 / ome;                       // a / r0
+    double f = 1.0 - A * omc;
+    double g = (ome * s + es * omc) / n;
+    double fd = -sqrt_mu * sa * s / (rho * r0);
+    double gd = 1.0 - omc / rho;
+    out[0] = f * r[0] + g * v[0];
+    out[1] = f * r[1] + g * v[1];
+    out[2] = f * r[2] + g * v[2];
+    out[3] = fd * r[0] + gd * v[0];
+    out[4] = fd * r[1] + gd * v[1];
+    out[5] = fd * r[2] + gd * v[2];
+}
+
+template <int PROP>
+SSA_DEV void kepler_step(const double* x, double tof, double* out)
+{
+    if (PROP == 1) kepler_fg(x, tof, out);
+    else kepler_elements(x, tof, out, nullptr);
+}
+
+// ---------------------------------------------------------------------------
+// U2: upper Cholesky of a symmetric 6x6 given by its upper triangle (packed row-major,
+// 21 values: (0,0)(0,1)..(0,5)(1,1)..(5,5)), LAPACK dpotf2('U') order; `jit` is added to the
+// diagonal.  Returns false if a pivot is <= 0 or NaN (scipy -> LinAlgError).
+SSA_DEV constexpr int tri(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
+
+SSA_DEV bool chol6_upper(const double* A, double jit, double* U)
+{
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double ajj = A[tri(j, j)] + jit;
+#pragma unroll
+        for (int i = 0; i < j; ++i) ajj = fma(-U[tri(i, j)], U[tri(i, j)], ajj);
+        ok = ok && (ajj > 0.0);
+        double d = sqrt(ajj);
+        U[tri(j, j)] = d;
+        double inv = 1.0 / d;
+#pragma unroll
+        for (int cidx = j + 1; cidx < 6; ++cidx) {
+            double sacc = A[tri(j, cidx)];
+#pragma unroll
+            for (int i = 0; i < j; ++i) sacc = fma(-U[tri(i, j)], U[tri(i, cidx)], sacc);
+            U[tri(j, cidx)] = sacc * inv;
+        }
+    }
+    return ok;
+}
+
+// robust_cholesky (dynamics.py:402-417): plain, then a + 10^i I for i = -6..9; rung = -1,
+// 0..15, or 16 when the ladder is exhausted (LinAlgError).  Non-finite input fails every rung
+// (scipy check_finite).
+SSA_DEV int robust_chol6(const double* A, double* U)
+{
+    const double JIT[16] = {1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1.0, 10.0, 100.0, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9};
+    bool finite = true;
+#pragma unroll
+    for (int i = 0; i < 21; ++i) finite = finite && (fabs(A[i]) <= 1.79769313486231570e308);
+    if (!finite) return 16;
+    if (chol6_upper(A, 0.0, U)) return -1;
+    for (int t = 0; t < 16; ++t)
+        if (chol6_upper(A, JIT[t], U)) return t;
+    return 16;
+}
+
+// ---------------------------------------------------------------------------
+// H1: hx_aer_erfa (dynamics.py:219) = ecef2aer(M x[:3]) (transformations.py:330-352).
+// enu = trans_uvw_ecef (row-major) for the observer.
+SSA_DEV void hx_aer(const double* x, const double* M, const double* enu, const double* obs, double* z)
+{
+    double xi[3], d[3], R[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xi[i] = M[i * 3] * x[0] + M[i * 3 + 1] * x[1] + M[i * 3 + 2] * x[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d[i] = xi[i] - obs[i];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R[j] = enu[j] * d[0] + enu[3 + j] * d[1] + enu[6 + j] * d[2];
+    double rng = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    double az = atan2(R[1], R[0]);
+    if (az < 0.0) az += TWO_PI;
+    z[0] = az;
+    z[1] = asin(R[2] / rng);
+    z[2] = rng;
+}
+SSA_DEV void aer2uvw(const double* aer, double* uvw)  // transformations.py:284
+{
+    double sa, ca, se, ce;
+    sincos(aer[0], &sa, &ca);
+    sincos(aer[1], &se, &ce);
+    uvw[0] = aer[2] * ce * ca;
+    uvw[1] = aer[2] * ce * sa;
+    uvw[2] = aer[2] * se;
+}
+SSA_DEV void uvw2aer(const double* uvw, double* aer)  // transformations.py:301
+{
+    double rng = sqrt(uvw[0] * uvw[0] + uvw[1] * uvw[1] + uvw[2] * uvw[2]);
+    double az = atan2(uvw[1], uvw[0]);
+    if (az < 0.0) az += TWO_PI;
+    aer[0] = az;
+    aer[1] = asin(uvw[2] / rng);
+    aer[2] = rng;
+}
+SSA_DEV void residual_z_aer(const double* a, const double* b, double* c)  // dynamics.py:260
+{
+    double d = a[0] - b[0], s, co;
+    sincos(d, &s, &co);
+    c[0] = atan2(s, co);
+    c[1] = a[1] - b[1];
+    c[2] = a[2] - b[2];
+}
+
+// 3x3 inverse by cofactors (numpy.linalg.inv in UKF.update); false if singular / non-finite.
+SSA_DEV bool inv3(const double* S, double* SI)
+{
+    double c00 = S[4] * S[8] - S[5] * S[7], c01 = S[5] * S[6] - S[3] * S[8], c02 = S[3] * S[7] - S[4] * S[6];
+    double det = S[0] * c00 + S[1] * c01 + S[2] * c02;
+    if (det == 0.0 || !(fabs(det) <= 1.79769313486231570e308)) return false;
+    double id = 1.0 / det;
+    SI[0] = c00 * id;
+    SI[1] = (S[2] * S[7] - S[1] * S[8]) * id;
+    SI[2] = (S[1] * S[5] - S[2] * S[4]) * id;
+    SI[3] = c01 * id;
+    SI[4] = (S[0] * S[8] - S[2] * S[6]) * id;
+    SI[5] = (S[2] * S[3] - S[0] * S[5]) * id;
+    SI[6] = c02 * id;
+    SI[7] = (S[1] * S[6] - S[0] * S[7]) * id;
+    SI[8] = (S[0] * S[4] - S[1] * S[3]) * id;
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// wave-level primitives: the 16-lane DPP rows of a wavefront are the "one sigma-point set".
+template <int CTRL>
+SSA_DEV double dpp_row(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over the 16 lanes of a DPP row, result in every lane (row_ror 8,4,2,1 butterfly).
+SSA_DEV double row_allsum(double v)
+{
+    v += dpp_row<0x128>(v);  // row_ror:8
+    v += dpp_row<0x124>(v);  // row_ror:4
+    v += dpp_row<0x122>(v);  // row_ror:2
+    v += dpp_row<0x121>(v);  // row_ror:1
+    return v;
+}
+// value of lane `src` (0..15) of the own row, in every lane of the row.
+SSA_DEV double row_bcast(double v, int src)
+{
+    int lane = (int)(threadIdx.x & 63);
+    return __shfl(v, (lane & ~15) | src, 64);
+}
+
+}  // namespace ssa

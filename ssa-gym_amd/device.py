@@ -1,0 +1,146 @@
+"""Thin torch front-end over the C ABI: PyTorch only owns device memory and streams here.
+
+Every function takes/returns CUDA (ROCm) float64 tensors laid out exactly like the
+reference's numpy arrays and launches on torch's current stream.  There is no CPU path:
+a CPU tensor or a missing library raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+f64 = torch.float64
+
+
+def _chk(t, name, dtype=f64):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.SsaHipError("%s must be a CUDA tensor (the hot path has no CPU fallback)" % name)
+    if t.dtype != dtype or not t.is_contiguous():
+        raise _lib.SsaHipError("%s must be contiguous %s" % (name, dtype))
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def as_dev(a, device="cuda", dtype=f64):
+    return torch.as_tensor(a, dtype=dtype).contiguous().to(device)
+
+
+def propagate(x, dt, propagator=_lib.PROP_FG, out=None):
+    """P1-P5: fx_xyz_farnocchia for every row of x[n,6]."""
+    lib = _lib.load()
+    n = x.shape[0]
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(lib.ssa_propagate_f64(_chk(x, "x"), _chk(out, "out"), n, float(dt), int(propagator), _stream()),
+               "ssa_propagate_f64")
+    return out
+
+
+def kepler_elements(x, dt):
+    lib = _lib.load()
+    n = x.shape[0]
+    coe = torch.empty((n, 8), dtype=f64, device=x.device)
+    _lib.check(lib.ssa_kepler_elements_f64(_chk(x, "x"), _chk(coe, "coe"), n, float(dt), _stream()),
+               "ssa_kepler_elements_f64")
+    return coe
+
+
+def robust_cholesky(A):
+    """U2: returns (U[n,6,6] upper, rung[n])."""
+    lib = _lib.load()
+    n = A.shape[0]
+    U = torch.empty_like(A)
+    rung = torch.empty(n, dtype=torch.int32, device=A.device)
+    _lib.check(lib.ssa_robust_cholesky6_f64(_chk(A, "A"), _chk(U, "U"), _chk(rung, "rung", torch.int32), n, _stream()),
+               "ssa_robust_cholesky6_f64")
+    return U, rung
+
+
+def sigma_points(x, P, scale):
+    """U1: returns (sigmas[n,13,6], fail[n])."""
+    lib = _lib.load()
+    n = x.shape[0]
+    sig = torch.empty((n, 13, 6), dtype=f64, device=x.device)
+    fail = torch.empty(n, dtype=torch.int32, device=x.device)
+    _lib.check(lib.ssa_sigma_points_f64(_chk(x, "x"), _chk(P, "P"), float(scale), _chk(sig, "sig"),
+                                        _chk(fail, "fail", torch.int32), n, _stream()), "ssa_sigma_points_f64")
+    return sig, fail
+
+
+def hx_aer(x, M, consts):
+    """H1: az/el/range of x[n,>=3] seen through GCRS->ITRS matrix M[3,3]."""
+    lib = _lib.load()
+    n = x.shape[0]
+    z = torch.empty((n, 3), dtype=f64, device=x.device)
+    _lib.check(lib.ssa_hx_aer_f64(_chk(x, "x"), x.shape[1], _chk(M, "M"), C.byref(consts), _chk(z, "z"), n, _stream()),
+               "ssa_hx_aer_f64")
+    return z
+
+
+def mean_z_uvw(sigmas, consts):
+    lib = _lib.load()
+    n = sigmas.shape[0]
+    zp = torch.empty((n, 3), dtype=f64, device=sigmas.device)
+    _lib.check(lib.ssa_mean_z_uvw_f64(_chk(sigmas, "sigmas"), C.byref(consts), _chk(zp, "zp"), n, _stream()),
+               "ssa_mean_z_uvw_f64")
+    return zp
+
+
+def residual_z_aer(a, b):
+    lib = _lib.load()
+    n = a.shape[0]
+    c = torch.empty_like(a)
+    _lib.check(lib.ssa_residual_z_aer_f64(_chk(a, "a"), _chk(b, "b"), _chk(c, "c"), n, _stream()),
+               "ssa_residual_z_aer_f64")
+    return c
+
+
+def visible_mask(x_true, M, consts, want_el=False):
+    """V1: object_visibility() for every row of x_true[n,6]."""
+    lib = _lib.load()
+    n = x_true.shape[0]
+    mask = torch.empty(n, dtype=torch.uint8, device=x_true.device)
+    el = torch.empty(n, dtype=f64, device=x_true.device) if want_el else None
+    _lib.check(lib.ssa_visible_mask_f64(_chk(x_true, "x_true"), _chk(M, "M"), C.byref(consts),
+                                        _chk(mask, "mask", torch.uint8), _chk(el, "el") if want_el else None, n,
+                                        _stream()), "ssa_visible_mask_f64")
+    return (mask, el) if want_el else mask
+
+
+def observe(x_true, x, P, obs=None, metrics=None):
+    """O1/O2: observations() + error() -> obs[n,12], metrics[4,n]."""
+    lib = _lib.load()
+    n = x.shape[0]
+    obs = torch.empty((n, 12), dtype=f64, device=x.device) if obs is None else obs
+    metrics = torch.empty((4, n), dtype=f64, device=x.device) if metrics is None else metrics
+    _lib.check(lib.ssa_observe_f64(_chk(x_true, "x_true"), _chk(x, "x"), _chk(P, "P"), _chk(obs, "obs"),
+                                   _chk(metrics, "metrics"), n, _stream()), "ssa_observe_f64")
+    return obs, metrics
+
+
+def aer_obs(x, P, M, consts, out=None):
+    """O4: aer_obs() -> out[n,4]."""
+    lib = _lib.load()
+    n = x.shape[0]
+    out = torch.empty((n, 4), dtype=f64, device=x.device) if out is None else out
+    _lib.check(lib.ssa_aer_obs_f64(_chk(x, "x"), _chk(P, "P"), _chk(M, "M"), C.byref(consts), _chk(out, "out"), n,
+                                   _stream()), "ssa_aer_obs_f64")
+    return out
+
+
+def reward_stats(metrics, status, n_obj, n_env=1, out=None):
+    """O3: per-env reductions -> stats[E, STAT_STRIDE]."""
+    lib = _lib.load()
+    out = torch.empty((n_env, _lib.STAT_STRIDE), dtype=f64, device=metrics.device) if out is None else out
+    _lib.check(lib.ssa_reward_stats_f64(_chk(metrics, "metrics"), _chk(status, "status", torch.int32),
+                                        _chk(out, "stats"), int(n_obj), int(n_env), _stream()), "ssa_reward_stats_f64")
+    return out
+
+
+def env_step(consts, params):
+    """E1: the fused step.  `params` is a filled _lib.ssa_step_params."""
+    lib = _lib.load()
+    _lib.check(lib.ssa_env_step_f64(C.byref(consts), C.byref(params), _stream()), "ssa_env_step_f64")

@@ -1,0 +1,111 @@
+"""HotPathEngine: device-resident state of E environments x m objects and the per-step
+launch sequence (fused step kernel + reward statistics kernel).
+
+Data layout in HBM (all float64, the reference's own array-of-structures shapes so a
+history slot is byte-identical to the reference's `x_true[i]`, `x_filter[i]`, `P_filter[i]`,
+`obs[i]` numpy slices -- ssa_tasker_simple_2.py:132-161):
+
+    x_true  [H][E*m][6]        x_filter [H][E*m][6]       P_filter [H][E*m][6][6]
+    obs     [H][E*m][12]       metrics  [H][E][4][m]      stats    [H][E][8]
+    upd     [H][E][64]         status   [E*m] int32
+
+H is the history depth: the reference keeps the whole episode (H = n steps); with 288 GB of
+HBM that is affordable up to hundreds of thousands of objects, and the step kernel then
+reads slot i-1 and writes slot i with no copy.  H = 2 is the ping-pong minimum (what
+agents.py needs: P_filter[i] and P_filter[i-1]).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, device
+
+f64 = torch.float64
+
+
+class HotPathEngine:
+    def __init__(self, consts, n_obj, n_env, trans, z_noise, history, device_name="cuda",
+                 zn_stride_env=None, zn_stride_time=None):
+        _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.SsaHipError("no GPU visible: the ssa-gym hot path runs on MI355X only (no CPU fallback)")
+        self.consts = consts
+        self.m, self.E, self.H = int(n_obj), int(n_env), int(history)
+        if self.H < 2:
+            raise ValueError("history depth must be >= 2")
+        self.dev = torch.device(device_name)
+        N = self.m * self.E
+        d = self.dev
+        self.x_true = torch.zeros((self.H, N, 6), dtype=f64, device=d)
+        self.x_filter = torch.zeros((self.H, N, 6), dtype=f64, device=d)
+        self.P_filter = torch.zeros((self.H, N, 6, 6), dtype=f64, device=d)
+        self.obs = torch.zeros((self.H, N, 12), dtype=f64, device=d)
+        self.metrics = torch.full((self.H, self.E, 4, self.m), float("nan"), dtype=f64, device=d)
+        self.stats = torch.zeros((self.H, self.E, _lib.STAT_STRIDE), dtype=f64, device=d)
+        self.upd = torch.zeros((self.H, self.E, _lib.UPD_STRIDE), dtype=f64, device=d)
+        self.status = torch.zeros(N, dtype=torch.int32, device=d)
+        self.trans = device.as_dev(np.asarray(trans, dtype=np.float64).reshape(-1, 9), d)
+        self.n_time = self.trans.shape[0]
+        self.z_noise = z_noise if isinstance(z_noise, torch.Tensor) else device.as_dev(z_noise, d)
+        # default strides for z_noise[E][n_time][m][3]
+        self.zn_stride_time = self.m * 3 if zn_stride_time is None else int(zn_stride_time)
+        self.zn_stride_env = self.n_time * self.m * 3 if zn_stride_env is None else int(zn_stride_env)
+        self.env_time0 = torch.zeros(self.E, dtype=torch.int32, device=d)   # per-env time origin
+        self.actions = torch.full((self.E,), -1, dtype=torch.int32, device=d)
+        self._p = _lib.ssa_step_params()
+        self._p.n_obj, self._p.n_env = self.m, self.E
+        self._p.status = self.status.data_ptr()
+        self._p.trans = self.trans.data_ptr()
+        self._p.env_time = self.env_time0.data_ptr()
+        self._p.z_noise = self.z_noise.data_ptr()
+        self._p.zn_stride_env, self._p.zn_stride_time = self.zn_stride_env, self.zn_stride_time
+        self._p.n_time = self.n_time
+        self._lib = _lib.load()
+        self._cref = C.byref(self.consts)
+        self._pref = C.byref(self._p)
+        # element strides of one history slot
+        self._sx, self._sP, self._so = N * 6 * 8, N * 36 * 8, N * 12 * 8
+        self._sm, self._ss, self._su = self.E * 4 * self.m * 8, self.E * _lib.STAT_STRIDE * 8, self.E * _lib.UPD_STRIDE * 8
+        self._bx_t, self._bx, self._bP = self.x_true.data_ptr(), self.x_filter.data_ptr(), self.P_filter.data_ptr()
+        self._bo, self._bm, self._bs, self._bu = (self.obs.data_ptr(), self.metrics.data_ptr(), self.stats.data_ptr(),
+                                                  self.upd.data_ptr())
+
+    # ------------------------------------------------------------------ state in
+    def load_state(self, slot, x_true, x_filter, P_filter):
+        """reset(): place the initial truth / estimates / covariances in history slot `slot`
+        and compute obs + metrics + stats for it (ssa_tasker_simple_2.py:228-229)."""
+        N = self.m * self.E
+        self.x_true[slot].copy_(device.as_dev(np.asarray(x_true).reshape(N, 6), self.dev))
+        self.x_filter[slot].copy_(device.as_dev(np.asarray(x_filter).reshape(N, 6), self.dev))
+        self.P_filter[slot].copy_(device.as_dev(np.asarray(P_filter).reshape(N, 6, 6), self.dev))
+        self.status.zero_()
+        for e in range(self.E):
+            sl = slice(e * self.m, (e + 1) * self.m)
+            device.observe(self.x_true[slot, sl], self.x_filter[slot, sl], self.P_filter[slot, sl],
+                           obs=self.obs[slot, sl], metrics=self.metrics[slot, e])
+        device.reward_stats(self.metrics[slot], self.status, self.m, self.E, out=self.stats[slot])
+
+    # ------------------------------------------------------------------ one step
+    def launch_step(self, slot_in, slot_out, time_offset, actions_ptr=None, stream=None):
+        """enqueue step kernel + statistics kernel; asynchronous, no host sync."""
+        p = self._p
+        p.time_offset = int(time_offset)
+        p.x_true_in, p.x_true_out = self._bx_t + slot_in * self._sx, self._bx_t + slot_out * self._sx
+        p.x_in, p.x_out = self._bx + slot_in * self._sx, self._bx + slot_out * self._sx
+        p.P_in, p.P_out = self._bP + slot_in * self._sP, self._bP + slot_out * self._sP
+        p.obs = self._bo + slot_out * self._so
+        p.metrics = self._bm + slot_out * self._sm
+        p.upd = self._bu + slot_out * self._su
+        p.actions = self.actions.data_ptr() if actions_ptr is None else actions_ptr
+        s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        rc = self._lib.ssa_env_step_f64(self._cref, self._pref, s)
+        if rc:
+            raise _lib.SsaHipError("ssa_env_step_f64 failed with code %d" % rc)
+        rc = self._lib.ssa_reward_stats_f64(p.metrics, self._p.status, self._bs + slot_out * self._ss, self.m, self.E, s)
+        if rc:
+            raise _lib.SsaHipError("ssa_reward_stats_f64 failed with code %d" % rc)
+
+    def set_actions(self, actions):
+        a = torch.as_tensor(np.asarray(actions, dtype=np.int32).reshape(self.E))
+        self.actions.copy_(a, non_blocking=True)

@@ -1,0 +1,154 @@
+"""Drop-in mirror of the reference's envs/dynamics.py operator names (SURVEY 8b "operator
+plug points").  Each name is (a) a TOKEN the environment recognises and maps to a fused
+kernel variant, and (b) directly callable with the reference's signature on numpy inputs --
+the call runs the corresponding HIP operator through the C ABI (single launch, host
+round trip; for exploration and tests, not the hot path).  There is no CPU implementation
+behind any of them.
+"""
+import numpy as np
+
+from .. import _lib, host
+
+
+def _dev():
+    import torch
+    from .. import device
+    if not torch.cuda.is_available():
+        raise _lib.SsaHipError("operator call needs a GPU: the hot path has no CPU fallback")
+    return torch, device
+
+
+class _Operator:
+    """callable token; `kernel_id` is what SSA_Tasker_Env dispatches on."""
+    kernel_id = None
+    reference = None
+
+    def __repr__(self):
+        return "<ssa-gym_amd operator %s (reference %s)>" % (type(self).__name__, self.reference)
+
+
+class _FxFarnocchia(_Operator):
+    kernel_id = ("fx", "farnocchia")
+    reference = "envs/farnocchia.py:1054 fx_xyz_farnocchia"
+
+    def __init__(self, propagator):
+        self.propagator = propagator
+
+    def __call__(self, x, dt):
+        torch, device = _dev()
+        xd = device.as_dev(np.asarray(x, dtype=np.float64).reshape(1, 6))
+        prop = {'elements': _lib.PROP_ELEMENTS, 'fg': _lib.PROP_FG}[self.propagator]
+        return device.propagate(xd, float(dt), prop).cpu().numpy().reshape(6)
+
+
+class _HxAer(_Operator):
+    kernel_id = ("hx", "aer")
+    reference = "envs/dynamics.py:219 hx_aer_erfa"
+
+    def __call__(self, x_gcrs, trans_matrix, observer_lla, observer_itrs=None, time=None):
+        torch, device = _dev()
+        c = _lib.ssa_consts()
+        lla = np.asarray(observer_lla, dtype=np.float64)
+        c.enu[:] = host.enu_matrix(lla).reshape(9)
+        c.obs_itrs[:] = host.lla2ecef(lla) if observer_itrs is None else np.asarray(observer_itrs, dtype=np.float64)
+        x = np.asarray(x_gcrs, dtype=np.float64).reshape(1, -1)[:, :3].copy()
+        z = device.hx_aer(device.as_dev(x), device.as_dev(np.asarray(trans_matrix, dtype=np.float64).reshape(3, 3)), c)
+        return z.cpu().numpy().reshape(3)
+
+
+class _HxXyz(_Operator):
+    kernel_id = ("hx", "xyz")
+    reference = "envs/dynamics.py:207 hx_xyz"
+
+    def __call__(self, x_gcrs, trans_matrix=None, observer_lla=None, observer_itrs=None, time=None):
+        return np.asarray(x_gcrs)[:3]
+
+
+class _MeanZUvw(_Operator):
+    kernel_id = ("mean_z", "uvw")
+    reference = "envs/dynamics.py:343 mean_z_uvw"
+
+    def __call__(self, sigmas, Wm):
+        torch, device = _dev()
+        Wm = np.asarray(Wm, dtype=np.float64)
+        sig = np.asarray(sigmas, dtype=np.float64)
+        if sig.shape != (13, 3) or not np.all(Wm[1:] == Wm[1]):
+            raise _lib.SsaHipError("mean_z_uvw kernel handles Merwe sigma sets: 13 points, Wm[1:] uniform")
+        c = _lib.ssa_consts()
+        c.Wi = float(Wm[1])
+        c.sum_wm_m1, _ = host.exact_weight_sums(Wm, Wm)
+        return device.mean_z_uvw(device.as_dev(sig.reshape(1, 13, 3)), c).cpu().numpy().reshape(3)
+
+
+class _MeanXyz(_Operator):
+    kernel_id = ("mean_z", "xyz")
+    reference = "envs/dynamics.py:276 mean_xyz"
+
+    def __call__(self, a, w):
+        raise _lib.SsaHipError("mean_xyz exists only fused inside the update kernel (obs_type='xyz')")
+
+
+class _ResidualAer(_Operator):
+    kernel_id = ("residual_z", "aer")
+    reference = "envs/dynamics.py:260 residual_z_aer"
+
+    def __call__(self, a, b):
+        torch, device = _dev()
+        a = device.as_dev(np.asarray(a, dtype=np.float64).reshape(1, 3))
+        b = device.as_dev(np.asarray(b, dtype=np.float64).reshape(1, 3))
+        return device.residual_z_aer(a, b).cpu().numpy().reshape(3)
+
+
+class _ResidualXyz(_Operator):
+    kernel_id = ("residual_z", "xyz")
+    reference = "envs/dynamics.py:271 residual_xyz"
+
+    def __call__(self, a, b):
+        return np.subtract(a, b)
+
+
+class _RobustCholesky(_Operator):
+    kernel_id = ("msqrt", "robust_cholesky")
+    reference = "envs/dynamics.py:402 robust_cholesky"
+
+    def __call__(self, a):
+        torch, device = _dev()
+        A = device.as_dev(np.asarray(a, dtype=np.float64).reshape(1, 6, 6))
+        U, rung = device.robust_cholesky(A)
+        if int(rung.item()) == 16:
+            raise np.linalg.LinAlgError
+        return U.cpu().numpy().reshape(6, 6)
+
+
+fx_xyz_farnocchia = _FxFarnocchia('fg')            # default: reduced strong-elliptic form (SSA_PROP_FG)
+fx_xyz_farnocchia_elements = _FxFarnocchia('elements')  # operation-by-operation variant (SSA_PROP_ELEMENTS)
+hx_aer_erfa = _HxAer()
+hx_xyz = _HxXyz()
+mean_z_uvw = _MeanZUvw()
+mean_xyz = _MeanXyz()
+residual_z_aer = _ResidualAer()
+residual_xyz = _ResidualXyz()
+robust_cholesky = _RobustCholesky()
+
+
+def kernel_id_of(fn, role):
+    """map a config callable to a fused-kernel variant; unknown callables are refused (the
+    reference would call arbitrary Python per sigma point; that is exactly the path this
+    package replaces, and there is deliberately no CPU fallback)."""
+    if isinstance(fn, _Operator):
+        kid = fn.kernel_id
+    elif role == "residual_z" and fn is np.subtract:
+        kid = ("residual_z", "xyz")
+    else:
+        # accept the reference's own functions by name, so an unmodified env_config works
+        table = {"fx_xyz_farnocchia": ("fx", "farnocchia"), "hx_aer_erfa": ("hx", "aer"), "hx_xyz": ("hx", "xyz"),
+                 "mean_z_uvw": ("mean_z", "uvw"), "mean_xyz": ("mean_z", "xyz"),
+                 "residual_z_aer": ("residual_z", "aer"), "residual_xyz": ("residual_z", "xyz"),
+                 "robust_cholesky": ("msqrt", "robust_cholesky")}
+        kid = table.get(getattr(fn, "__name__", None))
+    if kid is None or kid[0] != role:
+        raise NotImplementedError(
+            "env_config[%r]=%r has no fused MI355X kernel; supported: the reference's in-tree "
+            "fx_xyz_farnocchia, hx_aer_erfa/hx_xyz, mean_z_uvw/mean_xyz, residual_z_aer/np.subtract, "
+            "robust_cholesky (no CPU fallback by design)" % (role, fn))
+    return kid

@@ -1,0 +1,410 @@
+"""SSA_Tasker_Env: drop-in for the reference's envs/ssa_tasker_simple_2.py::SSA_Tasker_Env.
+
+Same constructor dict, env id, spaces, return shapes and inspectable attributes
+(SURVEY 8b); the per-object arithmetic of reset()/step() runs in the fused HIP kernels
+(engine.HotPathEngine).  Host code here is orchestration only: RNG draws in the reference's
+order, one launch per step, one small device->host copy for reward/done, lazy numpy views of
+the device-resident history.  Citations: ssa_tasker_simple_2.py:line in the reference.
+"""
+import time
+from copy import copy
+from datetime import timedelta
+
+import numpy as np
+
+from .. import _lib, host
+from . import dynamics, transformations
+from ._gymshim import Env, np_random, spaces
+from .results import error_failed
+
+
+class _History:
+    """numpy-indexable view of a device-resident history tensor [H][E*m][...] for ONE env.
+
+    `hist[i]` -> numpy array of step i (copied from HBM on access); `hist[i, j]`, `hist[i][mask]`,
+    negative indices and slices over the time axis work like on the reference's (n, m, ...) arrays.
+    Only the last H steps are resident when the env was built with a shorter history."""
+
+    def __init__(self, env, tensor, m_axis_len, tail_shape):
+        self._env, self._t = env, tensor
+        self.shape = (env.n, m_axis_len) + tuple(tail_shape)
+        self.dtype = np.dtype(np.float64)
+        self.ndim = len(self.shape)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def _slot(self, i):
+        env = self._env
+        i = int(i)
+        if i < 0:
+            i += env.n
+        if not 0 <= i < env.n:
+            raise IndexError(i)
+        H = env._engine.H
+        if i > env.i or i <= env.i - H:
+            if i > env.i:   # not simulated yet: the reference arrays hold zeros there after reset()
+                return np.zeros(self.shape[1:])
+            raise IndexError("step %d is no longer resident (history depth %d, current step %d); build the env "
+                             "with config['history'] = 'full'" % (i, H, env.i))
+        return self._t[i % H].cpu().numpy().reshape(self.shape[1:])
+
+    def __getitem__(self, idx):
+        if isinstance(idx, tuple):
+            head, rest = idx[0], idx[1:]
+        else:
+            head, rest = idx, ()
+        if isinstance(head, slice):
+            arr = np.stack([self._slot(i) for i in range(*head.indices(self.shape[0]))])
+            return arr[(slice(None),) + rest] if rest else arr
+        arr = self._slot(head)
+        return arr[rest] if rest else arr
+
+    def __array__(self, dtype=None, copy=None):
+        a = np.stack([self._slot(i) for i in range(self.shape[0])])
+        return a.astype(dtype) if dtype is not None else a
+
+
+class _Sparse:
+    """reference-shaped (n, m, k...) view of a quantity the reference stores only at [i, action]
+    (z_true, y: NaN elsewhere -- ssa_tasker_simple_2.py:139-142, 202)."""
+
+    def __init__(self, env, store, tail):
+        self._env, self._s = env, store
+        self.shape = (env.n, env.m) + tuple(tail)
+
+    def __getitem__(self, idx):
+        env = self._env
+        if isinstance(idx, tuple):
+            i, rest = idx[0], idx[1:]
+        else:
+            i, rest = idx, ()
+        if isinstance(i, slice):
+            return np.stack([self[k] for k in range(*i.indices(env.n))])[(slice(None),) + rest]
+        i = int(i) + (env.n if int(i) < 0 else 0)
+        row = np.full(self.shape[1:], np.nan)
+        a = env._upd_action[i]
+        if a >= 0:
+            row[a] = self._s[i]
+        return row[rest] if rest else row
+
+    def __array__(self, dtype=None, copy=None):
+        return np.stack([self[i] for i in range(self.shape[0])])
+
+
+class SSA_Tasker_Env(Env):
+    metadata = {'render.modes': ['live', 'none']}
+    visualization = None
+
+    def __init__(self, config=None):
+        s = time.time()
+        if config is None:
+            from . import env_config as config
+        self.runtime = {'__init__': 0, 'reset': 0, 'step': 0, 'step prep': 0, 'propagate next true state': 0,
+                        'perform predictions': 0, 'update with observation': 0, 'Observations and Reward': 0,
+                        'filter_error': 0, 'visible_objects': 0, 'object_visibility': 0, 'anees': 0,
+                        'failed_filters': 0, 'plot_sigma_delta': 0, 'plot_rewards': 0, 'plot_anees': 0,
+                        'plot_actions': 0, 'all_true_obs': 0, 'plot_visibility': 0, 'predict method': 0}
+        # ---- simulation configuration (:81-96)
+        self.t_0 = config['t_0']
+        self.dt = config['time_step']
+        self.n = config['steps']
+        self.m = config['rso_count']
+        self.obs_limit = np.radians(config['obs_limit'])
+        self.obs_returned = config['obs_returned']
+        self.reward_type = config['reward_type']
+        self.orbits = config['orbits']
+        self.obs_lla = np.array(config['observer']) * [host.deg2rad, host.deg2rad, 1]
+        self.obs_itrs = host.lla2ecef(self.obs_lla)
+        self.update_interval = config['update_interval']
+        self.i = 0
+        # ---- filter configuration (:97-118)
+        self.obs_type = config['obs_type']
+        if self.obs_type == 'aer':
+            self.z_sigma = config['z_sigma'] * np.array([host.arcsec2rad, host.arcsec2rad, 1])
+        elif self.obs_type == 'xyz':
+            self.z_sigma = np.asarray(config['z_sigma'], dtype=np.float64)
+        else:
+            print('Invalid Observation Type: ' + str(config['obs_type']))
+            raise SystemExit
+        self.x_sigma = np.array(config['x_sigma'])
+        self.Q = host.Q_discrete_white_noise(dim=2, dt=self.dt, var=config['q_sigma'] ** 2, block_size=3,
+                                             order_by_dim=False)
+        self.fx, self.hx = config['fx'], config['hx']
+        self.mean_z, self.residual_z, self.msqrt = config['mean_z'], config['residual_z'], config['msqrt']
+        self.alpha, self.beta, self.kappa = config['alpha'], config['beta'], config['kappa']
+        # operator plug points -> fused kernel variant (no CPU fallback for foreign callables)
+        fx_id = dynamics.kernel_id_of(self.fx, "fx")
+        hx_id = dynamics.kernel_id_of(self.hx, "hx")
+        mz_id = dynamics.kernel_id_of(self.mean_z, "mean_z")
+        rz_id = dynamics.kernel_id_of(self.residual_z, "residual_z")
+        dynamics.kernel_id_of(self.msqrt, "msqrt")
+        model = {(("hx", "aer"), ("mean_z", "uvw"), ("residual_z", "aer")): 'aer',
+                 (("hx", "xyz"), ("mean_z", "xyz"), ("residual_z", "xyz")): 'xyz'}.get((hx_id, mz_id, rz_id))
+        if model is None:
+            raise NotImplementedError("hx/mean_z/residual_z combination %s has no fused kernel" % ((hx_id, mz_id, rz_id),))
+        self._model = model
+        propagator = config.get('propagator', getattr(self.fx, 'propagator', 'fg'))
+        assert fx_id == ("fx", "farnocchia")
+        # ---- arrays (:120-161)
+        if config['P_0'] is None:
+            self.P_0 = np.copy(np.diag(self.x_sigma ** 2))
+        else:
+            self.P_0 = np.copy(config['P_0'])
+        if config['R'] is None:
+            self.R = np.diag(self.z_sigma ** 2)
+        else:
+            self.R = np.copy(config['R'])
+        self.time = [self.t_0 + (timedelta(seconds=self.dt) * i) for i in range(self.n)]
+        if config.get('trans_matrix') is not None:
+            self.trans_matrix = np.asarray(config['trans_matrix'], dtype=np.float64).reshape(-1, 3, 3)
+        else:
+            self.trans_matrix = transformations.trans_matrix_table(self.t_0, self.dt, self.n)
+        self.x_noise = np.empty(shape=(self.m, 6))
+        self.filters = []   # the reference keeps one filterpy object per RSO; state lives in HBM here
+        self.rewards = np.empty(self.n)
+        self.failed_filters_id = []
+        self.failed_filters_msg = ["None"] * self.m
+        self.actions = np.empty(self.n, dtype=int)
+        self.obs_taken = np.empty(self.n, dtype=bool)
+        self.x_failed = np.copy(host.X_FAILED)
+        self.P_failed = np.copy(host.P_FAILED)
+        self.visibility = []
+        self.sigmas_h = np.empty((self.n, 13, 3))
+        self.S = np.empty((self.n, self.m, 3, 3)) if self.n * self.m <= (1 << 22) else None
+        # ---- spaces (:163-177)
+        self.action_space = spaces.Discrete(self.m)
+        if self.obs_returned == 'flatten':
+            shp = (self.m * 12,)
+        elif self.obs_returned == 'aer':
+            shp = (self.m * 4,)
+            self.observation = np.zeros(self.m * 4)
+        else:
+            shp = (self.m, 12)
+        self.observation_space = spaces.Box(low=np.full(shp, -np.inf), high=np.full(shp, np.inf), dtype=np.float64)
+        # ---- device engine
+        hist = config.get('history', 'auto')
+        bytes_per_step = self.m * (6 + 6 + 36 + 12 + 4) * 8
+        if hist == 'auto':
+            hist = 'full' if self.n * bytes_per_step <= 64 * 2 ** 30 else 2
+        self._H = self.n if hist == 'full' else max(2, int(hist))
+        self._consts = host.make_consts(self.Q, self.R, self.alpha, self.beta, self.kappa, self.dt, self.obs_limit,
+                                        self.obs_lla, obs_type=self._model, propagator=propagator,
+                                        resample=bool(config.get('resample_sigmas', False)),
+                                        update_interval=self.update_interval)
+        self._engine = None
+        self._device_rng = bool(config.get('device_rng', False))
+        self.np_random = None
+        self.init_seed = self.seed(config.get('seed'))[0]
+        self.reset()
+        self.runtime['__init__'] += time.time() - s
+
+    # ------------------------------------------------------------------ gym API
+    def seed(self, seed=None):
+        self.np_random, seed = np_random(seed)   # old-gym hash_seed -> RandomState (:188-191)
+        self.init_seed = seed
+        return [seed]
+
+    def _build_engine(self):
+        from .. import engine
+        self._engine = engine.HotPathEngine(self._consts, self.m, 1, self.trans_matrix, self._z_noise_dev, self._H)
+        e = self._engine
+        self.x_true = _History(self, e.x_true, self.m, (6,))
+        self.x_filter = _History(self, e.x_filter, self.m, (6,))
+        self.P_filter = _History(self, e.P_filter, self.m, (6, 6))
+        self.obs = _History(self, e.obs, self.m, (12,))
+        self._met = [_History(self, e.metrics[:, 0, k], self.m, ()) for k in range(4)]
+        self.delta_pos, self.delta_vel, self.sigma_pos, self.sigma_vel = self._met
+
+    def reset(self):
+        s = time.time()
+        import torch
+        m, n = self.m, self.n
+        x_true0 = np.empty((m, 6))
+        N = self.orbits.shape[0]
+        for j in range(m):   # draw order of :206-209: (row, 6 normals) per object ...
+            x_true0[j] = self.orbits[self.np_random.randint(low=0, high=N), :]
+            self.x_noise[j] = self.np_random.normal(size=6) * self.x_sigma
+        x_filter0 = x_true0 + self.x_noise
+        # ... then n*m*3 normals (:219-221); RandomState.normal keeps its Box-Muller cache across
+        # calls, so one bulk draw consumes the stream exactly like the reference's n*m size-3 draws
+        if self._device_rng:
+            gen = torch.Generator(device="cuda").manual_seed(int(self.np_random.randint(0, 2 ** 31 - 1)))
+            zs = torch.as_tensor(self.z_sigma, dtype=torch.float64, device="cuda")
+            self._z_noise_dev = torch.randn((1, n, m, 3), dtype=torch.float64, device="cuda", generator=gen) * zs
+            self.z_noise = None
+        else:
+            self.z_noise = self.np_random.normal(size=(n, m, 3)) * self.z_sigma
+            self._z_noise_dev = torch.as_tensor(self.z_noise, dtype=torch.float64).to("cuda")
+        if self._engine is None:
+            self._build_engine()
+        else:
+            self._engine.z_noise.copy_(self._z_noise_dev.reshape(self._engine.z_noise.shape))
+        self._engine.load_state(0, x_true0, x_filter0, np.broadcast_to(self.P_0, (m, 6, 6)))
+        # tracking variables (:222-231)
+        self.actions[:], self.obs_taken[:], self.failed_filters_id, self.visibility = -1, False, [], []
+        self.failed_filters_msg = ["None"] * self.m
+        self.rewards[:] = 0
+        self.sigmas_h[:] = 0
+        if self.S is not None:
+            self.S[:] = np.nan
+        self._y = np.full((n, 3), np.nan)
+        self._z_true = np.full((n, 3), np.nan)
+        self._S_sel = np.full((n, 3, 3), np.nan)
+        self._upd_action = np.full(n, -1, dtype=int)
+        self.y = _Sparse(self, self._y, (3,))
+        self.z_true = _Sparse(self, self._z_true, (3,))
+        self._n_failed = 0
+        self._argmax_sigma_prev = None
+        self.i = 0
+        self._fetch_small(0)
+        self.runtime['reset'] += time.time() - s
+        return self._obs_out(reset=True)
+
+    def _fetch_small(self, i):
+        e = self._engine
+        slot = i % e.H
+        self._stats = e.stats[slot, 0].cpu().numpy()     # synchronises the stream
+        self._argmax_sigma = int(self._stats[_lib.STAT_ARGMAX_SPOS])
+
+    def _obs_out(self, reset=False):
+        e, slot = self._engine, self.i % self._engine.H
+        if self.obs_returned == 'flatten':
+            return e.obs[slot].cpu().numpy().reshape(-1)
+        elif self.obs_returned == 'aer':
+            self.observation = self.aer_obs(np.zeros(self.m * 4) if reset else self.observation)
+            return self.observation
+        return e.obs[slot].cpu().numpy()
+
+    def step(self, a):
+        step_s = time.time()
+        assert self.action_space.contains(a), "%r (%s) invalid" % (a, type(a))
+        self._argmax_sigma_prev = self._argmax_sigma
+        self.i += 1
+        i = self.i
+        self.actions[i] = np.copy(a)
+        e = self._engine
+        s = time.time()
+        self.runtime['step prep'] += s - step_s
+        # propagate + predict + update + observations/metrics + statistics: two launches (:265-322)
+        e.set_actions([int(a)])
+        e.launch_step((i - 1) % e.H, i % e.H, i)
+        rec = e.upd[i % e.H, 0].cpu().numpy()
+        self._fetch_small(i)
+        t_dev = time.time()
+        self.runtime['perform predictions'] += t_dev - s
+        # update bookkeeping (:292-315)
+        if rec[_lib.UPD_ACTION] >= 0:
+            self._upd_action[i] = int(a)
+            self._z_true[i] = rec[_lib.UPD_Z_TRUE:_lib.UPD_Z_TRUE + 3]
+            if rec[_lib.UPD_OBS_TAKEN] == 1.0:
+                self._y[i] = rec[_lib.UPD_Y:_lib.UPD_Y + 3]
+                self._S_sel[i] = rec[_lib.UPD_S:_lib.UPD_S + 9].reshape(3, 3)
+                if self.S is not None:
+                    self.S[i, int(a)] = self._S_sel[i]
+                self.sigmas_h[i] = rec[_lib.UPD_SIGMAS_H:_lib.UPD_SIGMAS_H + 39].reshape(13, 3)
+                self.obs_taken[i] = True
+        n_failed = int(self._stats[_lib.STAT_N_FAILED])
+        if n_failed != self._n_failed:
+            self._record_failures()
+        # reward / done (:324-354)
+        st = self._stats
+        max_dpos = st[_lib.STAT_MAX_DPOS]
+        done = False
+        if self.reward_type == 'jones':
+            if max_dpos > 5e6:
+                done, self.rewards[i] = True, 0
+            elif max_dpos < 3e4:
+                done, self.rewards[i] = True, 1
+            elif i + 1 >= self.n:
+                done, self.rewards[i] = True, 0
+            else:
+                done, self.rewards[i] = False, 0
+        elif self.reward_type == 'trinary':   # results.py:432
+            self.rewards[i] = (st[_lib.STAT_CNT_LT_1E4] + st[_lib.STAT_CNT_LT_1E7]) / self.m / 2
+        elif self.reward_type == 'shaped':
+            if max_dpos > 5e6:
+                done, self.rewards[i] = True, 0
+            elif max_dpos < 3e4:
+                done, self.rewards[i] = True, 1 - np.sum(self.rewards[:i])
+            elif a == self._argmax_sigma_prev:
+                self.rewards[i] = 1 / self.n
+            else:
+                self.rewards[i] = -1 / self.n
+        if i + 1 >= self.n:
+            done = True
+        obs = self._obs_out()
+        e_t = time.time()
+        self.runtime['Observations and Reward'] += e_t - t_dev
+        self.runtime['step'] += e_t - step_s
+        if self.obs_returned == 'flatten':
+            return obs, self.rewards[i], done, {}
+        return obs, np.nan_to_num(self.rewards[i], copy=False, nan=0.5, posinf=0.5, neginf=0.5), done, {}
+
+    # ------------------------------------------------------------------ failures (:369-382)
+    def _record_failures(self):
+        s = time.time()
+        status = self._engine.status.cpu().numpy()
+        kinds = {_lib.ST_PREDICT_NAN: ('predict', ', predict returned nan. '),
+                 _lib.ST_PREDICT_LINALG: ('predict', ', LinAlgError. '),
+                 _lib.ST_UPDATE_NAN: ('update', ', update returned nan. '),
+                 _lib.ST_UPDATE_LINALG: ('update', ', LinAlgError. ')}
+        for j in np.where(status != 0)[0]:
+            j = int(j)
+            if j in self.failed_filters_id:
+                continue
+            activity, error_type = kinds[int(status[j])]
+            prev = self.i - 1
+            msg = ["".join(['Object ', str(j), ' failed on ', activity, ' step ', str(self.i), error_type,
+                            str(np.round(error_failed(state=self.x_true[prev, j], x=self.x_filter[prev, j],
+                                                      P=np.diag(self.P_filter[prev, j])), 2))])]
+            self.failed_filters_msg[j] = copy(msg)
+            self.failed_filters_id.append(j)
+        self._n_failed = len(self.failed_filters_id)
+        self.runtime['filter_error'] += time.time() - s
+
+    def failed_filters(self):
+        if not self.failed_filters_id:
+            print("No failed Objects")
+        else:
+            print("Failed Objects: ", self.failed_filters_id)
+            for rso_id in self.failed_filters_id:
+                print(self.failed_filters_msg[rso_id])
+
+    # ------------------------------------------------------------------ visibility (:410-434)
+    def _mask(self):
+        from .. import device
+        e = self._engine
+        M = e.trans[self.i % e.n_time].reshape(3, 3)
+        return device.visible_mask(e.x_true[self.i % e.H], M, self._consts).cpu().numpy().astype(bool)
+
+    def visible_objects(self):
+        s = time.time()
+        viz = np.where(self._mask())[0]
+        self.runtime['visible_objects'] += time.time() - s
+        return viz
+
+    def object_visible(self, RSO_ID=[]):
+        if len(RSO_ID) == 0:
+            print('RSO ID expected, but not supplied')
+            return RSO_ID
+        return self._mask()[np.asarray(RSO_ID)]
+
+    def object_visibility(self):
+        s = time.time()
+        viz = self._mask()
+        self.runtime['object_visibility'] += time.time() - s
+        return viz
+
+    def aer_obs(self, obs):
+        """:834-840 -- [az, el, range, trace(P)] per object, NaN/inf -> 0.001."""
+        from .. import device
+        e = self._engine
+        slot = self.i % e.H
+        M = e.trans[self.i % e.n_time].reshape(3, 3)
+        out = device.aer_obs(e.x_filter[slot], e.P_filter[slot], M, self._consts).cpu().numpy().reshape(-1)
+        obs[:] = out
+        return obs
+
+    def render(self, mode='live'):
+        raise NotImplementedError("rendering/plots are outside the hot-path scope (SURVEY section 2, rows 1b/6b)")
