@@ -46,17 +46,24 @@ __device__ static double newton(bool hyper, double x0, double M, double ecc, int
     }
     return __builtin_nan("");
 }
+// S_x / dS_x_alt (farnocchia.py:692-760) sum (ecc - 1/(2k+3)) [(2k+3)] x^k until the term drops below
+// 1e-12 -- tens of thousands of terms as |x| -> 1.  Both series have closed forms, used here
+// (they agree with the truncated sums to the truncation tolerance):
+//   sum x^k/(2k+3) = (A(x) - 1)/x,  A = atanh(sqrt x)/sqrt x (x>0) | atan(sqrt -x)/sqrt -x (x<0)
+//   sum (2k+3) x^k = 2x/(1-x)^2 + 3/(1-x)
 __device__ static double S_x(double ecc, double x, bool alt)
 {
-    double S = 0.0, xk = 1.0;
-    for (int k = 0; k < 100000; ++k) {
-        double S_old = S;
-        double term = (ecc - 1.0 / (2 * k + 3)) * xk;
-        S += alt ? term * (2 * k + 3) : term;
-        xk *= x;
-        if (fabs(S - S_old) < 1e-12) return S;
+    if (!(fabs(x) < 1.0)) return __builtin_nan("");   // the reference asserts abs(x) < 1
+    const double omx = 1.0 - x;
+    if (alt) return ecc * (2.0 * x / (omx * omx) + 3.0 / omx) - 1.0 / omx;
+    if (fabs(x) < 0.05) {   // short series; the closed form cancels as x -> 0
+        double S = 0.0, xk = 1.0;
+        for (int k = 0; k < 12; ++k) { S += (ecc - 1.0 / (2 * k + 3)) * xk; xk *= x; }
+        return S;
     }
-    return __builtin_nan("");
+    const double sx = sqrt(fabs(x));
+    const double A = (x > 0.0) ? atanh(sx) / sx : atan(sx) / sx;
+    return ecc / omx - (A - 1.0) / x;
 }
 __device__ static double D_to_M_np(double D, double ecc)
 {
@@ -391,13 +398,14 @@ __global__ void __launch_bounds__(64) step_kernel(const StepK k)
     // branch needs no block barrier.
     const int act = valid ? p.actions[e] : -1;
     const int tix = valid ? p.env_time[e] + p.time_offset : 0;
+    const int tmod = (p.n_time > 0) ? tix % p.n_time : 0;   // row of `trans` / `z_noise` (episodes wrap)
     const bool interval_ok = (C.update_interval <= 1) || (tix % C.update_interval == 0);
     const bool my_update = valid && act >= 0 && (int64_t)act == j && interval_ok;
     if (my_update) {
         double* rec = p.upd ? p.upd + (int64_t)e * SSA_UPD_STRIDE : nullptr;
         bool taken = false, visible = false;
         if (st_new == SSA_ST_OK) {
-            const double* M = p.trans + (int64_t)(p.n_time > 0 ? tix % p.n_time : 0) * 9;
+            const double* M = p.trans + (int64_t)tmod * 9;
             double Mm[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) Mm[i] = M[i];
@@ -463,7 +471,7 @@ __global__ void __launch_bounds__(64) step_kernel(const StepK k)
                 // H4: residuals; lane 13 forms the innovation of the noisy measurement
                 double zin[3], rz[3];
                 if (l == 13) {
-                    const double* zn = p.z_noise + (int64_t)e * p.zn_stride_env + (int64_t)tix * p.zn_stride_time + (int64_t)act * 3;
+                    const double* zn = p.z_noise + (int64_t)e * p.zn_stride_env + (int64_t)tmod * p.zn_stride_time + (int64_t)act * 3;
 #pragma unroll
                     for (int c = 0; c < 3; ++c) zin[c] = z[c] + zn[c];
                 } else {

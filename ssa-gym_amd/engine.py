@@ -86,6 +86,22 @@ class HotPathEngine:
                            obs=self.obs[slot, sl], metrics=self.metrics[slot, e])
         device.reward_stats(self.metrics[slot], self.status, self.m, self.E, out=self.stats[slot])
 
+    def snapshot(self, slot):
+        """device-side copy of a history slot (initial state of an episode)."""
+        return (self.x_true[slot].clone(), self.x_filter[slot].clone(), self.P_filter[slot].clone(),
+                self.obs[slot].clone(), self.metrics[slot].clone(), self.stats[slot].clone())
+
+    def restore(self, slot, snap):
+        """reset(): device-to-device restore of an episode's initial state, asynchronous."""
+        xt, x, P, obs, met, st = snap
+        self.x_true[slot].copy_(xt)
+        self.x_filter[slot].copy_(x)
+        self.P_filter[slot].copy_(P)
+        self.obs[slot].copy_(obs)
+        self.metrics[slot].copy_(met)
+        self.stats[slot].copy_(st)
+        self.status.zero_()
+
     # ------------------------------------------------------------------ one step
     def launch_step(self, slot_in, slot_out, time_offset, actions_ptr=None, stream=None):
         """enqueue step kernel + statistics kernel; asynchronous, no host sync."""

@@ -339,7 +339,8 @@ class SSA_Tasker_Env(Env):
         self.runtime['step'] += e_t - step_s
         if self.obs_returned == 'flatten':
             return obs, self.rewards[i], done, {}
-        return obs, np.nan_to_num(self.rewards[i], copy=False, nan=0.5, posinf=0.5, neginf=0.5), done, {}
+        r = self.rewards[i]   # np.nan_to_num(..., nan=0.5, posinf=0.5, neginf=0.5) of a scalar (:365-367)
+        return obs, (r if np.isfinite(r) else np.float64(0.5)), done, {}
 
     # ------------------------------------------------------------------ failures (:369-382)
     def _record_failures(self):

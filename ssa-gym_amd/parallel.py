@@ -1,0 +1,142 @@
+"""Object-axis sharding of one environment across the GPUs of a node.
+
+Propagation and predict are independent per object and the single update touches only the
+object the action names, so the catalogue splits into contiguous blocks, one per rank; the only
+exchange is the per-step reassembly of the global observation vector plus the reward
+reductions.  Both travel in ONE all-gather per step (RCCL over xGMI through
+torch.distributed's "nccl" backend; "gloo" in the CPU tests): each rank contributes
+
+    [ aer_obs (4 doubles per local object: az, el, range, trace P -- ssa_tasker_simple_2.py:834) |
+      8 reward statistics (include/ssa_hip.h SSA_STAT_*) ]
+
+and every rank then holds the whole (4 * m_total) observation vector and reduces the statistics
+locally (max / sum / arg-max with global indices).  Messages are small (0.64 MB per rank at
+20 000 objects), so a single fully-connected all-gather over the 7 point-to-point xGMI links is
+the right collective; a separate all-reduce would only add a second launch latency.
+
+The local compute engine is injected (`LocalStepper` protocol), so that this host logic is
+exercised by world_size-2 gloo tests on CPU with an oracle-backed stepper; the product always
+injects the HIP engine (there is no CPU fallback in the product).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+STAT_STRIDE = 8
+STAT_MAX_DPOS, STAT_CNT_LT_1E4, STAT_CNT_LT_1E7, STAT_ARGMAX_SPOS, STAT_N_FAILED, STAT_MAX_SPOS = range(6)
+
+
+class ShardPlan:
+    """contiguous block partition of m_total objects over `world` ranks (sizes differ by <= 1)."""
+
+    def __init__(self, m_total, world, rank):
+        self.m_total, self.world, self.rank = int(m_total), int(world), int(rank)
+        base, rem = divmod(self.m_total, self.world)
+        self.sizes = [base + (1 if r < rem else 0) for r in range(self.world)]
+        self.offsets = np.concatenate([[0], np.cumsum(self.sizes)]).astype(np.int64)
+        self.lo, self.hi = int(self.offsets[rank]), int(self.offsets[rank + 1])
+        self.m_local = self.hi - self.lo
+        self.m_pad = max(self.sizes)   # all_gather_into_tensor needs equal contributions
+
+    def owner(self, a):
+        """global object index -> (rank, local index)"""
+        r = int(np.searchsorted(self.offsets, a, side="right") - 1)
+        return r, int(a - self.offsets[r])
+
+    def local_action(self, a):
+        """the action as seen by this rank: local index if it owns object a, else -1 (no update)."""
+        if a is None or a < 0:
+            return -1
+        r, j = self.owner(a)
+        return j if r == self.rank else -1
+
+
+class ShardedStepper:
+    """one env of m_total objects, one rank per shard."""
+
+    def __init__(self, plan, local, group=None):
+        self.plan, self.local, self.group = plan, local, group
+        dev = local.device
+        self.width = 4 * plan.m_pad + STAT_STRIDE
+        self.send = torch.zeros(self.width, dtype=torch.float64, device=dev)
+        self.recv = torch.zeros(plan.world * self.width, dtype=torch.float64, device=dev)
+        self._work = None
+
+    def step(self, global_action, async_op=False):
+        p = self.plan
+        self.local.step(p.local_action(global_action))           # enqueue kernels (no sync)
+        self.local.pack_into(self.send[:4 * p.m_local], self.send[4 * p.m_pad:])   # aer obs + stats
+        if p.world > 1:
+            self._work = dist.all_gather_into_tensor(self.recv, self.send, group=self.group, async_op=async_op)
+        else:
+            self.recv.copy_(self.send)
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+
+    # ---- views of the reassembled global state (call after the collective has completed)
+    def global_obs(self):
+        p = self.plan
+        rows = self.recv.view(p.world, self.width)
+        return torch.cat([rows[r, :4 * p.sizes[r]] for r in range(p.world)])
+
+    def global_stats(self):
+        """reduce the per-rank statistics exactly as the single-GPU kernel would have produced them."""
+        p = self.plan
+        st = self.recv.view(p.world, self.width)[:, 4 * p.m_pad:].cpu().numpy()
+        out = np.zeros(STAT_STRIDE)
+        out[STAT_MAX_DPOS] = np.nan if np.isnan(st[:, STAT_MAX_DPOS]).any() else st[:, STAT_MAX_DPOS].max()
+        out[STAT_CNT_LT_1E4] = st[:, STAT_CNT_LT_1E4].sum()
+        out[STAT_CNT_LT_1E7] = st[:, STAT_CNT_LT_1E7].sum()
+        out[STAT_N_FAILED] = st[:, STAT_N_FAILED].sum()
+        sp = st[:, STAT_MAX_SPOS]
+        if np.isnan(sp).any():                       # np.argmax: first NaN wins
+            r = int(np.where(np.isnan(sp))[0][0])
+        else:
+            r = int(np.argmax(sp))                   # first rank holding the maximum = lowest global index
+        out[STAT_MAX_SPOS] = sp[r]
+        out[STAT_ARGMAX_SPOS] = p.offsets[r] + st[r, STAT_ARGMAX_SPOS]
+        return out
+
+
+class HipLocalStepper:
+    """LocalStepper over the HIP engine (the only one the product uses)."""
+
+    def __init__(self, engine, consts):
+        self.engine, self.consts = engine, consts
+        self.device = engine.dev
+        self.tick = 0
+        self._act = torch.zeros(1, dtype=torch.int32)
+        self._sched = None
+
+    def load_schedule(self, local_actions):
+        """pre-stage the local action of every coming step in HBM (no per-step host->device copy)."""
+        self._sched = torch.as_tensor(np.asarray(local_actions, dtype=np.int32)).to(self.device)
+        self._sched_k0 = self.tick
+
+    def step(self, local_action):
+        e = self.engine
+        self.tick += 1
+        if self._sched is not None:
+            k = (self.tick - 1 - self._sched_k0) % self._sched.numel()
+            e.launch_step((self.tick - 1) % e.H, self.tick % e.H, self.tick, actions_ptr=self._sched.data_ptr() + 4 * k)
+            return
+        self._act[0] = int(local_action)
+        e.actions.copy_(self._act)
+        e.launch_step((self.tick - 1) % e.H, self.tick % e.H, self.tick)
+
+    def reset_episode(self, snap, episode_len):
+        """start a new episode from a device-resident snapshot: the next step gets time index 1."""
+        e = self.engine
+        self.tick += (-self.tick) % episode_len          # advance to the next multiple of the episode length
+        e.restore(self.tick % e.H, snap)
+
+    def pack_into(self, obs_out, stats_out):
+        from . import device
+        e = self.engine
+        slot = self.tick % e.H
+        M = e.trans[self.tick % e.n_time]
+        device.aer_obs(e.x_filter[slot], e.P_filter[slot], M, self.consts, out=obs_out.view(-1, 4))
+        stats_out.copy_(e.stats[slot, 0])

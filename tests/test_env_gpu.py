@@ -1,0 +1,154 @@
+"""GPU tests of the drop-in environment (SURVEY 8b boundary): API surface, shapes, bookkeeping,
+agents.py-style attribute access, and a whole-episode comparison with the composite golden."""
+import numpy as np
+import pytest
+
+import oracle as orc
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def envs():
+    import torch
+    import ssa_gym_amd
+    ssa_gym_amd.build()
+    assert torch.cuda.is_available()
+    from ssa_gym_amd import envs as E
+    return E
+
+
+def cfg_from_golden(E, ep, **over):
+    m, n, dt, alpha, lim, otype, seed, resample = ep["params"]
+    from ssa_gym_amd.envs import dynamics as D
+    cfg = dict(E.env_config)
+    cfg.update(rso_count=int(m), steps=int(n), time_step=float(dt), alpha=float(alpha), obs_limit=float(lim),
+               reward_type='trinary', obs_returned='flatten', seed=0)
+    if int(otype) == 1:
+        cfg.update(obs_type='xyz', z_sigma=(5e2,) * 3, R=np.diag([5e2 ** 2] * 3), hx=D.hx_xyz, mean_z=D.mean_xyz,
+                   residual_z=np.subtract)
+    cfg.update(over)
+    return cfg
+
+
+def force_state(env, ep):
+    """parity is defined on identical INPUTS: overwrite the reset draw with the golden's."""
+    import torch
+    m = env.m
+    env.z_noise = ep["z_noise"].copy()
+    env._engine.z_noise.copy_(torch.as_tensor(ep["z_noise"]).reshape(env._engine.z_noise.shape))
+    env._engine.load_state(0, ep["x_true0"], ep["x0"], np.broadcast_to(ep["P0"], (m, 6, 6)))
+    env._fetch_small(0)
+
+
+def test_api_surface_and_shapes(envs):
+    cfg = dict(envs.env_config)
+    cfg.update(rso_count=12, steps=30, seed=3)
+    for mode, shape in (('flatten', (144,)), ('aer', (48,)), ('2darray', (12, 12))):
+        cfg['obs_returned'] = mode
+        env = envs.make('ssa_tasker_simple-v2', config=cfg)
+        assert env.action_space.n == 12 and env.observation_space.shape == shape
+        obs = env.reset()
+        assert obs.shape == shape and obs.dtype == np.float64
+        obs, r, done, info = env.step(env.action_space.sample())
+        assert obs.shape == shape and isinstance(done, bool) and info == {}
+        with pytest.raises(AssertionError):
+            env.step(12)                                   # :258 action-range assertion
+    # attributes other code reads (agents.py:8-79, compare_agents.py)
+    assert env.P_filter[env.i].shape == (12, 6, 6) and env.P_filter[env.i - 1].shape == (12, 6, 6)
+    assert env.delta_pos[env.i].shape == (12,) and env.x_true[env.i, 3].shape == (6,)
+    assert env.obs[env.i].shape == (12, 12) and env.n == 30 and env.dt == 20.0
+    assert set(env.runtime) >= {'step', 'reset', 'perform predictions', 'Observations and Reward'}
+    viz = env.visible_objects()
+    assert viz.dtype.kind == 'i' and len(viz) == 12        # obs_limit = -90 deg: everything visible
+    assert env.object_visible([0, 5]).shape == (2,)
+    # agent_naive_greedy / agent_shannon style consumers
+    trace = [np.trace(P) for P in env.P_filter[env.i]]
+    assert np.argmax(trace) in range(12)
+    with np.errstate(all='ignore'):
+        calc = [np.log(np.linalg.det(P) / np.linalg.det(Pi)) for P, Pi in zip(env.P_filter[env.i][viz], env.P_filter[env.i - 1][viz])]
+    assert len(calc) == 12
+
+
+def test_seed_reproducibility_and_draw_order(envs):
+    cfg = dict(envs.env_config)
+    cfg.update(rso_count=8, steps=20, seed=5)
+    e1, e2 = envs.make(config=cfg), envs.make(config=cfg)
+    assert np.array_equal(e1.x_true[0], e2.x_true[0]) and np.array_equal(e1.z_noise, e2.z_noise)
+    # reset() draw order (:206-221): (randint, normal(6)) per object, then n*m*3 normals
+    from ssa_gym_amd.envs._gymshim import np_random
+    rs, _ = np_random(5)
+    rows, noise = [], []
+    for _ in range(8):
+        rows.append(rs.randint(low=0, high=cfg['orbits'].shape[0]))
+        noise.append(rs.normal(size=6) * np.array(cfg['x_sigma']))
+    zn = np.array([[rs.normal(size=3) for _ in range(8)] for _ in range(20)]) * e1.z_sigma
+    assert np.array_equal(e1.x_true[0], cfg['orbits'][rows])
+    assert np.allclose(e1.x_filter[0], cfg['orbits'][rows] + np.array(noise), rtol=0, atol=0)
+    assert np.array_equal(e1.z_noise, zn)
+    for a in (1, 2, 3):
+        o1, r1, d1, _ = e1.step(a)
+        o2, r2, d2, _ = e2.step(a)
+        assert np.array_equal(o1, o2) and r1 == r2
+
+
+@pytest.mark.parametrize("name", ["episode_aer_m20_n480.npz", "episode_aer_vis15_m10_n120.npz", "episode_xyz_m10_n60.npz"])
+def test_episode_vs_composite_golden(envs, name):
+    """the env, driven with the golden's inputs and round-robin actions, against the composite
+    golden (restated step loop + reference callbacks): truth to rounding, identical observation
+    gating, filter tight until an object's second update, statistical afterwards (see
+    tests/test_oracle_golden.py for why)."""
+    ep = golden(name)
+    cfg = cfg_from_golden(envs, ep)
+    env = envs.make(config=cfg)
+    force_state(env, ep)
+    m, n = env.m, env.n
+    keep = list(ep["keep"])
+    ratios = []
+    for i in range(1, n):
+        obs, r, done, _ = env.step((i - 1) % m)
+        assert done == (i + 1 >= n)
+        if i in keep:
+            k = keep.index(i)
+            xt, xf = env.x_true[i], env.x_filter[i]
+            assert (np.linalg.norm(xt - ep["x_true"][k], axis=1) / np.linalg.norm(xt, axis=1)).max() < 1e-9
+            d = np.linalg.norm((xf - ep["x_filter"][k])[:, :3], axis=1)
+            sig = np.sqrt(np.trace(ep["P_filter"][k][:, :3, :3], axis1=1, axis2=2))
+            if i <= m:
+                assert np.all(d < 0.02 * sig + 40.0), (i, d.max())
+            ratios.append(np.median(d / sig))
+    assert np.array_equal(env.obs_taken[1:], ep["obs_taken"][1:])
+    assert not env.failed_filters_id
+    assert np.median(ratios) < 1.0
+    assert np.mean(np.abs(env.rewards - ep["rewards"])) < 5e-2
+    assert env.rewards.mean() > ep["rewards"].mean() - 5e-2
+    # innovation / z_true bookkeeping of the first (well conditioned) update
+    i1 = int(np.where(ep["obs_taken"])[0][0])
+    a1 = (i1 - 1) % m
+    np.testing.assert_allclose(env.z_true[i1, a1], ep["z_true"][i1], rtol=1e-9)
+    Sd = np.sqrt(np.diag(ep["S"][i1]))
+    assert np.max(np.abs(env.y[i1, a1] - ep["y"][i1]) / Sd) < 1e-3
+    assert np.isnan(env.y[i1, (a1 + 1) % m]).all()
+
+
+def test_reward_types_and_failure_bookkeeping(envs):
+    cfg = dict(envs.env_config)
+    cfg.update(rso_count=6, steps=12, seed=1, reward_type='jones')
+    env = envs.make(config=cfg)
+    obs, r, done, _ = env.step(0)
+    assert r == 0 and not done                                # 3e4 < max dpos < 5e6 after one step
+    # poison one filter -> 'predict returned nan' -> sentinel + failed list + jones terminates
+    import torch
+    env._engine.x_filter[env.i % env._engine.H, 3, 0] = float('nan')
+    obs, r, done, _ = env.step(1)
+    assert env.failed_filters_id == [3] and 'predict' in env.failed_filters_msg[3][0]
+    assert np.array_equal(env.x_filter[env.i, 3], env.x_failed) and done and r == 0
+    cfg.update(reward_type='shaped', seed=2)
+    env = envs.make(config=cfg)
+    best = int(np.argmax(env.sigma_pos[0]))
+    _, r, _, _ = env.step(best)
+    assert r == pytest.approx(1 / env.n)
+    worst = (int(np.argmax(env.sigma_pos[env.i])) + 1) % env.m
+    _, r, _, _ = env.step(worst)
+    assert r == pytest.approx(-1 / env.n)

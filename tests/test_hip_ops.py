@@ -106,6 +106,24 @@ def test_propagate_edge_cases(hip, oracle):
     for prop in (0, 1):
         y = hip.dev.propagate(hip.up(x), 20.0, propagator=prop).cpu().numpy()
         assert relnorm(y, ref, slice(0, 3)).max() < 1e-9, prop
+    # sweep across the conic boundary: near-parabolic elliptic / parabolic-ish / hyperbolic branches of
+    # delta_t_from_nu and nu_from_delta_t (farnocchia.py:876-919, 955-1004) at several anomalies
+    from ssa_gym_amd.catalogue import coe2rv_host
+    rs = np.random.RandomState(17)
+    n = 600
+    ecc = np.concatenate([rs.uniform(0.985, 0.9999, n // 3), rs.uniform(1.0001, 1.015, n // 3), rs.uniform(1.02, 3.0, n // 3)])
+    rp = rs.uniform(6.6e6, 4e7, n)
+    nu_max = np.where(ecc > 1, 0.8 * np.arccos(-1 / np.maximum(ecc, 1.0000001)), 3.0)
+    nu = rs.uniform(-1, 1, n) * nu_max
+    xs = coe2rv_host(rp * (1 + ecc), ecc, rs.uniform(0.1, 3.0, n), rs.uniform(0, 6.28, n), rs.uniform(0, 6.28, n), nu)
+    for dt in (20.0, 600.0):
+        ref = oracle.propagate(xs, dt)
+        fin = np.isfinite(ref).all(axis=1)
+        assert fin.mean() > 0.95
+        for prop in (0, 1):
+            y = hip.dev.propagate(hip.up(xs), dt, propagator=prop).cpu().numpy()
+            assert np.array_equal(np.isfinite(y).all(axis=1), fin)
+            assert relnorm(y[fin], ref[fin], slice(0, 3)).max() < 1e-8, (prop, dt)
     # NaN in -> NaN out (newton returns NaN; the env turns that into a failed filter)
     bad = x.copy()
     bad[0, 0] = np.nan
