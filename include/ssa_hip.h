@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SSA_ABI_VERSION 1
+#define SSA_ABI_VERSION 3
 
 /* error codes */
 #define SSA_OK 0
@@ -115,17 +115,19 @@ typedef struct ssa_step_params {
     const double *z_noise;     /* measurement noise; element (e, i, a) at
                                   z_noise + e*zn_stride_env + i*zn_stride_time + a*3   (:219-221) */
     int64_t zn_stride_env, zn_stride_time;
-    int32_t n_time;            /* rows in `trans` (bounds check: i % n_time) */
+    int32_t n_time;            /* rows in `trans` / time rows of `z_noise` (index = i % n_time) */
     int32_t reserved;
 } ssa_step_params;
 
-/* ---------------------------------------------------------------- fused hot path */
+/* ---------------------------------------------------------------- fused hot path (one launch) */
 int ssa_env_step_f64(const ssa_consts *c_host, const ssa_step_params *p_host, void *stream);
 
 /* O3: per-env reductions over metrics[E][4][m] and status -> stats[E][SSA_STAT_STRIDE]
  * (ssa_tasker_simple_2.py:324-354, results.py:432). */
-int ssa_reward_stats_f64(const double *metrics, const int32_t *status, double *stats, int64_t n_obj,
-                         int32_t n_env, void *stream);
+int ssa_reward_stats_f64(const double *metrics, const int32_t *status, double *stats, void *workspace,
+                         int64_t n_obj, int32_t n_env, void *stream);
+/* bytes of device workspace ssa_reward_stats_f64 needs for n_env environments */
+int64_t ssa_reward_stats_workspace_bytes(int32_t n_env);
 
 /* ----------------------------------------------------- single operators (rows of SURVEY 8a) */
 /* P1-P5  fx_xyz_farnocchia(x, dt) for n states (farnocchia.py:1054). */

@@ -35,7 +35,7 @@ class ssa_step_params(C.Structure):
 
 
 # constants of include/ssa_hip.h
-ABI_VERSION = 1
+ABI_VERSION = 3
 ST_OK, ST_PREDICT_NAN, ST_PREDICT_LINALG, ST_UPDATE_NAN, ST_UPDATE_LINALG = range(5)
 OBS_AER, OBS_XYZ = 0, 1
 PROP_ELEMENTS, PROP_FG = 0, 1
@@ -48,7 +48,8 @@ SIGNATURES = {
     "ssa_abi_version": (C.c_int, []),
     "ssa_build_info": (C.c_char_p, []),
     "ssa_env_step_f64": (C.c_int, [C.POINTER(ssa_consts), C.POINTER(ssa_step_params), c_dp]),
-    "ssa_reward_stats_f64": (C.c_int, [c_dp, c_dp, c_dp, C.c_int64, C.c_int32, c_dp]),
+    "ssa_reward_stats_f64": (C.c_int, [c_dp, c_dp, c_dp, c_dp, C.c_int64, C.c_int32, c_dp]),
+    "ssa_reward_stats_workspace_bytes": (C.c_int64, [C.c_int32]),
     "ssa_propagate_f64": (C.c_int, [c_dp, c_dp, C.c_int64, C.c_double, C.c_int32, c_dp]),
     "ssa_kepler_elements_f64": (C.c_int, [c_dp, c_dp, C.c_int64, C.c_double, c_dp]),
     "ssa_robust_cholesky6_f64": (C.c_int, [c_dp, c_dp, c_dp, C.c_int64, c_dp]),

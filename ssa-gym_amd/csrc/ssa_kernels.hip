@@ -180,7 +180,7 @@ __device__ static double nu_from_delta_t(double delta_t, double ecc, double k, d
 }
 }  // namespace gen
 
-__device__ __noinline__ void kepler_general(const double* x, double tof, double* out, double* diag)
+__device__ static void kepler_general_impl(const double* x, double tof, double* out, double* diag)
 {
     const double tol = 1e-8;
     const double* r = x;
@@ -238,8 +238,53 @@ __device__ __noinline__ void kepler_general(const double* x, double tof, double*
     }
 }
 
+__device__ __noinline__ Vec6 kepler_general_v(Vec6 x, double tof)
+{
+    Vec6 o;
+    kepler_general_impl(x.v, tof, o.v, nullptr);
+    return o;
+}
+__device__ __noinline__ Vec8 kepler_general_diag_v(Vec6 x, double tof, Vec6* out)
+{
+    Vec8 d;
+    Vec6 o;
+    kepler_general_impl(x.v, tof, o.v, d.v);
+    *out = o;
+    return d;
+}
+
+// robust_cholesky's jitter ladder (dynamics.py:402-417), out of line: only covariances that are
+// not positive definite as they stand ever reach it.
+// Works from / to LDS (the P tile and the U tile of the row) so that the caller's register arrays
+// stay in registers.
+__device__ __noinline__ int chol_ladder(const double* sP, double scale, double* sU, int writer)
+{
+    const double JIT[16] = {1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1.0, 10.0, 100.0, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9};
+    double a[21], u[21];
+    bool finite = true;
+    for (int i = 0; i < 6; ++i)
+        for (int c = i; c < 6; ++c) {
+            a[tri(i, c)] = scale * sP[i * 6 + c];
+            finite = finite && (fabs(a[tri(i, c)]) <= 1.79769313486231570e308);
+        }
+    int rung = 16;
+    if (finite) {
+        if (chol6_upper(a, 0.0, u)) rung = -1;
+        else
+            for (int t = 0; t < 16; ++t)
+                if (chol6_upper(a, JIT[t], u)) { rung = t; break; }
+    }
+    if (writer && rung != 16)
+        for (int i = 0; i < 6; ++i)
+            for (int c = 0; c < 6; ++c) sU[i * 6 + c] = (c >= i) ? u[tri(i, c)] : 0.0;
+    return rung;
+}
+
 // ------------------------------------------------------------------------------------------
-// fused env step
+// fused env step: ONE launch per step over every object.  The common path (plain Cholesky,
+// strong-elliptic Kepler) is inline; the robust_cholesky jitter ladder and the other conic branches
+// are out-of-line calls taken only by the lanes that need them.  The per-env UKF update runs in the
+// row that owns the selected object, hidden among the other waves of the launch.
 struct StepK {
     ssa_consts c;
     ssa_step_params p;
@@ -248,442 +293,516 @@ struct StepK {
 constexpr int OBJ_PER_WAVE = 4;
 constexpr double X_FAILED_POS = 1e20, X_FAILED_VEL = 1e12;  // ssa_tasker_simple_2.py:157-158
 
-template <int PROP>
-__global__ void __launch_bounds__(64) step_kernel(const StepK k)
+struct Tiles {   // LDS working set of one wavefront (4 objects)
+    double P[OBJ_PER_WAVE * 36];       // P_in, later P_out
+    double X[OBJ_PER_WAVE * 6];        // x_in, later x_out
+    double T[OBJ_PER_WAVE * 6];        // x_true_in, later x_true_out
+    double U[OBJ_PER_WAVE * 36];       // Cholesky factor rows
+    double D[OBJ_PER_WAVE * 13 * 6];   // centred propagated sigma points d_i
+    double M[OBJ_PER_WAVE * 12];       // s = Wi sum d_i | m' = mean - sigma_0
+    double Obs[OBJ_PER_WAVE * 12];
+    double Met[OBJ_PER_WAVE * 4];
+    int St[OBJ_PER_WAVE];
+};
+
+// per-row (16-lane) gather of one object's state into the tiles; objects of a fast-kernel wave are
+// consecutive, so the four rows together read one contiguous 1152-byte span of P (coalesced).
+SSA_DEV void load_object(Tiles& t, const ssa_step_params& p, int g, int l, int64_t obj, bool valid)
 {
-    __shared__ double sP[OBJ_PER_WAVE * 36];       // P_in tile, later P_out tile
-    __shared__ double sX[OBJ_PER_WAVE * 6];        // x_in tile, later x_out tile
-    __shared__ double sT[OBJ_PER_WAVE * 6];        // x_true_in tile, later x_true_out tile
-    __shared__ double sU[OBJ_PER_WAVE * 36];       // Cholesky factor rows
-    __shared__ double sD[OBJ_PER_WAVE * 13 * 6];   // centred propagated sigma points d_i
-    __shared__ double sM[OBJ_PER_WAVE * 12];       // s = Wi sum d_i | m' = mean - sigma_0
-    __shared__ double sObs[OBJ_PER_WAVE * 12];
-    __shared__ double sMet[OBJ_PER_WAVE * 4];
-    __shared__ int sSt[OBJ_PER_WAVE];
-
-    const ssa_consts& C = k.c;
-    const ssa_step_params& p = k.p;
-    const int lane = threadIdx.x;
-    const int g = lane >> 4, l = lane & 15;
-    const int64_t total = (int64_t)p.n_env * p.n_obj;
-    const int64_t base = (int64_t)blockIdx.x * OBJ_PER_WAVE;
-    const int64_t obj = base + g;
-    const bool valid = obj < total;
-
-    // ---- coalesced tile loads (block-contiguous in the reference's own AoS layout)
-    for (int t = lane; t < OBJ_PER_WAVE * 36; t += 64) {
-        int64_t gi = base * 36 + t;
-        sP[t] = gi < total * 36 ? p.P_in[gi] : 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        int idx = l + 16 * r;
+        if (idx < 36) t.P[g * 36 + idx] = valid ? p.P_in[obj * 36 + idx] : 0.0;
     }
-    if (lane < 24) {
-        int64_t gi = base * 6 + lane;
-        sX[lane] = gi < total * 6 ? p.x_in[gi] : 0.0;
-    } else if (lane >= 32 && lane < 56) {
-        int64_t gi = base * 6 + (lane - 32);
-        sT[lane - 32] = gi < total * 6 ? p.x_true_in[gi] : 0.0;
-    } else if (lane >= 56 && lane < 60) {
-        int64_t gi = base + (lane - 56);
-        sSt[lane - 56] = gi < total ? p.status[gi] : SSA_ST_PREDICT_NAN;
+    if (l < 6) t.X[g * 6 + l] = valid ? p.x_in[obj * 6 + l] : 0.0;
+    else if (l >= 8 && l < 14) t.T[g * 6 + l - 8] = valid ? p.x_true_in[obj * 6 + l - 8] : 0.0;
+    else if (l == 15) t.St[g] = valid ? p.status[obj] : SSA_ST_PREDICT_NAN;
+}
+
+SSA_DEV void store_object(const Tiles& t, const ssa_step_params& p, int g, int l, int64_t obj, bool valid, int e, int64_t j,
+                          bool write_status)
+{
+    if (!valid) return;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        int idx = l + 16 * r;
+        if (idx < 36) p.P_out[obj * 36 + idx] = t.P[g * 36 + idx];
     }
-    __syncthreads();
+    if (l < 6) p.x_out[obj * 6 + l] = t.X[g * 6 + l];
+    else if (l >= 8 && l < 14) p.x_true_out[obj * 6 + l - 8] = t.T[g * 6 + l - 8];
+    else if (l == 15 && write_status) p.status[obj] = t.St[g];
+    if (l < 12) p.obs[obj * 12 + l] = t.Obs[g * 12 + l];
+    if (l < 4) p.metrics[((int64_t)e * 4 + l) * p.n_obj + j] = t.Met[g * 4 + l];
+}
 
-    const int st_in = sSt[g];
-    const bool active = valid && st_in == SSA_ST_OK;
-    const int e = valid ? (int)(obj / p.n_obj) : 0;
-    const int64_t j = valid ? obj - (int64_t)e * p.n_obj : 0;
-
-    double xin[6], xt[6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        xin[c] = sX[g * 6 + c];
-        xt[c] = sT[g * 6 + c];
-    }
-
-    // ---- U1/U2: sigma points.  Every lane factorises (n+lambda) P redundantly (no divergence,
-    // no cross-lane traffic); lane 0 publishes the rows.
-    int rung;
-    {
-        double A[21], U[21];
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int c = i; c < 6; ++c) A[tri(i, c)] = C.scale * sP[g * 36 + i * 6 + c];
-        rung = robust_chol6(A, U);
-        if (l == 0) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int c = 0; c < 6; ++c) sU[g * 36 + i * 6 + c] = (c >= i) ? U[tri(i, c)] : 0.0;
+// O1/O2 for the row's object from the tiles (results.py:61, :37)
+SSA_DEV void observe_rows(Tiles& t, int g, int l)
+{
+    if (l < 12) t.Obs[g * 12 + l] = (l < 6) ? t.X[g * 6 + l] : t.P[g * 36 + 7 * (l - 6)];
+    if (l < 4) {
+        const int off = (l & 1) * 3;  // 0: position block, 1: velocity block
+        double v;
+        if (l < 2) {
+            double a0 = t.X[g * 6 + off] - t.T[g * 6 + off];
+            double a1 = t.X[g * 6 + off + 1] - t.T[g * 6 + off + 1];
+            double a2 = t.X[g * 6 + off + 2] - t.T[g * 6 + off + 2];
+            v = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+        } else {
+            v = sqrt(t.P[g * 36 + 7 * off] + t.P[g * 36 + 7 * (off + 1)] + t.P[g * 36 + 7 * (off + 2)]);
         }
+        t.Met[g * 4 + l] = v;
     }
-    __syncthreads();
-    const bool chol_fail = (rung == 16);
+}
 
-    const bool is_sigma = (l <= 12);
-    const bool is_pm = (l >= 1 && l <= 12);
-    double s[6];
-    {
-        const int krow = is_pm ? (l - 1) % 6 : 0;
-        const double sgn = (l >= 1 && l <= 6) ? 1.0 : ((l >= 7 && l <= 12) ? -1.0 : 0.0);
-        const bool use_filter = active && !chol_fail && l != 13;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            double u = sU[g * 36 + krow * 6 + c];
-            // inactive rows (failed / out-of-range objects) propagate the true state instead,
-            // so that their lanes stay on the fast path; their results are discarded.
-            s[c] = use_filter ? (xin[c] + sgn * u) : xt[c];
-        }
-    }
-
-    // ---- P1-P5: one Kepler solve per lane
-    double o[6];
-    kepler_step<PROP>(s, C.dt, o);
-
-    // ---- U3: unscented transform.  Centred form of x = dot(Wm, sigmas_f):
-    //   x = sigma_0' + m',   m' = (sum(Wm) - 1) sigma_0' + Wi sum_{i>=1} (sigma_i' - sigma_0')
-    // which is the reference's sum evaluated without the 1e8-fold cancellation of Wm0 ~ -2e8.
-    double s0[6], d[6], ssum[6], mp[6], xb[6];
-    bool nan_x = false;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        s0[c] = row_bcast(o[c], 0);
-        d[c] = is_pm ? (o[c] - s0[c]) : 0.0;
-        ssum[c] = C.Wi * row_allsum(d[c]);
-        mp[c] = C.sum_wm_m1 * s0[c] + ssum[c];
-        xb[c] = s0[c] + mp[c];
-        nan_x = nan_x || (xb[c] != xb[c]);
-    }
-    if (is_pm) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) sD[(g * 13 + l) * 6 + c] = d[c];
-    }
-    if (l == 0) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            sM[g * 12 + c] = ssum[c];
-            sM[g * 12 + 6 + c] = mp[c];
-            sX[g * 6 + c] = xb[c];
-        }
-    }
-    if (l == 13) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) sT[g * 6 + c] = o[c];  // x_true[i]
-    }
-    __syncthreads();
-    // P = sum Wc_i y_i y_i^T + Q with y_i = sigma_i' - x, expanded around sigma_0':
-    //   P = Wi sum_{i>=1} d_i d_i^T - m' s^T - s m'^T + sum(Wc) m' m'^T + Q
+// U3 (second half): P = sum Wc_i y_i y_i^T + Q with y_i = sigma_i' - x, expanded around sigma_0':
+//   P = Wi sum_{i>=1} d_i d_i^T - m' s^T - s m'^T + sum(Wc) m' m'^T + Q       (d_i, s, m' in LDS)
+SSA_DEV void covariance_rows(Tiles& t, const ssa_consts& C, int g, int l)
+{
     for (int idx = l; idx < 21; idx += 16) {
         int a = 0, rem = idx;
         while (rem >= 6 - a) { rem -= 6 - a; ++a; }
         const int b = a + rem;
         double acc = 0.0;
 #pragma unroll
-        for (int i = 1; i <= 12; ++i) acc = fma(sD[(g * 13 + i) * 6 + a], sD[(g * 13 + i) * 6 + b], acc);
-        const double sa_ = sM[g * 12 + a], sb_ = sM[g * 12 + b];
-        const double ma = sM[g * 12 + 6 + a], mb = sM[g * 12 + 6 + b];
+        for (int i = 1; i <= 12; ++i) acc = fma(t.D[(g * 13 + i) * 6 + a], t.D[(g * 13 + i) * 6 + b], acc);
+        const double sa_ = t.M[g * 12 + a], sb_ = t.M[g * 12 + b];
+        const double ma = t.M[g * 12 + 6 + a], mb = t.M[g * 12 + 6 + b];
         double Pab = C.Wi * acc - ma * sb_ - sa_ * mb + C.sum_wc * ma * mb + C.Q[a * 6 + b];
-        sP[g * 36 + a * 6 + b] = Pab;
-        sP[g * 36 + b * 6 + a] = Pab;
+        t.P[g * 36 + a * 6 + b] = Pab;
+        t.P[g * 36 + b * 6 + a] = Pab;
     }
-    __syncthreads();
+}
 
-    int st_new = st_in;
-    if (active) {
-        if (chol_fail) st_new = SSA_ST_PREDICT_LINALG;
-        else if (nan_x) st_new = SSA_ST_PREDICT_NAN;
-    }
+// ------------------------------------------------------------------------------------------
+#ifndef SSA_STEP_WAVES
+#define SSA_STEP_WAVES 3   // minimum waves per SIMD the register allocator must leave room for (<= 168 VGPRs)
+#endif
+template <int PROP>
+__global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_kernel(const StepK k)
+{
+    __shared__ Tiles t;
+    const ssa_consts& C = k.c;
+    const ssa_step_params& p = k.p;
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, l = lane & 15;
+    const int64_t total = (int64_t)p.n_env * p.n_obj;
+    {
+        const int64_t obj = (int64_t)blockIdx.x * OBJ_PER_WAVE + g;
+        const bool valid = obj < total;
+        const int e = valid ? (int)(obj / p.n_obj) : 0;
+        const int64_t j = valid ? obj - (int64_t)e * p.n_obj : 0;
+        // the action / time index of this object's env, fetched early (used after the transform)
+        const int act = valid ? p.actions[e] : -1;
+        const int tix = valid ? p.env_time[e] + p.time_offset : 0;
 
-    // ---- U5: the one update of this env (ssa_tasker_simple_2.py:292-315), done by the row
-    // that owns object `a`; all cross-lane traffic below is row-level (DPP / bpermute), so the
-    // branch needs no block barrier.
-    const int act = valid ? p.actions[e] : -1;
-    const int tix = valid ? p.env_time[e] + p.time_offset : 0;
-    const int tmod = (p.n_time > 0) ? tix % p.n_time : 0;   // row of `trans` / `z_noise` (episodes wrap)
-    const bool interval_ok = (C.update_interval <= 1) || (tix % C.update_interval == 0);
-    const bool my_update = valid && act >= 0 && (int64_t)act == j && interval_ok;
-    if (my_update) {
-        double* rec = p.upd ? p.upd + (int64_t)e * SSA_UPD_STRIDE : nullptr;
-        bool taken = false, visible = false;
-        if (st_new == SSA_ST_OK) {
-            const double* M = p.trans + (int64_t)tmod * 9;
-            double Mm[9];
+        load_object(t, p, g, l, valid ? obj : 0, valid);
+        __syncthreads();
+
+        const int st_in = t.St[g];
+        const bool active = valid && st_in == SSA_ST_OK;
+        double xin[6], xt[6];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) Mm[i] = M[i];
-            // sigma points handed to update(): the propagated ones or, with
-            // SSA_FLAG_RESAMPLE, a fresh set drawn from the prior
-            double sf[6];
+        for (int c = 0; c < 6; ++c) {
+            xin[c] = t.X[g * 6 + c];
+            xt[c] = t.T[g * 6 + c];
+        }
+        // U1/U2 with the robust_cholesky ladder
+        int rung;
+        {
+            double A[21], U[21];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) sf[c] = o[c];
-            bool rs_fail = false;
-            if (C.flags & SSA_FLAG_RESAMPLE) {
-                double A[21], U[21];
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int c = i; c < 6; ++c) A[tri(i, c)] = C.scale * t.P[g * 36 + i * 6 + c];
+            bool finite = true;
+#pragma unroll
+            for (int i = 0; i < 21; ++i) finite = finite && (fabs(A[i]) <= 1.79769313486231570e308);
+            const bool plain_ok = finite && chol6_upper(A, 0.0, U);
+            rung = plain_ok ? -1 : 16;
+            if (l == 0) {
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
 #pragma unroll
-                    for (int c = i; c < 6; ++c) A[tri(i, c)] = C.scale * sP[g * 36 + i * 6 + c];
-                rs_fail = robust_chol6(A, U) == 16;
-                const int krow = is_pm ? (l - 1) % 6 : 0;
-                const double sgn = (l >= 1 && l <= 6) ? 1.0 : ((l >= 7 && l <= 12) ? -1.0 : 0.0);
+                    for (int c = 0; c < 6; ++c) t.U[g * 36 + i * 6 + c] = (c >= i) ? U[tri(i, c)] : 0.0;
+            }
+            if (!plain_ok) rung = chol_ladder(&t.P[g * 36], C.scale, &t.U[g * 36], l == 0);
+        }
+        __syncthreads();
+        const bool chol_fail = (rung == 16);
+        const bool is_sigma = (l <= 12);
+        const bool is_pm = (l >= 1 && l <= 12);
+        double s[6];
+        {
+            const int krow = is_pm ? (l - 1) % 6 : 0;
+            const double sgn = (l >= 1 && l <= 6) ? 1.0 : ((l >= 7 && l <= 12) ? -1.0 : 0.0);
+            const bool use_filter = active && !chol_fail && l != 13;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                double u = t.U[g * 36 + krow * 6 + c];
+                s[c] = use_filter ? (xin[c] + sgn * u) : xt[c];
+            }
+        }
+        // P1-P5: one Kepler solve per lane; the strong-elliptic fast path inline, every other conic
+        // branch through the out-of-line complete restatement
+        double o[6];
+        if (!kepler_step_fast<PROP>(s, C.dt, o)) {
+            Vec6 si;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) si.v[c] = s[c];
+            Vec6 oo = kepler_general_v(si, C.dt);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) o[c] = oo.v[c];
+        }
+
+        double xb[6];
+        bool nan_x = false;
+        {
+            double ssum[6], mp[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                double s0 = row_bcast(o[c], 0);
+                double d = is_pm ? (o[c] - s0) : 0.0;
+                if (is_pm) t.D[(g * 13 + l) * 6 + c] = d;
+                ssum[c] = C.Wi * row_allsum(d);
+                mp[c] = C.sum_wm_m1 * s0 + ssum[c];
+                xb[c] = s0 + mp[c];
+                nan_x = nan_x || (xb[c] != xb[c]);
+            }
+            if (l == 0) {
 #pragma unroll
                 for (int c = 0; c < 6; ++c) {
-                    double u = 0.0;
+                    t.M[g * 12 + c] = ssum[c];
+                    t.M[g * 12 + 6 + c] = mp[c];
+                    t.X[g * 6 + c] = xb[c];
+                }
+            }
+            if (l == 13) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) t.T[g * 6 + c] = o[c];
+            }
+        }
+        __syncthreads();
+        covariance_rows(t, C, g, l);
+        __syncthreads();
+
+        int st_new = st_in;
+        if (active) {
+            if (chol_fail) st_new = SSA_ST_PREDICT_LINALG;
+            else if (nan_x) st_new = SSA_ST_PREDICT_NAN;
+        }
+
+        // ---- U5: the one update of this env (ssa_tasker_simple_2.py:292-315); all cross-lane traffic
+        // below is row-level (DPP / bpermute), so the branch needs no block barrier.
+        const bool interval_ok = (C.update_interval <= 1) || (tix % C.update_interval == 0);
+        const bool my_update = valid && act >= 0 && (int64_t)act == j && interval_ok;
+        if (my_update) {
+            const int tmod = (p.n_time > 0) ? tix % p.n_time : 0;   // row of `trans` / `z_noise` (episodes wrap)
+            double* rec = p.upd ? p.upd + (int64_t)e * SSA_UPD_STRIDE : nullptr;
+            bool taken = false, visible = false;
+            if (st_new == SSA_ST_OK) {
+                const double* M = p.trans + (int64_t)tmod * 9;
+                double Mm[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) Mm[i] = M[i];
+                // sigma points handed to update(): the propagated ones or, with
+                // SSA_FLAG_RESAMPLE, a fresh set drawn from the prior
+                double sf[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) sf[c] = o[c];
+                bool rs_fail = false;
+                if (C.flags & SSA_FLAG_RESAMPLE) {
+                    double A[21], U[21];
 #pragma unroll
                     for (int i = 0; i < 6; ++i)
-                        if (c >= i) u = (krow == i) ? U[tri(i, c)] : u;
-                    if (l != 13) sf[c] = xb[c] + sgn * u;
-                }
-            }
-            // H1/H2: measurement of every sigma point (lanes 0-12) and of the true state (lane 13)
-            double aer[3], z[3];
-            hx_aer(sf, Mm, C.enu, C.obs_itrs, aer);
-            if (C.obs_type == SSA_OBS_AER) { z[0] = aer[0]; z[1] = aer[1]; z[2] = aer[2]; }
-            else { z[0] = sf[0]; z[1] = sf[1]; z[2] = sf[2]; }
-            const double el_true = row_bcast(aer[1], 13);
-            visible = el_true >= C.obs_limit;  // object_visible(): elevation of the TRUE state (:418-425)
-            if (rec && l == 13) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) rec[SSA_UPD_Z_TRUE + c] = z[c];
-            }
-            if (visible && rs_fail) {
-                st_new = SSA_ST_UPDATE_LINALG;
-            } else if (visible) {
-                // H3/H5: predicted measurement
-                double zp[3];
-                const double wl = (l == 0) ? C.Wc0 : (is_pm ? C.Wi : 0.0);
-                if (C.obs_type == SSA_OBS_AER) {
-                    double uvw[3], um[3];
-                    aer2uvw(z, uvw);
+                        for (int c = i; c < 6; ++c) A[tri(i, c)] = C.scale * t.P[g * 36 + i * 6 + c];
+                    rs_fail = robust_chol6(A, U) == 16;
+                    const int krow = is_pm ? (l - 1) % 6 : 0;
+                    const double sgn = (l >= 1 && l <= 6) ? 1.0 : ((l >= 7 && l <= 12) ? -1.0 : 0.0);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        double u0 = row_bcast(uvw[c], 0);
-                        double du = is_pm ? (uvw[c] - u0) : 0.0;
-                        um[c] = u0 + (C.sum_wm_m1 * u0 + C.Wi * row_allsum(du));
-                    }
-                    uvw2aer(um, zp);
-                } else {
+                    for (int c = 0; c < 6; ++c) {
+                        double u = 0.0;
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        double u0 = row_bcast(z[c], 0);
-                        double du = is_pm ? (z[c] - u0) : 0.0;
-                        zp[c] = u0 + (C.sum_wm_m1 * u0 + C.Wi * row_allsum(du));
+                        for (int i = 0; i < 6; ++i)
+                            if (c >= i) u = (krow == i) ? U[tri(i, c)] : u;
+                        if (l != 13) sf[c] = xb[c] + sgn * u;
                     }
                 }
-                // H4: residuals; lane 13 forms the innovation of the noisy measurement
-                double zin[3], rz[3];
-                if (l == 13) {
-                    const double* zn = p.z_noise + (int64_t)e * p.zn_stride_env + (int64_t)tmod * p.zn_stride_time + (int64_t)act * 3;
+                // H1/H2: measurement of every sigma point (lanes 0-12) and of the true state (lane 13)
+                double aer[3], z[3];
+                hx_aer(sf, Mm, C.enu, C.obs_itrs, aer);
+                if (C.obs_type == SSA_OBS_AER) { z[0] = aer[0]; z[1] = aer[1]; z[2] = aer[2]; }
+                else { z[0] = sf[0]; z[1] = sf[1]; z[2] = sf[2]; }
+                const double el_true = row_bcast(aer[1], 13);
+                visible = el_true >= C.obs_limit;  // object_visible(): elevation of the TRUE state (:418-425)
+                if (rec && l == 13) {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) zin[c] = z[c] + zn[c];
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) zin[c] = z[c];
+                    for (int c = 0; c < 3; ++c) rec[SSA_UPD_Z_TRUE + c] = z[c];
                 }
-                if (C.obs_type == SSA_OBS_AER) residual_z_aer(zin, zp, rz);
-                else {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) rz[c] = zin[c] - zp[c];
-                }
-                double y[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) y[c] = row_bcast(rz[c], 13);
-                // S = sum Wc rz rz^T + R ; Pxz = sum Wc (sigma_f - x)(rz)^T
-                double S[9], Pxz[18], dx[6];
-#pragma unroll
-                for (int c = 0; c < 6; ++c) dx[c] = sf[c] - xb[c];
-#pragma unroll
-                for (int a = 0; a < 3; ++a)
-#pragma unroll
-                    for (int b = a; b < 3; ++b) {
-                        double v = row_allsum(wl * (rz[a] * rz[b]));
-                        S[a * 3 + b] = v + C.R[a * 3 + b];
-                        S[b * 3 + a] = v + C.R[b * 3 + a];
-                    }
-#pragma unroll
-                for (int a = 0; a < 6; ++a)
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) Pxz[a * 3 + b] = row_allsum(wl * (dx[a] * rz[b]));
-                double SI[9];
-                const bool inv_ok = inv3(S, SI);
-                if (!inv_ok) {
+                if (visible && rs_fail) {
                     st_new = SSA_ST_UPDATE_LINALG;
-                } else {
-                    taken = true;
-                    double K[18];
+                } else if (visible) {
+                    // H3/H5: predicted measurement
+                    double zp[3];
+                    const double wl = (l == 0) ? C.Wc0 : (is_pm ? C.Wi : 0.0);
+                    if (C.obs_type == SSA_OBS_AER) {
+                        double uvw[3], um[3];
+                        aer2uvw(z, uvw);
 #pragma unroll
-                    for (int a = 0; a < 6; ++a)
+                        for (int c = 0; c < 3; ++c) {
+                            double u0 = row_bcast(uvw[c], 0);
+                            double du = is_pm ? (uvw[c] - u0) : 0.0;
+                            um[c] = u0 + (C.sum_wm_m1 * u0 + C.Wi * row_allsum(du));
+                        }
+                        uvw2aer(um, zp);
+                    } else {
 #pragma unroll
-                        for (int b = 0; b < 3; ++b)
-                            K[a * 3 + b] = Pxz[a * 3] * SI[b] + Pxz[a * 3 + 1] * SI[3 + b] + Pxz[a * 3 + 2] * SI[6 + b];
-                    double xn[6];
-                    bool nan_u = false;
-#pragma unroll
-                    for (int a = 0; a < 6; ++a) {
-                        xn[a] = xb[a] + (K[a * 3] * y[0] + K[a * 3 + 1] * y[1] + K[a * 3 + 2] * y[2]);
-                        nan_u = nan_u || (xn[a] != xn[a]);
+                        for (int c = 0; c < 3; ++c) {
+                            double u0 = row_bcast(z[c], 0);
+                            double du = is_pm ? (z[c] - u0) : 0.0;
+                            zp[c] = u0 + (C.sum_wm_m1 * u0 + C.Wi * row_allsum(du));
+                        }
                     }
-                    double SKt[18];  // S K^T  [3][6]
+                    // H4: residuals; lane 13 forms the innovation of the noisy measurement
+                    double zin[3], rz[3];
+                    if (l == 13) {
+                        const double* zn = p.z_noise + (int64_t)e * p.zn_stride_env + (int64_t)tmod * p.zn_stride_time + (int64_t)act * 3;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) zin[c] = z[c] + zn[c];
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) zin[c] = z[c];
+                    }
+                    if (C.obs_type == SSA_OBS_AER) residual_z_aer(zin, zp, rz);
+                    else {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) rz[c] = zin[c] - zp[c];
+                    }
+                    double y[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) y[c] = row_bcast(rz[c], 13);
+                    // S = sum Wc rz rz^T + R ; Pxz = sum Wc (sigma_f - x)(rz)^T
+                    double S[9], Pxz[18], dx[6];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) dx[c] = sf[c] - xb[c];
 #pragma unroll
                     for (int a = 0; a < 3; ++a)
 #pragma unroll
-                        for (int b = 0; b < 6; ++b)
-                            SKt[a * 6 + b] = S[a * 3] * K[b * 3] + S[a * 3 + 1] * K[b * 3 + 1] + S[a * 3 + 2] * K[b * 3 + 2];
-                    // P -= K (S K^T): lanes 0..5 each own one row of P
-                    if (l < 6) {
-#pragma unroll
-                        for (int b = 0; b < 6; ++b) {
-                            double kr0 = 0.0, kr1 = 0.0, kr2 = 0.0;
-#pragma unroll
-                            for (int a = 0; a < 6; ++a) {
-                                kr0 = (l == a) ? K[a * 3] : kr0;
-                                kr1 = (l == a) ? K[a * 3 + 1] : kr1;
-                                kr2 = (l == a) ? K[a * 3 + 2] : kr2;
-                            }
-                            double corr = kr0 * SKt[b] + kr1 * SKt[6 + b] + kr2 * SKt[12 + b];
-                            sP[g * 36 + l * 6 + b] = sP[g * 36 + l * 6 + b] - corr;
+                        for (int b = a; b < 3; ++b) {
+                            double v = row_allsum(wl * (rz[a] * rz[b]));
+                            S[a * 3 + b] = v + C.R[a * 3 + b];
+                            S[b * 3 + a] = v + C.R[b * 3 + a];
                         }
-                    }
-                    if (l == 0) {
 #pragma unroll
-                        for (int a = 0; a < 6; ++a) sX[g * 6 + a] = xn[a];
-                    }
-                    if (nan_u) st_new = SSA_ST_UPDATE_NAN;
-                    if (rec) {
+                    for (int a = 0; a < 6; ++a)
+#pragma unroll
+                        for (int b = 0; b < 3; ++b) Pxz[a * 3 + b] = row_allsum(wl * (dx[a] * rz[b]));
+                    double SI[9];
+                    const bool inv_ok = inv3(S, SI);
+                    if (!inv_ok) {
+                        st_new = SSA_ST_UPDATE_LINALG;
+                    } else {
+                        taken = true;
+                        double K[18];
+#pragma unroll
+                        for (int a = 0; a < 6; ++a)
+#pragma unroll
+                            for (int b = 0; b < 3; ++b)
+                                K[a * 3 + b] = Pxz[a * 3] * SI[b] + Pxz[a * 3 + 1] * SI[3 + b] + Pxz[a * 3 + 2] * SI[6 + b];
+                        double xn[6];
+                        bool nan_u = false;
+#pragma unroll
+                        for (int a = 0; a < 6; ++a) {
+                            xn[a] = xb[a] + (K[a * 3] * y[0] + K[a * 3 + 1] * y[1] + K[a * 3 + 2] * y[2]);
+                            nan_u = nan_u || (xn[a] != xn[a]);
+                        }
+                        double SKt[18];  // S K^T  [3][6]
+#pragma unroll
+                        for (int a = 0; a < 3; ++a)
+#pragma unroll
+                            for (int b = 0; b < 6; ++b)
+                                SKt[a * 6 + b] = S[a * 3] * K[b * 3] + S[a * 3 + 1] * K[b * 3 + 1] + S[a * 3 + 2] * K[b * 3 + 2];
+                        // P -= K (S K^T): lanes 0..5 each own one row of P
+                        if (l < 6) {
+#pragma unroll
+                            for (int b = 0; b < 6; ++b) {
+                                double kr0 = 0.0, kr1 = 0.0, kr2 = 0.0;
+#pragma unroll
+                                for (int a = 0; a < 6; ++a) {
+                                    kr0 = (l == a) ? K[a * 3] : kr0;
+                                    kr1 = (l == a) ? K[a * 3 + 1] : kr1;
+                                    kr2 = (l == a) ? K[a * 3 + 2] : kr2;
+                                }
+                                double corr = kr0 * SKt[b] + kr1 * SKt[6 + b] + kr2 * SKt[12 + b];
+                                t.P[g * 36 + l * 6 + b] = t.P[g * 36 + l * 6 + b] - corr;
+                            }
+                        }
                         if (l == 0) {
 #pragma unroll
-                            for (int c = 0; c < 3; ++c) rec[SSA_UPD_Y + c] = y[c];
-#pragma unroll
-                            for (int c = 0; c < 9; ++c) rec[SSA_UPD_S + c] = S[c];
+                            for (int a = 0; a < 6; ++a) t.X[g * 6 + a] = xn[a];
                         }
-                        if (is_sigma) {
+                        if (nan_u) st_new = SSA_ST_UPDATE_NAN;
+                        if (rec) {
+                            if (l == 0) {
 #pragma unroll
-                            for (int c = 0; c < 3; ++c) rec[SSA_UPD_SIGMAS_H + l * 3 + c] = z[c];
+                                for (int c = 0; c < 3; ++c) rec[SSA_UPD_Y + c] = y[c];
+#pragma unroll
+                                for (int c = 0; c < 9; ++c) rec[SSA_UPD_S + c] = S[c];
+                            }
+                            if (is_sigma) {
+#pragma unroll
+                                for (int c = 0; c < 3; ++c) rec[SSA_UPD_SIGMAS_H + l * 3 + c] = z[c];
+                            }
                         }
                     }
                 }
             }
+            if (rec && l == 0) {
+                rec[SSA_UPD_OBS_TAKEN] = taken ? 1.0 : 0.0;
+                rec[SSA_UPD_VISIBLE] = visible ? 1.0 : 0.0;
+                rec[SSA_UPD_ACTION] = (double)act;
+            }
         }
-        if (rec && l == 0) {
-            rec[SSA_UPD_OBS_TAKEN] = taken ? 1.0 : 0.0;
-            rec[SSA_UPD_VISIBLE] = visible ? 1.0 : 0.0;
-            rec[SSA_UPD_ACTION] = (double)act;
-        }
-    }
-    // envs whose action selects nobody still get a cleared record (written by object 0's row)
-    if (valid && p.upd && j == 0 && l == 0 && !(act >= 0 && interval_ok && (int64_t)act < p.n_obj)) {
-        double* rec = p.upd + (int64_t)e * SSA_UPD_STRIDE;
-        rec[SSA_UPD_OBS_TAKEN] = 0.0;
-        rec[SSA_UPD_VISIBLE] = 0.0;
-        rec[SSA_UPD_ACTION] = -1.0;
-    }
 
-    // ---- F1: failed filters carry the sentinels (ssa_tasker_simple_2.py:157-158, 369-382)
-    if (valid && st_new != SSA_ST_OK && st_in == SSA_ST_OK) {
-        for (int t = l; t < 36; t += 16) {
-            int a = t / 6, b = t - a * 6;
-            sP[g * 36 + t] = (a == b) ? (a < 3 ? X_FAILED_POS : X_FAILED_VEL) : 0.0;
+        // ---- F1: failed filters carry the sentinels (ssa_tasker_simple_2.py:157-158, 369-382)
+        if (valid && st_new != SSA_ST_OK && st_in == SSA_ST_OK) {
+            for (int idx = l; idx < 36; idx += 16) {
+                int a = idx / 6, b = idx - a * 6;
+                t.P[g * 36 + idx] = (a == b) ? (a < 3 ? X_FAILED_POS : X_FAILED_VEL) : 0.0;
+            }
+            if (l < 6) t.X[g * 6 + l] = (l < 3) ? X_FAILED_POS : X_FAILED_VEL;
         }
-        if (l < 6) sX[g * 6 + l] = (l < 3) ? X_FAILED_POS : X_FAILED_VEL;
-    }
-    if (valid && st_in != SSA_ST_OK) {  // already failed: state passes through unchanged
-        for (int t = l; t < 36; t += 16) sP[g * 36 + t] = p.P_in[obj * 36 + t];
-        if (l < 6) sX[g * 6 + l] = xin[l];
-    }
-    if (l == 0) sSt[g] = st_new;
-    __syncthreads();
-
-    // ---- O1/O2: observation row and error metrics (results.py:61, :37)
-    if (l < 12) sObs[g * 12 + l] = (l < 6) ? sX[g * 6 + l] : sP[g * 36 + 7 * (l - 6)];
-    if (l < 4) {
-        const int off = (l & 1) * 3;  // 0: position block, 1: velocity block
-        double v;
-        if (l < 2) {
-            double a0 = sX[g * 6 + off] - sT[g * 6 + off];
-            double a1 = sX[g * 6 + off + 1] - sT[g * 6 + off + 1];
-            double a2 = sX[g * 6 + off + 2] - sT[g * 6 + off + 2];
-            v = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
-        } else {
-            v = sqrt(sP[g * 36 + 7 * off] + sP[g * 36 + 7 * (off + 1)] + sP[g * 36 + 7 * (off + 2)]);
+        if (valid && st_in != SSA_ST_OK) {  // already failed: state passes through unchanged
+            for (int idx = l; idx < 36; idx += 16) t.P[g * 36 + idx] = p.P_in[obj * 36 + idx];
+            if (l < 6) t.X[g * 6 + l] = xin[l];
         }
-        sMet[g * 4 + l] = v;
+        // envs whose action selects nobody still get a cleared record (written by object 0's row)
+        if (valid && p.upd && j == 0 && l == 0 && !(act >= 0 && interval_ok && (int64_t)act < p.n_obj)) {
+            double* rec = p.upd + (int64_t)e * SSA_UPD_STRIDE;
+            rec[SSA_UPD_OBS_TAKEN] = 0.0;
+            rec[SSA_UPD_VISIBLE] = 0.0;
+            rec[SSA_UPD_ACTION] = -1.0;
+        }
+        if (l == 0) t.St[g] = st_new;
+        __syncthreads();
+        observe_rows(t, g, l);
+        __syncthreads();
+        store_object(t, p, g, l, obj, valid, e, j, true);
     }
-    __syncthreads();
-
-    // ---- coalesced tile stores
-    for (int t = lane; t < OBJ_PER_WAVE * 36; t += 64) {
-        int64_t gi = base * 36 + t;
-        if (gi < total * 36) p.P_out[gi] = sP[t];
-    }
-    if (lane < 24) {
-        int64_t gi = base * 6 + lane;
-        if (gi < total * 6) p.x_out[gi] = sX[lane];
-    } else if (lane >= 32 && lane < 56) {
-        int64_t gi = base * 6 + (lane - 32);
-        if (gi < total * 6) p.x_true_out[gi] = sT[lane - 32];
-    } else if (lane >= 56 && lane < 60) {
-        int64_t gi = base + (lane - 56);
-        if (gi < total) p.status[gi] = sSt[lane - 56];
-    }
-    if (lane < 48) {
-        int64_t gi = base * 12 + lane;
-        if (gi < total * 12) p.obs[gi] = sObs[lane];
-    }
-    if (valid && l < 4) p.metrics[((int64_t)e * 4 + l) * p.n_obj + j] = sMet[g * 4 + l];
 }
 
 // ------------------------------------------------------------------------------------------
 // O3: per-env reward statistics
-__global__ void __launch_bounds__(1024) reward_stats_kernel(const double* __restrict__ metrics,
-                                                            const int32_t* __restrict__ status,
-                                                            double* __restrict__ stats, int64_t m)
+// One 1024-thread block per env.  Loads are issued 8 deep per thread before any use (the metrics
+// were just written by another kernel, every load is an L2/HBM round trip), then a wave-shuffle
+// reduction and one 16-entry LDS pass.  NaN ranks above everything (np.max / np.argmax semantics),
+// ties keep the lowest index.
+struct StatAcc {
+    double mx, sm;       // max delta_pos (NaN excluded), max sigma_pos (valid when !sm_nan)
+    long long arg;       // index of sm (or of the first NaN sigma_pos)
+    unsigned c4, c7, nf;
+    int mx_nan, sm_nan;
+};
+SSA_DEV void stat_merge(StatAcc& a, const StatAcc& b)
 {
-    const int e = blockIdx.x;
+    a.mx = fmax(a.mx, b.mx);
+    a.mx_nan |= b.mx_nan;
+    a.c4 += b.c4; a.c7 += b.c7; a.nf += b.nf;
+    bool take_b;
+    if (a.sm_nan || b.sm_nan) take_b = b.sm_nan && (!a.sm_nan || b.arg < a.arg);
+    else take_b = (b.sm > a.sm) || (b.sm == a.sm && b.arg < a.arg);
+    if (take_b) { a.sm = b.sm; a.arg = b.arg; a.sm_nan = b.sm_nan; }
+}
+SSA_DEV StatAcc stat_shfl_down(const StatAcc& a, int off)
+{
+    StatAcc b;
+    b.mx = __shfl_down(a.mx, off, 64);
+    b.sm = __shfl_down(a.sm, off, 64);
+    b.arg = __shfl_down(a.arg, off, 64);
+    b.c4 = __shfl_down(a.c4, off, 64);
+    b.c7 = __shfl_down(a.c7, off, 64);
+    b.nf = __shfl_down(a.nf, off, 64);
+    b.mx_nan = __shfl_down(a.mx_nan, off, 64);
+    b.sm_nan = __shfl_down(a.sm_nan, off, 64);
+    return b;
+}
+// Two small launches: `reward_partial_kernel` spreads the 20-byte-per-object read over many CUs
+// (a single CU only pulls ~24 GB/s, MI355X_MICROARCH.md) and leaves one StatAcc per block;
+// `reward_final_kernel` folds those.  The kernel boundary orders the two, no device-scope fence.
+constexpr int STAT_T = 256, STAT_ILP = 4, STAT_MAX_PARTS = 1024;
+
+SSA_DEV StatAcc stat_identity()
+{
+    StatAcc a;
+    a.mx = -1.0; a.sm = -1.0; a.arg = 0x7fffffffffffffffLL; a.c4 = a.c7 = a.nf = 0; a.mx_nan = a.sm_nan = 0;
+    return a;
+}
+SSA_DEV StatAcc stat_wave_reduce(StatAcc a)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        StatAcc b = stat_shfl_down(a, off);
+        stat_merge(a, b);
+    }
+    return a;
+}
+__global__ void __launch_bounds__(STAT_T) reward_partial_kernel(const double* __restrict__ metrics,
+                                                                const int32_t* __restrict__ status,
+                                                                StatAcc* __restrict__ parts, int64_t m, int nparts)
+{
+    const int e = blockIdx.y, t = threadIdx.x;
     const double* dpos = metrics + ((int64_t)e * 4 + 0) * m;
     const double* spos = metrics + ((int64_t)e * 4 + 2) * m;
     const int32_t* st = status + (int64_t)e * m;
-    // NaN ranks above everything (np.max / np.argmax semantics); ties keep the lowest index.
-    double mx = -1.0, sm = -1.0;
-    bool mx_nan = false, sm_nan = false;
-    long long arg = 0x7fffffffffffffffLL;
-    unsigned c4 = 0, c7 = 0, nf = 0;
-    for (int64_t i = threadIdx.x; i < m; i += blockDim.x) {
-        double dp = dpos[i], sp = spos[i];
-        if (dp != dp) mx_nan = true; else mx = fmax(mx, dp);
-        c4 += dp < 1e4;
-        c7 += dp < 1e7;
-        nf += st[i] != 0;
-        bool better = sm_nan ? false : ((sp != sp) ? true : (sp > sm));
-        if (better) { sm = sp; arg = i; sm_nan = (sp != sp); }
-    }
-    __shared__ double s_mx[1024], s_sm[1024];
-    __shared__ long long s_arg[1024];
-    __shared__ unsigned s_c4[1024], s_c7[1024], s_nf[1024];
-    __shared__ unsigned char s_flag[1024];
-    const int t = threadIdx.x;
-    s_mx[t] = mx; s_sm[t] = sm; s_arg[t] = arg; s_c4[t] = c4; s_c7[t] = c7; s_nf[t] = nf;
-    s_flag[t] = (mx_nan ? 1 : 0) | (sm_nan ? 2 : 0);
-    __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
-        if (t < w) {
-            s_mx[t] = fmax(s_mx[t], s_mx[t + w]);
-            s_c4[t] += s_c4[t + w]; s_c7[t] += s_c7[t + w]; s_nf[t] += s_nf[t + w];
-            unsigned char fa = s_flag[t], fb = s_flag[t + w];
-            bool a_nan = fa & 2, b_nan = fb & 2;
-            bool take_b;
-            if (a_nan || b_nan) take_b = b_nan && (!a_nan || s_arg[t + w] < s_arg[t]);
-            else take_b = (s_sm[t + w] > s_sm[t]) || (s_sm[t + w] == s_sm[t] && s_arg[t + w] < s_arg[t]);
-            if (take_b) { s_sm[t] = s_sm[t + w]; s_arg[t] = s_arg[t + w]; }
-            s_flag[t] = (unsigned char)(((fa | fb) & 1) | ((a_nan || b_nan) ? 2 : 0));
+    StatAcc a = stat_identity();
+    for (int64_t base = (int64_t)blockIdx.x * STAT_T * STAT_ILP; base < m; base += (int64_t)nparts * STAT_T * STAT_ILP) {
+        double dp[STAT_ILP], sp[STAT_ILP];
+        int sv[STAT_ILP];
+#pragma unroll
+        for (int k = 0; k < STAT_ILP; ++k) {
+            int64_t i = base + (int64_t)k * STAT_T + t;
+            bool in = i < m;
+            dp[k] = in ? dpos[i] : 0.0;
+            sp[k] = in ? spos[i] : -2.0;
+            sv[k] = in ? st[i] : 0;
         }
-        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < STAT_ILP; ++k) {
+            int64_t i = base + (int64_t)k * STAT_T + t;
+            if (i < m) {
+                if (dp[k] != dp[k]) a.mx_nan = 1; else a.mx = fmax(a.mx, dp[k]);
+                a.c4 += dp[k] < 1e4;
+                a.c7 += dp[k] < 1e7;
+                a.nf += sv[k] != 0;
+                bool better = a.sm_nan ? false : ((sp[k] != sp[k]) ? true : (sp[k] > a.sm));
+                if (better) { a.sm = sp[k]; a.arg = i; a.sm_nan = (sp[k] != sp[k]); }
+            }
+        }
     }
+    a = stat_wave_reduce(a);
+    __shared__ StatAcc part[STAT_T / 64];
+    if ((t & 63) == 0) part[t >> 6] = a;
+    __syncthreads();
+    if (t == 0) {
+        StatAcc r = part[0];
+        for (int w = 1; w < STAT_T / 64; ++w) stat_merge(r, part[w]);
+        parts[(int64_t)e * nparts + blockIdx.x] = r;
+    }
+}
+__global__ void __launch_bounds__(64) reward_final_kernel(const StatAcc* __restrict__ parts, double* __restrict__ stats, int nparts)
+{
+    const int e = blockIdx.x, t = threadIdx.x;
+    StatAcc a = stat_identity();
+    for (int i = t; i < nparts; i += 64) stat_merge(a, parts[(int64_t)e * nparts + i]);
+    a = stat_wave_reduce(a);
     if (t == 0) {
         double* o = stats + (int64_t)e * SSA_STAT_STRIDE;
-        o[SSA_STAT_MAX_DPOS] = (s_flag[0] & 1) ? __builtin_nan("") : s_mx[0];
-        o[SSA_STAT_CNT_LT_1E4] = (double)s_c4[0];
-        o[SSA_STAT_CNT_LT_1E7] = (double)s_c7[0];
-        o[SSA_STAT_ARGMAX_SPOS] = (double)s_arg[0];
-        o[SSA_STAT_N_FAILED] = (double)s_nf[0];
-        o[SSA_STAT_MAX_SPOS] = (s_flag[0] & 2) ? __builtin_nan("") : s_sm[0];
+        o[SSA_STAT_MAX_DPOS] = a.mx_nan ? __builtin_nan("") : a.mx;
+        o[SSA_STAT_CNT_LT_1E4] = (double)a.c4;
+        o[SSA_STAT_CNT_LT_1E7] = (double)a.c7;
+        o[SSA_STAT_ARGMAX_SPOS] = (double)a.arg;
+        o[SSA_STAT_N_FAILED] = (double)a.nf;
+        o[SSA_STAT_MAX_SPOS] = a.sm_nan ? __builtin_nan("") : a.sm;
         o[6] = 0.0; o[7] = 0.0;
     }
 }
@@ -911,12 +1030,21 @@ int ssa_env_step_f64(const ssa_consts* c, const ssa_step_params* p, void* stream
     return launch_status();
 }
 
-int ssa_reward_stats_f64(const double* metrics, const int32_t* status, double* stats, int64_t n_obj, int32_t n_env,
-                         void* stream)
+int ssa_reward_stats_f64(const double* metrics, const int32_t* status, double* stats, void* workspace, int64_t n_obj,
+                         int32_t n_env, void* stream)
 {
-    if (!metrics || !status || !stats || n_obj <= 0 || n_env <= 0) return SSA_E_INVALID;
-    hipLaunchKernelGGL(reward_stats_kernel, dim3(n_env), dim3(1024), 0, (hipStream_t)stream, metrics, status, stats, n_obj);
+    if (!metrics || !status || !stats || !workspace || n_obj <= 0 || n_env <= 0) return SSA_E_INVALID;
+    int64_t want = (n_obj + (int64_t)STAT_T * STAT_ILP - 1) / ((int64_t)STAT_T * STAT_ILP);
+    int nparts = (int)(want < 1 ? 1 : (want > STAT_MAX_PARTS / 4 ? STAT_MAX_PARTS / 4 : want));
+    StatAcc* parts = (StatAcc*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(reward_partial_kernel, dim3(nparts, n_env), dim3(STAT_T), 0, s, metrics, status, parts, n_obj, nparts);
+    hipLaunchKernelGGL(reward_final_kernel, dim3(n_env), dim3(64), 0, s, (const StatAcc*)parts, stats, nparts);
     return launch_status();
+}
+int64_t ssa_reward_stats_workspace_bytes(int32_t n_env)
+{
+    return (int64_t)(n_env < 1 ? 1 : n_env) * (STAT_MAX_PARTS / 4) * (int64_t)sizeof(StatAcc);
 }
 
 int ssa_propagate_f64(const double* x_in, double* x_out, int64_t n, double dt, int32_t propagator, void* stream)

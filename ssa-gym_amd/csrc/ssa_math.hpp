@@ -123,7 +123,30 @@ SSA_DEV bool rv2coe_elliptic(const double* r, const double* v, double* coe)
 // Complete restatement of farnocchia() with every conic branch (parabolic, near-parabolic,
 // hyperbolic): farnocchia.py:847-1050.  Out of line: only objects that have left the
 // strong-elliptic regime (a diverged filter) ever reach it.
-__device__ __noinline__ void kepler_general(const double* x, double tof, double* out, double* diag);
+// Arguments travel BY VALUE (registers): passing pointers to the caller's arrays would force those
+// arrays -- and every inline use of them -- into scratch memory.
+struct Vec6 { double v[6]; };
+struct Vec8 { double v[8]; };
+__device__ __noinline__ Vec6 kepler_general_v(Vec6 x, double tof);
+__device__ __noinline__ Vec8 kepler_general_diag_v(Vec6 x, double tof, Vec6* out);
+SSA_DEV void kepler_general(const double* x, double tof, double* out, double* diag)
+{
+    Vec6 xi;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xi.v[i] = x[i];
+    if (diag) {
+        Vec6 o;
+        Vec8 d = kepler_general_diag_v(xi, tof, &o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) out[i] = o.v[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) diag[i] = d.v[i];
+    } else {
+        Vec6 o = kepler_general_v(xi, tof);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) out[i] = o.v[i];
+    }
+}
 
 // SSA_PROP_ELEMENTS: farnocchia() for the strong-elliptic regime, operation by operation
 // (rv2coe -> delta_t_from_nu :871-875 -> nu_from_delta_t :946-954 -> coe2rv).
@@ -214,6 +237,110 @@ SSA_DEV void kepler_fg(const double* x, double tof, double* out)
     out[3] = fd * r[0] + gd * v[0];
     out[4] = fd * r[1] + gd * v[1];
     out[5] = fd * r[2] + gd * v[2];
+}
+
+// ---------------------------------------------------------------------------
+// Fast-path variants for the lean step kernel: same mathematics as kepler_fg /
+// kepler_elements on the strong-elliptic domain, but they RETURN FALSE instead of falling
+// back when the state is outside it (a <= 0, ecc >= 0.99, NaN); the caller then queues the
+// object for the complete kernel.  kepler_fg_fast also trims the Newton loop: one sincos,
+// afterwards sin/cos are carried along by the angle-addition formulas with a short Taylor
+// series in the (tiny) Newton step.
+SSA_DEV void rot_small(double d, double& s, double& c)
+{
+    // (s, c) <- (sin, cos)(angle + d), |d| <= 0.02: truncation d^9/9! < 2e-21
+    double d2 = d * d;
+    double sd = d * (1.0 - d2 * (1.0 / 6.0) * (1.0 - d2 * (1.0 / 20.0) * (1.0 - d2 * (1.0 / 42.0))));
+    double cd = 1.0 - d2 * 0.5 * (1.0 - d2 * (1.0 / 12.0) * (1.0 - d2 * (1.0 / 30.0) * (1.0 - d2 * (1.0 / 56.0))));
+    double s2 = s * cd + c * sd;
+    c = c * cd - s * sd;
+    s = s2;
+}
+
+SSA_DEV bool kepler_fg_fast(const double* x, double tof, double* out)
+{
+    const double* r = x;
+    const double* v = x + 3;
+    const double sqrt_mu = sqrt(MU), inv_sqrt_mu = 1.0 / sqrt(MU), inv_mu = 1.0 / MU;
+    double rr = dot3(r, r), vv = dot3(v, v), rv = dot3(r, v);
+    double r0 = sqrt(rr);
+    double inv_r0 = 1.0 / r0;
+    double alpha = 2.0 * inv_r0 - vv * inv_mu;  // 1/a
+    double ome = r0 * alpha;                    // r0 / a = 1 - e cos E0
+    double ec = 1.0 - ome;                      // e cos E0
+    double sa = sqrt(alpha);
+    double es = rv * sa * inv_sqrt_mu;          // e sin E0
+    double ecc2 = ec * ec + es * es;
+    bool ok = (alpha > 0.0) && (ecc2 < 0.99 * 0.99);
+    // keep out-of-domain lanes numerically harmless (their result is discarded)
+    if (!ok) { alpha = 1e-7; ome = 1.0; ec = 0.0; es = 0.0; sa = sqrt(alpha); }
+    double n = sqrt_mu * alpha * sa;            // mean motion
+    double Mt = n * tof;
+    double k = rint(Mt * (1.0 / TWO_PI));
+    double Mr = fma(-k, TWO_PI, Mt);            // in [-pi, pi]
+    double inv_ome = 1.0 / ome;
+    double x1 = Mr * inv_ome;
+    double xs = x1 - 0.5 * es * x1 * x1 * inv_ome;
+    double lo = Mr - 2.0, hi = Mr + 2.0;
+    double xk = (fabs(Mr) < 0.5 && xs > lo && xs < hi) ? xs : Mr - es;
+    double s, c;
+    sincos(xk, &s, &c);
+    bool done = false;
+    for (int it = 0; it < 50; ++it) {
+        double G = (xk - ec * s + es * (1.0 - c)) - Mr;
+        double dG = 1.0 - ec * c + es * s;
+        if (G > 0.0) hi = xk; else lo = xk;
+        double xn = xk - G / dG;
+        if (!(xn >= lo && xn <= hi)) xn = 0.5 * (lo + hi);
+        double dx = xn - xk;
+        if (!done) {
+            if (fabs(dx) <= 0.02) rot_small(dx, s, c);
+            else sincos(xn, &s, &c);
+            xk = xn;
+            done = fabs(dx) < 1e-10;
+        }
+        if (__all(done || !ok)) break;
+    }
+    ok = ok && done;                            // non-convergence -> complete kernel (NaN semantics there)
+    double omc = 1.0 - c;
+    double rho = 1.0 - (ec * c - es * s);       // r / a
+    double inv_rho = 1.0 / rho;
+    double f = 1.0 - inv_ome * omc;
+    double g = (ome * s + es * omc) / n;
+    double fd = -sqrt_mu * sa * s * inv_rho * inv_r0;
+    double gd = 1.0 - omc * inv_rho;
+    out[0] = f * r[0] + g * v[0];
+    out[1] = f * r[1] + g * v[1];
+    out[2] = f * r[2] + g * v[2];
+    out[3] = fd * r[0] + gd * v[0];
+    out[4] = fd * r[1] + gd * v[1];
+    out[5] = fd * r[2] + gd * v[2];
+    return ok;
+}
+
+SSA_DEV bool kepler_elements_fast(const double* x, double tof, double* out)
+{
+    double coe[6] = {1e7, 0.0, 0.0, 0.0, 0.0, 0.0};
+    bool ok = rv2coe_elliptic(x, x + 3, coe);
+    double p = coe[0], ecc = ok ? coe[1] : 0.0, nu0 = coe[5];
+    double q = p / (1.0 + ecc);
+    double ome = 1.0 - ecc;
+    double E0 = 2.0 * atan(sqrt(ome / (1.0 + ecc)) * tan(0.5 * nu0));
+    double M0 = E0 - ecc * sin(E0);
+    double nmm = sqrt(MU * ome * ome * ome / (q * q * q));
+    double dt0 = M0 / nmm;
+    double M = nmm * (dt0 + tof);
+    double E = solve_kepler_E(wrap_pi(M), ecc);
+    double nu = 2.0 * atan(sqrt((1.0 + ecc) / ome) * tan(0.5 * E));
+    coe2rv(p, ecc, coe[2], coe[3], coe[4], nu, out);
+    return ok && (E == E);
+}
+
+template <int PROP>
+SSA_DEV bool kepler_step_fast(const double* x, double tof, double* out)
+{
+    if (PROP == 1) return kepler_fg_fast(x, tof, out);
+    return kepler_elements_fast(x, tof, out);
 }
 
 template <int PROP>

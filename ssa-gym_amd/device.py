@@ -131,12 +131,26 @@ def aer_obs(x, P, M, consts, out=None):
     return out
 
 
+_stats_ws = {}
+
+
+def stats_workspace(n_env, dev):
+    """device scratch of the two-launch statistics reduction (cached per (device, n_env))."""
+    key = (str(dev), int(n_env))
+    if key not in _stats_ws:
+        nbytes = _lib.load().ssa_reward_stats_workspace_bytes(int(n_env))
+        _stats_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    return _stats_ws[key]
+
+
 def reward_stats(metrics, status, n_obj, n_env=1, out=None):
     """O3: per-env reductions -> stats[E, STAT_STRIDE]."""
     lib = _lib.load()
     out = torch.empty((n_env, _lib.STAT_STRIDE), dtype=f64, device=metrics.device) if out is None else out
+    ws = stats_workspace(n_env, metrics.device)
     _lib.check(lib.ssa_reward_stats_f64(_chk(metrics, "metrics"), _chk(status, "status", torch.int32),
-                                        _chk(out, "stats"), int(n_obj), int(n_env), _stream()), "ssa_reward_stats_f64")
+                                        _chk(out, "stats"), ws.data_ptr(), int(n_obj), int(n_env), _stream()),
+               "ssa_reward_stats_f64")
     return out
 
 

@@ -62,6 +62,7 @@ class HotPathEngine:
         self._p.zn_stride_env, self._p.zn_stride_time = self.zn_stride_env, self.zn_stride_time
         self._p.n_time = self.n_time
         self._lib = _lib.load()
+        self._stats_ws = device.stats_workspace(self.E, d)
         self._cref = C.byref(self.consts)
         self._pref = C.byref(self._p)
         # element strides of one history slot
@@ -118,7 +119,8 @@ class HotPathEngine:
         rc = self._lib.ssa_env_step_f64(self._cref, self._pref, s)
         if rc:
             raise _lib.SsaHipError("ssa_env_step_f64 failed with code %d" % rc)
-        rc = self._lib.ssa_reward_stats_f64(p.metrics, self._p.status, self._bs + slot_out * self._ss, self.m, self.E, s)
+        rc = self._lib.ssa_reward_stats_f64(p.metrics, self._p.status, self._bs + slot_out * self._ss,
+                                            self._stats_ws.data_ptr(), self.m, self.E, s)
         if rc:
             raise _lib.SsaHipError("ssa_reward_stats_f64 failed with code %d" % rc)
 
