@@ -293,7 +293,7 @@ struct StepK {
 constexpr int OBJ_PER_WAVE = 4;
 constexpr double X_FAILED_POS = 1e20, X_FAILED_VEL = 1e12;  // ssa_tasker_simple_2.py:157-158
 
-struct Tiles {   // LDS working set of one wavefront (4 objects)
+struct alignas(16) Tiles {   // LDS working set of one wavefront (4 objects)
     double P[OBJ_PER_WAVE * 36];       // P_in, later P_out
     double X[OBJ_PER_WAVE * 6];        // x_in, later x_out
     double T[OBJ_PER_WAVE * 6];        // x_true_in, later x_true_out
@@ -333,6 +333,54 @@ SSA_DEV void store_object(const Tiles& t, const ssa_step_params& p, int g, int l
     else if (l == 15 && write_status) p.status[obj] = t.St[g];
     if (l < 12) p.obs[obj * 12 + l] = t.Obs[g * 12 + l];
     if (l < 4) p.metrics[((int64_t)e * 4 + l) * p.n_obj + j] = t.Met[g * 4 + l];
+}
+
+// Wave-contiguous tile I/O: the 4 objects of a wavefront are consecutive, so P / x / x_true / obs are
+// single contiguous spans (1152 / 192 / 192 / 384 B) moved as 16-byte lanes -- whole cache lines per
+// instruction instead of four 288-byte pieces.  `cnt` = valid objects in the tile (1..4).
+SSA_DEV void load_tile(Tiles& t, const ssa_step_params& p, int lane, int64_t base, int cnt)
+{
+    const double2* P2 = reinterpret_cast<const double2*>(p.P_in + base * 36);
+    double2* tP = reinterpret_cast<double2*>(t.P);
+    for (int i = lane; i < 72; i += 64) tP[i] = (i < cnt * 18) ? P2[i] : make_double2(0.0, 0.0);
+    if (lane < 12) {
+        const double2* X2 = reinterpret_cast<const double2*>(p.x_in + base * 6);
+        reinterpret_cast<double2*>(t.X)[lane] = (lane < cnt * 3) ? X2[lane] : make_double2(0.0, 0.0);
+    } else if (lane >= 16 && lane < 28) {
+        const int i = lane - 16;
+        const double2* T2 = reinterpret_cast<const double2*>(p.x_true_in + base * 6);
+        reinterpret_cast<double2*>(t.T)[i] = (i < cnt * 3) ? T2[i] : make_double2(0.0, 0.0);
+    } else if (lane >= 32 && lane < 36) {
+        const int i = lane - 32;
+        t.St[i] = (i < cnt) ? p.status[base + i] : SSA_ST_PREDICT_NAN;
+    }
+}
+SSA_DEV void store_tile(const Tiles& t, const ssa_step_params& p, int lane, int64_t base, int cnt)
+{
+    double2* P2 = reinterpret_cast<double2*>(p.P_out + base * 36);
+    const double2* tP = reinterpret_cast<const double2*>(t.P);
+    for (int i = lane; i < 72; i += 64)
+        if (i < cnt * 18) P2[i] = tP[i];
+    if (lane < 12) {
+        if (lane < cnt * 3) reinterpret_cast<double2*>(p.x_out + base * 6)[lane] = reinterpret_cast<const double2*>(t.X)[lane];
+    } else if (lane >= 16 && lane < 28) {
+        const int i = lane - 16;
+        if (i < cnt * 3) reinterpret_cast<double2*>(p.x_true_out + base * 6)[i] = reinterpret_cast<const double2*>(t.T)[i];
+    } else if (lane >= 32 && lane < 36) {
+        const int i = lane - 32;
+        if (i < cnt) p.status[base + i] = t.St[i];
+    } else if (lane >= 40 && lane < 64) {
+        const int i = lane - 40;
+        if (i < cnt * 6) reinterpret_cast<double2*>(p.obs + base * 12)[i] = reinterpret_cast<const double2*>(t.Obs)[i];
+    }
+    if (lane < 16) {   // metrics [E][4][m]: four 32-byte runs per tile
+        const int kk = lane >> 2, jj = lane & 3;
+        if (jj < cnt) {
+            const int64_t obj = base + jj;
+            const int64_t e = obj / p.n_obj, j = obj - e * p.n_obj;
+            p.metrics[(e * 4 + kk) * p.n_obj + j] = t.Met[jj * 4 + kk];
+        }
+    }
 }
 
 // O1/O2 for the row's object from the tiles (results.py:61, :37)
@@ -395,7 +443,9 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_kernel(const StepK k)
         const int act = valid ? p.actions[e] : -1;
         const int tix = valid ? p.env_time[e] + p.time_offset : 0;
 
-        load_object(t, p, g, l, valid ? obj : 0, valid);
+        const int64_t base = (int64_t)blockIdx.x * OBJ_PER_WAVE;
+        const int cnt = (int)((total - base) < OBJ_PER_WAVE ? (total - base) : OBJ_PER_WAVE);
+        load_tile(t, p, lane, base, cnt);
         __syncthreads();
 
         const int st_in = t.St[g];
@@ -687,7 +737,7 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_kernel(const StepK k)
         __syncthreads();
         observe_rows(t, g, l);
         __syncthreads();
-        store_object(t, p, g, l, obj, valid, e, j, true);
+        store_tile(t, p, lane, base, cnt);
     }
 }
 
