@@ -28,7 +28,7 @@ for path in sorted(glob.glob(os.path.join(ROOT,'build_ablate','*.so'))):
                 p.x_true_in,p.x_true_out=eng._bx_t+sin*eng._sx,eng._bx_t+sout*eng._sx
                 p.x_in,p.x_out=eng._bx+sin*eng._sx,eng._bx+sout*eng._sx
                 p.P_in,p.P_out=eng._bP+sin*eng._sP,eng._bP+sout*eng._sP
-                p.obs=eng._bo; p.metrics=eng._bm; p.upd=eng._bu
+                p.obs=eng._bo; p.metrics=eng._bm; p.upd=eng._bu; p.stats=eng._bs; p.launch_mask=int(os.environ.get('MASK','1'))
                 p.actions=sched.data_ptr()+4*(k%64)
                 lib.ssa_env_step_f64(eng._cref,eng._pref,s)
             e1.record(); torch.cuda.synchronize(); best=min(best,e0.elapsed_time(e1)/100)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SSA_ABI_VERSION 3
+#define SSA_ABI_VERSION 4
 
 /* error codes */
 #define SSA_OK 0
@@ -116,11 +116,20 @@ typedef struct ssa_step_params {
                                   z_noise + e*zn_stride_env + i*zn_stride_time + a*3   (:219-221) */
     int64_t zn_stride_env, zn_stride_time;
     int32_t n_time;            /* rows in `trans` / time rows of `z_noise` (index = i % n_time) */
-    int32_t reserved;
+    uint32_t launch_mask;      /* 0 = everything; diagnostic: 1 common-path kernel, 2 post kernel, 4 final */
+    double *stats;             /* [E][SSA_STAT_STRIDE] reward statistics of this step (O3), may be NULL */
+    int32_t *work;             /* ssa_env_step_work_bytes(): exception queue; zero it once before the first call */
+    void *stat_ws;             /* ssa_reward_stats_workspace_bytes(): per-block statistics partials */
 } ssa_step_params;
 
-/* ---------------------------------------------------------------- fused hot path (one launch) */
+/* ---------------------------------------------------------------- fused hot path
+ * Three launches: (1) the common path for every object, 4 objects per wavefront; objects that need
+ * robust_cholesky's jitter ladder or a non-strong-elliptic conic branch are queued; (2) a post kernel
+ * that re-does the queued objects with complete semantics and reduces the reward statistics per
+ * block; (3) a one-wave kernel that folds the statistics and resets the queue. */
 int ssa_env_step_f64(const ssa_consts *c_host, const ssa_step_params *p_host, void *stream);
+/* bytes of the int32 `work` buffer for n_env environments of n_obj objects */
+int64_t ssa_env_step_work_bytes(int64_t n_obj, int32_t n_env);
 
 /* O3: per-env reductions over metrics[E][4][m] and status -> stats[E][SSA_STAT_STRIDE]
  * (ssa_tasker_simple_2.py:324-354, results.py:432). */

@@ -30,12 +30,12 @@ class ssa_step_params(C.Structure):
         ("P_in", c_dp), ("P_out", c_dp), ("status", c_dp), ("obs", c_dp), ("metrics", c_dp),
         ("upd", c_dp), ("trans", c_dp), ("env_time", c_dp), ("actions", c_dp), ("z_noise", c_dp),
         ("zn_stride_env", C.c_int64), ("zn_stride_time", C.c_int64),
-        ("n_time", C.c_int32), ("reserved", C.c_int32),
+        ("n_time", C.c_int32), ("launch_mask", C.c_uint32), ("stats", c_dp), ("work", c_dp), ("stat_ws", c_dp),
     ]
 
 
 # constants of include/ssa_hip.h
-ABI_VERSION = 3
+ABI_VERSION = 4
 ST_OK, ST_PREDICT_NAN, ST_PREDICT_LINALG, ST_UPDATE_NAN, ST_UPDATE_LINALG = range(5)
 OBS_AER, OBS_XYZ = 0, 1
 PROP_ELEMENTS, PROP_FG = 0, 1
@@ -48,6 +48,7 @@ SIGNATURES = {
     "ssa_abi_version": (C.c_int, []),
     "ssa_build_info": (C.c_char_p, []),
     "ssa_env_step_f64": (C.c_int, [C.POINTER(ssa_consts), C.POINTER(ssa_step_params), c_dp]),
+    "ssa_env_step_work_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
     "ssa_reward_stats_f64": (C.c_int, [c_dp, c_dp, c_dp, c_dp, C.c_int64, C.c_int32, c_dp]),
     "ssa_reward_stats_workspace_bytes": (C.c_int64, [C.c_int32]),
     "ssa_propagate_f64": (C.c_int, [c_dp, c_dp, C.c_int64, C.c_double, C.c_int32, c_dp]),

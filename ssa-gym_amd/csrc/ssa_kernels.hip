@@ -253,33 +253,6 @@ __device__ __noinline__ Vec8 kepler_general_diag_v(Vec6 x, double tof, Vec6* out
     return d;
 }
 
-// robust_cholesky's jitter ladder (dynamics.py:402-417), out of line: only covariances that are
-// not positive definite as they stand ever reach it.
-// Works from / to LDS (the P tile and the U tile of the row) so that the caller's register arrays
-// stay in registers.
-__device__ __noinline__ int chol_ladder(const double* sP, double scale, double* sU, int writer)
-{
-    const double JIT[16] = {1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1.0, 10.0, 100.0, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9};
-    double a[21], u[21];
-    bool finite = true;
-    for (int i = 0; i < 6; ++i)
-        for (int c = i; c < 6; ++c) {
-            a[tri(i, c)] = scale * sP[i * 6 + c];
-            finite = finite && (fabs(a[tri(i, c)]) <= 1.79769313486231570e308);
-        }
-    int rung = 16;
-    if (finite) {
-        if (chol6_upper(a, 0.0, u)) rung = -1;
-        else
-            for (int t = 0; t < 16; ++t)
-                if (chol6_upper(a, JIT[t], u)) { rung = t; break; }
-    }
-    if (writer && rung != 16)
-        for (int i = 0; i < 6; ++i)
-            for (int c = 0; c < 6; ++c) sU[i * 6 + c] = (c >= i) ? u[tri(i, c)] : 0.0;
-    return rung;
-}
-
 // ------------------------------------------------------------------------------------------
 // fused env step: ONE launch per step over every object.  The common path (plain Cholesky,
 // strong-elliptic Kepler) is inline; the robust_cholesky jitter ladder and the other conic branches
@@ -421,332 +394,7 @@ SSA_DEV void covariance_rows(Tiles& t, const ssa_consts& C, int g, int l)
     }
 }
 
-// ------------------------------------------------------------------------------------------
-#ifndef SSA_STEP_WAVES
-#define SSA_STEP_WAVES 3   // minimum waves per SIMD the register allocator must leave room for (<= 168 VGPRs)
-#endif
-template <int PROP>
-__global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_kernel(const StepK k)
-{
-    __shared__ Tiles t;
-    const ssa_consts& C = k.c;
-    const ssa_step_params& p = k.p;
-    const int lane = threadIdx.x;
-    const int g = lane >> 4, l = lane & 15;
-    const int64_t total = (int64_t)p.n_env * p.n_obj;
-    {
-        const int64_t obj = (int64_t)blockIdx.x * OBJ_PER_WAVE + g;
-        const bool valid = obj < total;
-        const int e = valid ? (int)(obj / p.n_obj) : 0;
-        const int64_t j = valid ? obj - (int64_t)e * p.n_obj : 0;
-        // the action / time index of this object's env, fetched early (used after the transform)
-        const int act = valid ? p.actions[e] : -1;
-        const int tix = valid ? p.env_time[e] + p.time_offset : 0;
-
-        const int64_t base = (int64_t)blockIdx.x * OBJ_PER_WAVE;
-        const int cnt = (int)((total - base) < OBJ_PER_WAVE ? (total - base) : OBJ_PER_WAVE);
-        load_tile(t, p, lane, base, cnt);
-        __syncthreads();
-
-        const int st_in = t.St[g];
-        const bool active = valid && st_in == SSA_ST_OK;
-        double xin[6], xt[6];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            xin[c] = t.X[g * 6 + c];
-            xt[c] = t.T[g * 6 + c];
-        }
-        // U1/U2 with the robust_cholesky ladder
-        int rung;
-        {
-            double A[21], U[21];
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int c = i; c < 6; ++c) A[tri(i, c)] = C.scale * t.P[g * 36 + i * 6 + c];
-            bool finite = true;
-#pragma unroll
-            for (int i = 0; i < 21; ++i) finite = finite && (fabs(A[i]) <= 1.79769313486231570e308);
-            const bool plain_ok = finite && chol6_upper(A, 0.0, U);
-            rung = plain_ok ? -1 : 16;
-            if (l == 0) {
-#pragma unroll
-                for (int i = 0; i < 6; ++i)
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) t.U[g * 36 + i * 6 + c] = (c >= i) ? U[tri(i, c)] : 0.0;
-            }
-            if (!plain_ok) rung = chol_ladder(&t.P[g * 36], C.scale, &t.U[g * 36], l == 0);
-        }
-        __syncthreads();
-        const bool chol_fail = (rung == 16);
-        const bool is_sigma = (l <= 12);
-        const bool is_pm = (l >= 1 && l <= 12);
-        double s[6];
-        {
-            const int krow = is_pm ? (l - 1) % 6 : 0;
-            const double sgn = (l >= 1 && l <= 6) ? 1.0 : ((l >= 7 && l <= 12) ? -1.0 : 0.0);
-            const bool use_filter = active && !chol_fail && l != 13;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                double u = t.U[g * 36 + krow * 6 + c];
-                s[c] = use_filter ? (xin[c] + sgn * u) : xt[c];
-            }
-        }
-        // P1-P5: one Kepler solve per lane; the strong-elliptic fast path inline, every other conic
-        // branch through the out-of-line complete restatement
-        double o[6];
-        if (!kepler_step_fast<PROP>(s, C.dt, o)) {
-            Vec6 si;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) si.v[c] = s[c];
-            Vec6 oo = kepler_general_v(si, C.dt);
-#pragma unroll
-            for (int c = 0; c < 6; ++c) o[c] = oo.v[c];
-        }
-
-        double xb[6];
-        bool nan_x = false;
-        {
-            double ssum[6], mp[6];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                double s0 = row_bcast(o[c], 0);
-                double d = is_pm ? (o[c] - s0) : 0.0;
-                if (is_pm) t.D[(g * 13 + l) * 6 + c] = d;
-                ssum[c] = C.Wi * row_allsum(d);
-                mp[c] = C.sum_wm_m1 * s0 + ssum[c];
-                xb[c] = s0 + mp[c];
-                nan_x = nan_x || (xb[c] != xb[c]);
-            }
-            if (l == 0) {
-#pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    t.M[g * 12 + c] = ssum[c];
-                    t.M[g * 12 + 6 + c] = mp[c];
-                    t.X[g * 6 + c] = xb[c];
-                }
-            }
-            if (l == 13) {
-#pragma unroll
-                for (int c = 0; c < 6; ++c) t.T[g * 6 + c] = o[c];
-            }
-        }
-        __syncthreads();
-        covariance_rows(t, C, g, l);
-        __syncthreads();
-
-        int st_new = st_in;
-        if (active) {
-            if (chol_fail) st_new = SSA_ST_PREDICT_LINALG;
-            else if (nan_x) st_new = SSA_ST_PREDICT_NAN;
-        }
-
-        // ---- U5: the one update of this env (ssa_tasker_simple_2.py:292-315); all cross-lane traffic
-        // below is row-level (DPP / bpermute), so the branch needs no block barrier.
-        const bool interval_ok = (C.update_interval <= 1) || (tix % C.update_interval == 0);
-        const bool my_update = valid && act >= 0 && (int64_t)act == j && interval_ok;
-        if (my_update) {
-            const int tmod = (p.n_time > 0) ? tix % p.n_time : 0;   // row of `trans` / `z_noise` (episodes wrap)
-            double* rec = p.upd ? p.upd + (int64_t)e * SSA_UPD_STRIDE : nullptr;
-            bool taken = false, visible = false;
-            if (st_new == SSA_ST_OK) {
-                const double* M = p.trans + (int64_t)tmod * 9;
-                double Mm[9];
-#pragma unroll
-                for (int i = 0; i < 9; ++i) Mm[i] = M[i];
-                // sigma points handed to update(): the propagated ones or, with
-                // SSA_FLAG_RESAMPLE, a fresh set drawn from the prior
-                double sf[6];
-#pragma unroll
-                for (int c = 0; c < 6; ++c) sf[c] = o[c];
-                bool rs_fail = false;
-                if (C.flags & SSA_FLAG_RESAMPLE) {
-                    double A[21], U[21];
-#pragma unroll
-                    for (int i = 0; i < 6; ++i)
-#pragma unroll
-                        for (int c = i; c < 6; ++c) A[tri(i, c)] = C.scale * t.P[g * 36 + i * 6 + c];
-                    rs_fail = robust_chol6(A, U) == 16;
-                    const int krow = is_pm ? (l - 1) % 6 : 0;
-                    const double sgn = (l >= 1 && l <= 6) ? 1.0 : ((l >= 7 && l <= 12) ? -1.0 : 0.0);
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) {
-                        double u = 0.0;
-#pragma unroll
-                        for (int i = 0; i < 6; ++i)
-                            if (c >= i) u = (krow == i) ? U[tri(i, c)] : u;
-                        if (l != 13) sf[c] = xb[c] + sgn * u;
-                    }
-                }
-                // H1/H2: measurement of every sigma point (lanes 0-12) and of the true state (lane 13)
-                double aer[3], z[3];
-                hx_aer(sf, Mm, C.enu, C.obs_itrs, aer);
-                if (C.obs_type == SSA_OBS_AER) { z[0] = aer[0]; z[1] = aer[1]; z[2] = aer[2]; }
-                else { z[0] = sf[0]; z[1] = sf[1]; z[2] = sf[2]; }
-                const double el_true = row_bcast(aer[1], 13);
-                visible = el_true >= C.obs_limit;  // object_visible(): elevation of the TRUE state (:418-425)
-                if (rec && l == 13) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) rec[SSA_UPD_Z_TRUE + c] = z[c];
-                }
-                if (visible && rs_fail) {
-                    st_new = SSA_ST_UPDATE_LINALG;
-                } else if (visible) {
-                    // H3/H5: predicted measurement
-                    double zp[3];
-                    const double wl = (l == 0) ? C.Wc0 : (is_pm ? C.Wi : 0.0);
-                    if (C.obs_type == SSA_OBS_AER) {
-                        double uvw[3], um[3];
-                        aer2uvw(z, uvw);
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            double u0 = row_bcast(uvw[c], 0);
-                            double du = is_pm ? (uvw[c] - u0) : 0.0;
-                            um[c] = u0 + (C.sum_wm_m1 * u0 + C.Wi * row_allsum(du));
-                        }
-                        uvw2aer(um, zp);
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            double u0 = row_bcast(z[c], 0);
-                            double du = is_pm ? (z[c] - u0) : 0.0;
-                            zp[c] = u0 + (C.sum_wm_m1 * u0 + C.Wi * row_allsum(du));
-                        }
-                    }
-                    // H4: residuals; lane 13 forms the innovation of the noisy measurement
-                    double zin[3], rz[3];
-                    if (l == 13) {
-                        const double* zn = p.z_noise + (int64_t)e * p.zn_stride_env + (int64_t)tmod * p.zn_stride_time + (int64_t)act * 3;
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) zin[c] = z[c] + zn[c];
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) zin[c] = z[c];
-                    }
-                    if (C.obs_type == SSA_OBS_AER) residual_z_aer(zin, zp, rz);
-                    else {
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) rz[c] = zin[c] - zp[c];
-                    }
-                    double y[3];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) y[c] = row_bcast(rz[c], 13);
-                    // S = sum Wc rz rz^T + R ; Pxz = sum Wc (sigma_f - x)(rz)^T
-                    double S[9], Pxz[18], dx[6];
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) dx[c] = sf[c] - xb[c];
-#pragma unroll
-                    for (int a = 0; a < 3; ++a)
-#pragma unroll
-                        for (int b = a; b < 3; ++b) {
-                            double v = row_allsum(wl * (rz[a] * rz[b]));
-                            S[a * 3 + b] = v + C.R[a * 3 + b];
-                            S[b * 3 + a] = v + C.R[b * 3 + a];
-                        }
-#pragma unroll
-                    for (int a = 0; a < 6; ++a)
-#pragma unroll
-                        for (int b = 0; b < 3; ++b) Pxz[a * 3 + b] = row_allsum(wl * (dx[a] * rz[b]));
-                    double SI[9];
-                    const bool inv_ok = inv3(S, SI);
-                    if (!inv_ok) {
-                        st_new = SSA_ST_UPDATE_LINALG;
-                    } else {
-                        taken = true;
-                        double K[18];
-#pragma unroll
-                        for (int a = 0; a < 6; ++a)
-#pragma unroll
-                            for (int b = 0; b < 3; ++b)
-                                K[a * 3 + b] = Pxz[a * 3] * SI[b] + Pxz[a * 3 + 1] * SI[3 + b] + Pxz[a * 3 + 2] * SI[6 + b];
-                        double xn[6];
-                        bool nan_u = false;
-#pragma unroll
-                        for (int a = 0; a < 6; ++a) {
-                            xn[a] = xb[a] + (K[a * 3] * y[0] + K[a * 3 + 1] * y[1] + K[a * 3 + 2] * y[2]);
-                            nan_u = nan_u || (xn[a] != xn[a]);
-                        }
-                        double SKt[18];  // S K^T  [3][6]
-#pragma unroll
-                        for (int a = 0; a < 3; ++a)
-#pragma unroll
-                            for (int b = 0; b < 6; ++b)
-                                SKt[a * 6 + b] = S[a * 3] * K[b * 3] + S[a * 3 + 1] * K[b * 3 + 1] + S[a * 3 + 2] * K[b * 3 + 2];
-                        // P -= K (S K^T): lanes 0..5 each own one row of P
-                        if (l < 6) {
-#pragma unroll
-                            for (int b = 0; b < 6; ++b) {
-                                double kr0 = 0.0, kr1 = 0.0, kr2 = 0.0;
-#pragma unroll
-                                for (int a = 0; a < 6; ++a) {
-                                    kr0 = (l == a) ? K[a * 3] : kr0;
-                                    kr1 = (l == a) ? K[a * 3 + 1] : kr1;
-                                    kr2 = (l == a) ? K[a * 3 + 2] : kr2;
-                                }
-                                double corr = kr0 * SKt[b] + kr1 * SKt[6 + b] + kr2 * SKt[12 + b];
-                                t.P[g * 36 + l * 6 + b] = t.P[g * 36 + l * 6 + b] - corr;
-                            }
-                        }
-                        if (l == 0) {
-#pragma unroll
-                            for (int a = 0; a < 6; ++a) t.X[g * 6 + a] = xn[a];
-                        }
-                        if (nan_u) st_new = SSA_ST_UPDATE_NAN;
-                        if (rec) {
-                            if (l == 0) {
-#pragma unroll
-                                for (int c = 0; c < 3; ++c) rec[SSA_UPD_Y + c] = y[c];
-#pragma unroll
-                                for (int c = 0; c < 9; ++c) rec[SSA_UPD_S + c] = S[c];
-                            }
-                            if (is_sigma) {
-#pragma unroll
-                                for (int c = 0; c < 3; ++c) rec[SSA_UPD_SIGMAS_H + l * 3 + c] = z[c];
-                            }
-                        }
-                    }
-                }
-            }
-            if (rec && l == 0) {
-                rec[SSA_UPD_OBS_TAKEN] = taken ? 1.0 : 0.0;
-                rec[SSA_UPD_VISIBLE] = visible ? 1.0 : 0.0;
-                rec[SSA_UPD_ACTION] = (double)act;
-            }
-        }
-
-        // ---- F1: failed filters carry the sentinels (ssa_tasker_simple_2.py:157-158, 369-382)
-        if (valid && st_new != SSA_ST_OK && st_in == SSA_ST_OK) {
-            for (int idx = l; idx < 36; idx += 16) {
-                int a = idx / 6, b = idx - a * 6;
-                t.P[g * 36 + idx] = (a == b) ? (a < 3 ? X_FAILED_POS : X_FAILED_VEL) : 0.0;
-            }
-            if (l < 6) t.X[g * 6 + l] = (l < 3) ? X_FAILED_POS : X_FAILED_VEL;
-        }
-        if (valid && st_in != SSA_ST_OK) {  // already failed: state passes through unchanged
-            for (int idx = l; idx < 36; idx += 16) t.P[g * 36 + idx] = p.P_in[obj * 36 + idx];
-            if (l < 6) t.X[g * 6 + l] = xin[l];
-        }
-        // envs whose action selects nobody still get a cleared record (written by object 0's row)
-        if (valid && p.upd && j == 0 && l == 0 && !(act >= 0 && interval_ok && (int64_t)act < p.n_obj)) {
-            double* rec = p.upd + (int64_t)e * SSA_UPD_STRIDE;
-            rec[SSA_UPD_OBS_TAKEN] = 0.0;
-            rec[SSA_UPD_VISIBLE] = 0.0;
-            rec[SSA_UPD_ACTION] = -1.0;
-        }
-        if (l == 0) t.St[g] = st_new;
-        __syncthreads();
-        observe_rows(t, g, l);
-        __syncthreads();
-        store_tile(t, p, lane, base, cnt);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// O3: per-env reward statistics
-// One 1024-thread block per env.  Loads are issued 8 deep per thread before any use (the metrics
-// were just written by another kernel, every load is an L2/HBM round trip), then a wave-shuffle
-// reduction and one 16-entry LDS pass.  NaN ranks above everything (np.max / np.argmax semantics),
-// ties keep the lowest index.
+// O3 accumulator.  NaN ranks above everything (np.max / np.argmax semantics), ties keep the lowest index.
 struct StatAcc {
     double mx, sm;       // max delta_pos (NaN excluded), max sigma_pos (valid when !sm_nan)
     long long arg;       // index of sm (or of the first NaN sigma_pos)
@@ -776,11 +424,6 @@ SSA_DEV StatAcc stat_shfl_down(const StatAcc& a, int off)
     b.sm_nan = __shfl_down(a.sm_nan, off, 64);
     return b;
 }
-// Two small launches: `reward_partial_kernel` spreads the 20-byte-per-object read over many CUs
-// (a single CU only pulls ~24 GB/s, MI355X_MICROARCH.md) and leaves one StatAcc per block;
-// `reward_final_kernel` folds those.  The kernel boundary orders the two, no device-scope fence.
-constexpr int STAT_T = 256, STAT_ILP = 4, STAT_MAX_PARTS = 1024;
-
 SSA_DEV StatAcc stat_identity()
 {
     StatAcc a;
@@ -796,6 +439,477 @@ SSA_DEV StatAcc stat_wave_reduce(StatAcc a)
     }
     return a;
 }
+
+// ------------------------------------------------------------------------------------------
+// Intra-wave LDS hand-off.  The step kernel's workgroup IS one wavefront, all lanes run in
+// lockstep and the LDS queue is in order, so "every lane's earlier LDS writes are visible to every
+// lane's later LDS reads" only needs the compiler not to move accesses across this point and the
+// outstanding DS operations to have completed.  (Usable inside row-divergent branches, unlike a
+// workgroup barrier.)
+SSA_DEV void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// 1/sqrt(v) to double precision from the hardware estimate + two Newton steps.
+SSA_DEV double rsqrt_nr(double v)
+{
+    double y = __builtin_amdgcn_rsq(v);
+    double e = fma(-v * y, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-v * y, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    return y;
+}
+
+// U2 (common case): upper Cholesky of scale*P for the row's object, lane-distributed through LDS:
+// lane c owns column c; step j forms the pivot and row j (LAPACK dpotf2('U') order).  Ten VGPRs
+// instead of the 84 of a per-lane register factorisation.  Returns false (row-uniform) when a
+// pivot is <= 0 / NaN or P holds a non-finite entry -> robust_cholesky's ladder (out of line).
+SSA_DEV bool chol_row_lds(Tiles& t, double scale, double jit, int g, int l)
+{
+    const double* Pg = &t.P[g * 36];
+    double* Ug = &t.U[g * 36];
+    bool ok = true;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {   // scipy check_finite looks at all 36 entries
+        int idx = l + 16 * r;
+        if (idx < 36) ok = ok && (fabs(Pg[idx]) <= 1.79769313486231570e308);
+    }
+    ok = ((__ballot(!ok) >> (g * 16)) & 0xFFFFull) == 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double v = 1.0;
+        if (l >= j && l < 6) {
+            v = scale * Pg[j * 6 + l] + ((l == j) ? jit : 0.0);
+#pragma unroll
+            for (int i = 0; i < j; ++i) v = fma(-Ug[i * 6 + j], Ug[i * 6 + l], v);
+        }
+        const double ajj = row_bcast(v, j);
+        ok = ok && (ajj > 0.0);
+        const double y = rsqrt_nr(ajj);
+        if (l < 6) Ug[j * 6 + l] = (l == j) ? ajj * y : (l > j ? v * y : 0.0);
+        wave_lds_sync();
+    }
+    return ok;
+}
+
+// robust_cholesky (dynamics.py:402-417) for the row's object: plain attempt, then a + 10^i I for
+// i = -6..9 (first success wins); returns -1, 0..15, or 16 (LinAlgError).  Row-level operations only.
+__constant__ double JITTER[16] = {1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1.0, 10.0, 100.0, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9};
+SSA_DEV int robust_chol_row_lds(Tiles& t, double scale, int g, int l)
+{
+    if (chol_row_lds(t, scale, 0.0, g, l)) return -1;
+    bool finite = true;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        int idx = l + 16 * r;
+        if (idx < 36) finite = finite && (fabs(t.P[g * 36 + idx]) <= 1.79769313486231570e308);
+    }
+    finite = ((__ballot(!finite) >> (g * 16)) & 0xFFFFull) == 0;
+    if (!finite) return 16;
+    for (int r = 0; r < 16; ++r)
+        if (chol_row_lds(t, scale, JITTER[r], g, l)) return r;
+    return 16;
+}
+
+// One wavefront advances up to 4 objects (one per 16-lane row).
+//   FAST = true : the objects are consecutive (tile I/O); anything beyond the common path -- a
+//                 Cholesky that needs the jitter ladder, a sigma point outside the strong-elliptic
+//                 regime -- is NOT handled here: the object is queued (work list + mark) and its
+//                 status left untouched.  No out-of-line calls -> small register budget.
+//   FAST = false: complete semantics for arbitrary objects (the queue), per-row I/O; the row's
+//                 metrics are folded into `acc` (reward statistics of queued objects).
+template <int PROP, bool FAST>
+SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& p, int lane, int64_t obj, bool valid,
+                          int64_t base, int cnt, StatAcc& acc)
+{
+    const int g = lane >> 4, l = lane & 15;
+    const int e = valid ? (int)(obj / p.n_obj) : 0;
+    const int64_t j = valid ? obj - (int64_t)e * p.n_obj : 0;
+    // the action / time index of this object's env, fetched early (used after the transform)
+    const int act = valid ? p.actions[e] : -1;
+    const int tix = valid ? p.env_time[e] + p.time_offset : 0;
+
+    if (FAST) load_tile(t, p, lane, base, cnt);
+    else load_object(t, p, g, l, valid ? obj : 0, valid);
+    wave_lds_sync();
+
+    const int st_in = t.St[g];
+    const bool active = valid && st_in == SSA_ST_OK;
+    bool need_full = false;   // FAST only: row-uniform "this object needs the complete kernel"
+
+    // ---- U1/U2: sigma points
+    const int rung = robust_chol_row_lds(t, C.scale, g, l);
+    wave_lds_sync();
+    const bool chol_fail = (rung == 16);
+    const bool is_sigma = (l <= 12);
+    const bool is_pm = (l >= 1 && l <= 12);
+    double s[6];
+    {
+        const int krow = is_pm ? (l - 1) % 6 : 0;
+        const double sgn = (l >= 1 && l <= 6) ? 1.0 : ((l >= 7 && l <= 12) ? -1.0 : 0.0);
+        const bool use_filter = active && !chol_fail && l != 13;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            // inactive rows (failed / out-of-range objects) and lane 13 propagate the true state
+            s[c] = use_filter ? (t.X[g * 6 + c] + sgn * t.U[g * 36 + krow * 6 + c]) : t.T[g * 6 + c];
+        }
+    }
+    // ---- P1-P5: one Kepler solve per lane; strong-elliptic fast path inline, every other conic
+    // branch through the out-of-line complete restatement
+    double o[6];
+    {
+        const bool kep_ok = kepler_step_fast<PROP>(s, C.dt, o);
+        if (FAST) {
+            need_full = need_full || (((__ballot(!kep_ok && l < 14) >> (g * 16)) & 0xFFFFull) != 0);
+        } else if (!kep_ok) {
+            Vec6 si;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) si.v[c] = s[c];
+            Vec6 oo = kepler_general_v(si, C.dt);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) o[c] = oo.v[c];
+        }
+    }
+    wave_lds_sync();   // every lane has consumed t.X / t.T / t.U
+
+    // ---- U3: unscented transform, centred form of x = dot(Wm, sigmas_f):
+    //   x = sigma_0' + m',   m' = (sum(Wm) - 1) sigma_0' + Wi sum_{i>=1} (sigma_i' - sigma_0')
+    // (the reference's sum evaluated without the 1e8-fold cancellation of Wm0 ~ -2e8)
+    double xb[6];
+    bool nan_x = false;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const double s0 = row_bcast(o[c], 0);
+        const double d = is_pm ? (o[c] - s0) : 0.0;
+        if (is_pm) t.D[(g * 13 + l) * 6 + c] = d;
+        const double ssum = C.Wi * row_allsum(d);
+        const double mp = C.sum_wm_m1 * s0 + ssum;
+        xb[c] = s0 + mp;
+        nan_x = nan_x || (xb[c] != xb[c]);
+        if (l == 0) {
+            t.M[g * 12 + c] = ssum;
+            t.M[g * 12 + 6 + c] = mp;
+            t.X[g * 6 + c] = xb[c];
+        }
+        if (l == 13) t.T[g * 6 + c] = o[c];   // x_true[i]
+    }
+    wave_lds_sync();
+    covariance_rows(t, C, g, l);
+    wave_lds_sync();
+
+    int st_new = st_in;
+    if (active) {
+        if (chol_fail) st_new = SSA_ST_PREDICT_LINALG;
+        else if (nan_x) st_new = SSA_ST_PREDICT_NAN;
+    }
+
+    // ---- U5: the one update of this env (ssa_tasker_simple_2.py:292-315), in the row that owns the
+    // selected object.  Cross-lane traffic is row-level (DPP / bpermute); the small matrices are staged
+    // in the row's (now free) t.D area:  W[0..9) S | W[9..27) Pxz | W[27..36) inv(S) | W[36..54) K
+    const bool interval_ok = (C.update_interval <= 1) || (tix % C.update_interval == 0);
+    const bool my_update = valid && act >= 0 && (int64_t)act == j && interval_ok;
+    if (my_update && !need_full) {
+        const int tmod = (p.n_time > 0) ? tix % p.n_time : 0;   // row of `trans` / `z_noise` (episodes wrap)
+        double* rec = p.upd ? p.upd + (int64_t)e * SSA_UPD_STRIDE : nullptr;
+        double* W = &t.D[g * 78];
+        bool taken = false, visible = false;
+        if (st_new == SSA_ST_OK) {
+            const double* M = p.trans + (int64_t)tmod * 9;
+            // sigma points handed to update(): the propagated ones or, with
+            // SSA_FLAG_RESAMPLE, a fresh set drawn from the prior (x, P now in t.X / t.P)
+            double sf[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) sf[c] = o[c];
+            bool rs_fail = false;
+            if (C.flags & SSA_FLAG_RESAMPLE) {
+                const int rg = robust_chol_row_lds(t, C.scale, g, l);
+                wave_lds_sync();
+                rs_fail = (rg == 16);
+                const int krow = is_pm ? (l - 1) % 6 : 0;
+                const double sgn = (l >= 1 && l <= 6) ? 1.0 : ((l >= 7 && l <= 12) ? -1.0 : 0.0);
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+                    if (l != 13) sf[c] = xb[c] + sgn * t.U[g * 36 + krow * 6 + c];
+            }
+            // H1/H2: measurement of every sigma point (lanes 0-12) and of the true state (lane 13)
+            double z[3];
+            double el_mine;
+            {
+                double Mm[9], aer[3];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) Mm[i] = M[i];
+                hx_aer(sf, Mm, C.enu, C.obs_itrs, aer);
+                el_mine = aer[1];
+                if (C.obs_type == SSA_OBS_AER) { z[0] = aer[0]; z[1] = aer[1]; z[2] = aer[2]; }
+                else { z[0] = sf[0]; z[1] = sf[1]; z[2] = sf[2]; }
+            }
+            visible = row_bcast(el_mine, 13) >= C.obs_limit;  // object_visible(): elevation of the TRUE state (:418-425)
+            if (rec && l == 13) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) rec[SSA_UPD_Z_TRUE + c] = z[c];
+            }
+            if (visible && rs_fail) {
+                st_new = SSA_ST_UPDATE_LINALG;
+            } else if (visible) {
+                // H3/H5: predicted measurement
+                double zp[3];
+                const double wl = (l == 0) ? C.Wc0 : (is_pm ? C.Wi : 0.0);
+                if (C.obs_type == SSA_OBS_AER) {
+                    double uvw[3], um[3];
+                    aer2uvw(z, uvw);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        double u0 = row_bcast(uvw[c], 0);
+                        double du = is_pm ? (uvw[c] - u0) : 0.0;
+                        um[c] = u0 + (C.sum_wm_m1 * u0 + C.Wi * row_allsum(du));
+                    }
+                    uvw2aer(um, zp);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        double u0 = row_bcast(z[c], 0);
+                        double du = is_pm ? (z[c] - u0) : 0.0;
+                        zp[c] = u0 + (C.sum_wm_m1 * u0 + C.Wi * row_allsum(du));
+                    }
+                }
+                // H4: residuals; lane 13 forms the innovation of the noisy measurement
+                double rz[3];
+                {
+                    double zin[3];
+                    if (l == 13) {
+                        const double* zn = p.z_noise + (int64_t)e * p.zn_stride_env + (int64_t)tmod * p.zn_stride_time + (int64_t)act * 3;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) zin[c] = z[c] + zn[c];
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) zin[c] = z[c];
+                    }
+                    if (C.obs_type == SSA_OBS_AER) residual_z_aer(zin, zp, rz);
+                    else {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) rz[c] = zin[c] - zp[c];
+                    }
+                }
+                double y[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) y[c] = row_bcast(rz[c], 13);
+                // S = sum Wc rz rz^T + R ; Pxz = sum Wc (sigma_f - x)(rz)^T   -> LDS
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = a; b < 3; ++b) {
+                        double v = row_allsum(wl * (rz[a] * rz[b]));
+                        if (l == 0) {
+                            W[a * 3 + b] = v + C.R[a * 3 + b];
+                            W[b * 3 + a] = v + C.R[b * 3 + a];
+                        }
+                    }
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    const double dxa = sf[a] - xb[a];
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        double v = row_allsum(wl * (dxa * rz[b]));
+                        if (l == 0) W[9 + a * 3 + b] = v;
+                    }
+                }
+                wave_lds_sync();
+                bool inv_ok;
+                {
+                    double S[9], SI[9];
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) S[c] = W[c];
+                    inv_ok = inv3(S, SI);
+                    if (l == 0) {
+#pragma unroll
+                        for (int c = 0; c < 9; ++c) W[27 + c] = SI[c];
+                    }
+                }
+                wave_lds_sync();
+                if (!inv_ok) {
+                    st_new = SSA_ST_UPDATE_LINALG;
+                } else {
+                    taken = true;
+                    // K = Pxz inv(S): 18 entries over the row's lanes
+                    for (int idx = l; idx < 18; idx += 16) {
+                        const int a = idx / 3, b = idx - 3 * a;
+                        W[36 + idx] = W[9 + a * 3] * W[27 + b] + W[9 + a * 3 + 1] * W[30 + b] + W[9 + a * 3 + 2] * W[33 + b];
+                    }
+                    wave_lds_sync();
+                    // x += K y  (lanes 0..5); P -= K S K^T (36 entries over the row's lanes)
+                    double xn = 0.0;
+                    if (l < 6) xn = t.X[g * 6 + l] + (W[36 + l * 3] * y[0] + W[36 + l * 3 + 1] * y[1] + W[36 + l * 3 + 2] * y[2]);
+                    const bool nan_u = ((__ballot(l < 6 && xn != xn) >> (g * 16)) & 0xFFFFull) != 0;
+                    for (int idx = l; idx < 36; idx += 16) {
+                        const int a = idx / 6, b = idx - 6 * a;
+                        double corr = 0.0;
+#pragma unroll
+                        for (int u = 0; u < 3; ++u) {
+                            const double sk = W[u * 3] * W[36 + b * 3] + W[u * 3 + 1] * W[36 + b * 3 + 1] + W[u * 3 + 2] * W[36 + b * 3 + 2];  // (S K^T)[u][b]
+                            corr = fma(W[36 + a * 3 + u], sk, corr);
+                        }
+                        t.P[g * 36 + idx] = t.P[g * 36 + idx] - corr;
+                    }
+                    if (l < 6) t.X[g * 6 + l] = xn;
+                    if (nan_u) st_new = SSA_ST_UPDATE_NAN;
+                    if (rec) {
+                        if (l < 3) rec[SSA_UPD_Y + l] = y[l == 0 ? 0 : (l == 1 ? 1 : 2)];
+                        if (l < 9) rec[SSA_UPD_S + l] = W[l];
+                        if (is_sigma) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) rec[SSA_UPD_SIGMAS_H + l * 3 + c] = z[c];
+                        }
+                    }
+                }
+            }
+        }
+        if (rec && l == 0) {
+            rec[SSA_UPD_OBS_TAKEN] = taken ? 1.0 : 0.0;
+            rec[SSA_UPD_VISIBLE] = visible ? 1.0 : 0.0;
+            rec[SSA_UPD_ACTION] = (double)act;
+        }
+    }
+    // envs whose action selects nobody still get a cleared record (written by object 0's row)
+    if (FAST && valid && p.upd && j == 0 && l == 0 && !(act >= 0 && interval_ok && (int64_t)act < p.n_obj)) {
+        double* rec = p.upd + (int64_t)e * SSA_UPD_STRIDE;
+        rec[SSA_UPD_OBS_TAKEN] = 0.0;
+        rec[SSA_UPD_VISIBLE] = 0.0;
+        rec[SSA_UPD_ACTION] = -1.0;
+    }
+
+    // ---- F1: failed filters carry the sentinels (ssa_tasker_simple_2.py:157-158, 369-382)
+    wave_lds_sync();
+    if (valid && st_new != SSA_ST_OK && st_in == SSA_ST_OK) {
+        for (int idx = l; idx < 36; idx += 16) {
+            int a = idx / 6, b = idx - a * 6;
+            t.P[g * 36 + idx] = (a == b) ? (a < 3 ? X_FAILED_POS : X_FAILED_VEL) : 0.0;
+        }
+        if (l < 6) t.X[g * 6 + l] = (l < 3) ? X_FAILED_POS : X_FAILED_VEL;
+    }
+    if (valid && st_in != SSA_ST_OK) {  // already failed: the filter state passes through unchanged (:272)
+        for (int idx = l; idx < 36; idx += 16) t.P[g * 36 + idx] = p.P_in[obj * 36 + idx];
+        if (l < 6) t.X[g * 6 + l] = p.x_in[obj * 6 + l];
+    }
+    if (FAST) {
+        // queue what the common path could not finish; its status stays as it was and whatever was
+        // computed for it is overwritten by the complete kernel
+        need_full = need_full && active;
+        if (need_full) st_new = st_in;
+        if (l == 0) {
+            if (need_full) {
+                const int pos = atomicAdd(p.work, 1);
+                if ((int64_t)pos < (int64_t)p.n_env * p.n_obj) p.work[4 + pos] = (int32_t)obj;   // capacity = every object once
+            }
+            if (valid) p.work[4 + p.n_env * p.n_obj + obj] = need_full ? 1 : 0;   // mark: excluded from the slice statistics
+        }
+    }
+    if (l == 0) t.St[g] = st_new;
+    wave_lds_sync();
+    observe_rows(t, g, l);
+    wave_lds_sync();
+    if (FAST) {
+        store_tile(t, p, lane, base, cnt);
+    } else {
+        store_object(t, p, g, l, obj, valid, e, j, true);
+        if (valid && l == 0) {
+            StatAcc a = stat_identity();
+            const double dp = t.Met[g * 4 + 0], sp = t.Met[g * 4 + 2];
+            if (dp != dp) a.mx_nan = 1; else a.mx = dp;
+            a.c4 = dp < 1e4; a.c7 = dp < 1e7; a.nf = st_new != 0;
+            a.sm = sp; a.arg = j; a.sm_nan = (sp != sp);
+            stat_merge(acc, a);
+        }
+    }
+}
+
+#ifndef SSA_STEP_WAVES
+#define SSA_STEP_WAVES 4   // minimum waves per SIMD the register allocator must leave room for (<= 128 VGPRs; 5 spills)
+#endif
+template <int PROP>
+__global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(const StepK k)
+{
+    __shared__ Tiles t;
+    const int lane = threadIdx.x;
+    const int64_t total = (int64_t)k.p.n_env * k.p.n_obj;
+    const int64_t base = (int64_t)blockIdx.x * OBJ_PER_WAVE;
+    const int cnt = (int)((total - base) < OBJ_PER_WAVE ? (total - base) : OBJ_PER_WAVE);
+    StatAcc unused = stat_identity();
+    process_wave<PROP, true>(t, k.c, k.p, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, unused);
+}
+
+// Post kernel, grid (nparts, n_env) x 256 threads: (1) the queued objects of this env with complete
+// semantics, 4 per wavefront per iteration; (2) this block's slice of the env's reward statistics
+// (queued objects are skipped there -- `mark` -- and folded in by the wavefront that re-did them);
+// (3) one StatAcc per block for reward_final_kernel.
+constexpr int POST_T = 256, POST_ILP = 4;
+template <int PROP>
+__global__ void __launch_bounds__(POST_T) step_post_kernel(const StepK k, StatAcc* __restrict__ parts, int nparts)
+{
+    __shared__ Tiles tiles[POST_T / 64];
+    __shared__ StatAcc part[POST_T / 64];
+    const ssa_consts& C = k.c;
+    const ssa_step_params& p = k.p;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int e = blockIdx.y;
+    const int64_t m = p.n_obj, N = (int64_t)p.n_env * p.n_obj;
+    StatAcc acc = stat_identity();
+    const int n_listed = (int)((int64_t)p.work[0] < N ? (int64_t)p.work[0] : N);
+    const int waves_total = nparts * (POST_T / 64);
+    for (int it = blockIdx.x * (POST_T / 64) + w; it * OBJ_PER_WAVE < n_listed; it += waves_total) {
+        const int idx = it * OBJ_PER_WAVE + (lane >> 4);
+        int64_t obj = (idx < n_listed) ? (int64_t)p.work[4 + idx] : -1;
+        if (obj >= 0 && obj / m != e) obj = -1;   // another env's block takes it
+        process_wave<PROP, false>(tiles[w], C, p, lane, obj < 0 ? 0 : obj, obj >= 0, 0, 0, acc);
+        wave_lds_sync();
+    }
+    if (p.stats) {
+        const double* dpos = p.metrics + ((int64_t)e * 4 + 0) * m;
+        const double* spos = p.metrics + ((int64_t)e * 4 + 2) * m;
+        const int32_t* st = p.status + (int64_t)e * m;
+        const int32_t* mark = p.work + 4 + N + (int64_t)e * m;
+        for (int64_t b0 = (int64_t)blockIdx.x * POST_T * POST_ILP; b0 < m; b0 += (int64_t)nparts * POST_T * POST_ILP) {
+            double dp[POST_ILP], sp[POST_ILP];
+            int sv[POST_ILP], mk[POST_ILP];
+#pragma unroll
+            for (int q = 0; q < POST_ILP; ++q) {
+                int64_t i = b0 + (int64_t)q * POST_T + tid;
+                bool in = i < m;
+                dp[q] = in ? dpos[i] : 0.0;
+                sp[q] = in ? spos[i] : -2.0;
+                sv[q] = in ? st[i] : 0;
+                mk[q] = in ? mark[i] : 1;
+            }
+#pragma unroll
+            for (int q = 0; q < POST_ILP; ++q) {
+                int64_t i = b0 + (int64_t)q * POST_T + tid;
+                if (i < m && mk[q] == 0) {
+                    if (dp[q] != dp[q]) acc.mx_nan = 1; else acc.mx = fmax(acc.mx, dp[q]);
+                    acc.c4 += dp[q] < 1e4;
+                    acc.c7 += dp[q] < 1e7;
+                    acc.nf += sv[q] != 0;
+                    bool better = acc.sm_nan ? false : ((sp[q] != sp[q]) ? true : (sp[q] > acc.sm || (sp[q] == acc.sm && i < acc.arg)));
+                    if (better) { acc.sm = sp[q]; acc.arg = i; acc.sm_nan = (sp[q] != sp[q]); }
+                }
+            }
+        }
+        acc = stat_wave_reduce(acc);
+        if (lane == 0) part[w] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            StatAcc r = part[0];
+            for (int q = 1; q < POST_T / 64; ++q) stat_merge(r, part[q]);
+            parts[(int64_t)e * nparts + blockIdx.x] = r;
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// O3: per-env reward statistics
+// Two small launches: `reward_partial_kernel` spreads the 20-byte-per-object read over many CUs
+// (a single CU only pulls ~24 GB/s, MI355X_MICROARCH.md) and leaves one StatAcc per block;
+// `reward_final_kernel` folds those.  The kernel boundary orders the two, no device-scope fence.
+constexpr int STAT_T = 256, STAT_ILP = 4, STAT_MAX_PARTS = 1024;
+
 __global__ void __launch_bounds__(STAT_T) reward_partial_kernel(const double* __restrict__ metrics,
                                                                 const int32_t* __restrict__ status,
                                                                 StatAcc* __restrict__ parts, int64_t m, int nparts)
@@ -839,13 +953,15 @@ __global__ void __launch_bounds__(STAT_T) reward_partial_kernel(const double* __
         parts[(int64_t)e * nparts + blockIdx.x] = r;
     }
 }
-__global__ void __launch_bounds__(64) reward_final_kernel(const StatAcc* __restrict__ parts, double* __restrict__ stats, int nparts)
+__global__ void __launch_bounds__(64) reward_final_kernel(const StatAcc* __restrict__ parts, double* __restrict__ stats, int nparts,
+                                                          int32_t* __restrict__ work_count)
 {
     const int e = blockIdx.x, t = threadIdx.x;
+    if (work_count && e == 0 && t == 0) *work_count = 0;   // the step's queue has been consumed
     StatAcc a = stat_identity();
     for (int i = t; i < nparts; i += 64) stat_merge(a, parts[(int64_t)e * nparts + i]);
     a = stat_wave_reduce(a);
-    if (t == 0) {
+    if (t == 0 && stats) {
         double* o = stats + (int64_t)e * SSA_STAT_STRIDE;
         o[SSA_STAT_MAX_DPOS] = a.mx_nan ? __builtin_nan("") : a.mx;
         o[SSA_STAT_CNT_LT_1E4] = (double)a.c4;
@@ -1061,23 +1177,52 @@ extern "C" {
 int ssa_abi_version(void) { return SSA_ABI_VERSION; }
 const char* ssa_build_info(void) { return "libssa_hip gfx950 fp64 (" __DATE__ " " __TIME__ ")"; }
 
+static int post_parts(int64_t n_obj, int32_t n_env)
+{
+    int64_t want = (n_obj + (int64_t)POST_T * POST_ILP - 1) / ((int64_t)POST_T * POST_ILP);
+    int64_t spread = 256 / (n_env < 1 ? 1 : n_env);   // enough wavefronts to re-do a long queue quickly
+    if (want < spread) want = spread;
+    if (want < 1) want = 1;
+    if (want > 256) want = 256;
+    return (int)want;
+}
+
 int ssa_env_step_f64(const ssa_consts* c, const ssa_step_params* p, void* stream)
 {
     if (!c || !p || p->n_obj <= 0 || p->n_env <= 0) return SSA_E_INVALID;
     if (!p->x_true_in || !p->x_true_out || !p->x_in || !p->x_out || !p->P_in || !p->P_out || !p->status ||
-        !p->obs || !p->metrics || !p->trans || !p->env_time || !p->actions || !p->z_noise)
+        !p->obs || !p->metrics || !p->trans || !p->env_time || !p->actions || !p->z_noise || !p->work || !p->stat_ws)
         return SSA_E_INVALID;
     if (c->obs_type != SSA_OBS_AER && c->obs_type != SSA_OBS_XYZ) return SSA_E_INVALID;
     StepK k;
     k.c = *c;
     k.p = *p;
     const int64_t total = (int64_t)p->n_env * p->n_obj;
+    if (total >= ((int64_t)1 << 31)) return SSA_E_INVALID;
     dim3 grid(nblk(total, OBJ_PER_WAVE)), block(64);
+    const int nparts = post_parts(p->n_obj, p->n_env);
+    StatAcc* parts = (StatAcc*)p->stat_ws;
     hipStream_t s = (hipStream_t)stream;
-    if (c->propagator == SSA_PROP_FG) hipLaunchKernelGGL(step_kernel<1>, grid, block, 0, s, k);
-    else if (c->propagator == SSA_PROP_ELEMENTS) hipLaunchKernelGGL(step_kernel<0>, grid, block, 0, s, k);
-    else return SSA_E_INVALID;
+    const unsigned mask = p->launch_mask ? p->launch_mask : 7u;   // diagnostic: time one launch alone
+    if (c->propagator != SSA_PROP_FG && c->propagator != SSA_PROP_ELEMENTS) return SSA_E_INVALID;
+    const bool fg = c->propagator == SSA_PROP_FG;
+    if (mask & 1u) {
+        if (fg) hipLaunchKernelGGL(step_fast_kernel<1>, grid, block, 0, s, k);
+        else hipLaunchKernelGGL(step_fast_kernel<0>, grid, block, 0, s, k);
+    }
+    if (mask & 2u) {
+        if (fg) hipLaunchKernelGGL(step_post_kernel<1>, dim3(nparts, p->n_env), dim3(POST_T), 0, s, k, parts, nparts);
+        else hipLaunchKernelGGL(step_post_kernel<0>, dim3(nparts, p->n_env), dim3(POST_T), 0, s, k, parts, nparts);
+    }
+    // folds the per-block statistics (when requested) and resets the queue for the next step
+    if (mask & 4u)
+        hipLaunchKernelGGL(reward_final_kernel, dim3(p->n_env), dim3(64), 0, s, (const StatAcc*)parts, p->stats,
+                           p->stats ? nparts : 0, p->work);
     return launch_status();
+}
+int64_t ssa_env_step_work_bytes(int64_t n_obj, int32_t n_env)
+{
+    return (int64_t)(4 + 2 * n_obj * (int64_t)n_env) * (int64_t)sizeof(int32_t);
 }
 
 int ssa_reward_stats_f64(const double* metrics, const int32_t* status, double* stats, void* workspace, int64_t n_obj,
@@ -1089,12 +1234,12 @@ int ssa_reward_stats_f64(const double* metrics, const int32_t* status, double* s
     StatAcc* parts = (StatAcc*)workspace;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(reward_partial_kernel, dim3(nparts, n_env), dim3(STAT_T), 0, s, metrics, status, parts, n_obj, nparts);
-    hipLaunchKernelGGL(reward_final_kernel, dim3(n_env), dim3(64), 0, s, (const StatAcc*)parts, stats, nparts);
+    hipLaunchKernelGGL(reward_final_kernel, dim3(n_env), dim3(64), 0, s, (const StatAcc*)parts, stats, nparts, (int32_t*)nullptr);
     return launch_status();
 }
 int64_t ssa_reward_stats_workspace_bytes(int32_t n_env)
 {
-    return (int64_t)(n_env < 1 ? 1 : n_env) * (STAT_MAX_PARTS / 4) * (int64_t)sizeof(StatAcc);
+    return (int64_t)(n_env < 1 ? 1 : n_env) * 256 * (int64_t)sizeof(StatAcc) + 64;
 }
 
 int ssa_propagate_f64(const double* x_in, double* x_out, int64_t n, double dt, int32_t propagator, void* stream)

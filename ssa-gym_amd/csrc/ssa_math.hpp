@@ -176,69 +176,6 @@ SSA_DEV void kepler_elements(const double* x, double tof, double* out, double* d
     }
 }
 
-// SSA_PROP_FG: the same strong-elliptic branch with the element round trip removed
-// algebraically.  With e cos E0 = r0 v^2/mu - 1 and e sin E0 = r.v/sqrt(mu a)
-// (farnocchia.py:295-297) Kepler's equation for x = E - E0 reads
-//     x - (e cos E0) sin x + (e sin E0)(1 - cos x) = n tof              (:871-875, :946-954)
-// and coe2rv(nu(E)) equals the Lagrange combination r' = f r + g v, v' = f' r + g' v.
-// No acos/atan2/tan/atan, no singular elements (circular / equatorial orbits need no
-// special branch).  Falls back to kepler_general outside the strong-elliptic regime.
-SSA_DEV void kepler_fg(const double* x, double tof, double* out)
-{
-    const double* r = x;
-    const double* v = x + 3;
-    double rr = dot3(r, r), vv = dot3(v, v), rv = dot3(r, v);
-    double r0 = sqrt(rr);
-    double alpha = 2.0 / r0 - vv * (1.0 / MU);  // 1/a
-    double ome = r0 * alpha;                    // r0 / a = 1 - e cos E0
-    double ec = 1.0 - ome;                      // e cos E0
-    double sa = sqrt(alpha);
-    const double sqrt_mu = sqrt(MU);            // folded at compile time
-    double es = rv * sa / sqrt_mu;              // e sin E0
-    double ecc2 = ec * ec + es * es;
-    if (!(alpha > 0.0) || !(ecc2 < 0.99 * 0.99)) {
-        kepler_general(x, tof, out, nullptr);
-        return;
-    }
-    double n = sqrt_mu * alpha * sa;            // mean motion
-    double Mt = n * tof;
-    double k = rint(Mt * (1.0 / TWO_PI));
-    double Mr = fma(-k, TWO_PI, Mt);            // in [-pi, pi]
-    // safeguarded Newton on the monotone G(x) = x - ec sin x + es (1 - cos x) - Mr, G' = r/a > 0.
-    double x1 = Mr / ome;
-    double xs = x1 - 0.5 * es * x1 * x1 / ome;  // second-order starter, exact as Mr -> 0
-    double lo = Mr - 2.0, hi = Mr + 2.0;        // |periodic part| <= 2 e < 2
-    double xk = (fabs(Mr) < 0.5 && xs > lo && xs < hi) ? xs : Mr - es;
-    double s = 0.0, c = 1.0;
-    bool done = false;
-    double xres = __builtin_nan("");
-    for (int it = 0; it < 50; ++it) {
-        sincos(xk, &s, &c);
-        double G = (xk - ec * s + es * (1.0 - c)) - Mr;
-        double dG = 1.0 - ec * c + es * s;
-        if (G > 0.0) hi = xk; else lo = xk;
-        double xn = xk - G / dG;
-        if (!(xn >= lo && xn <= hi)) xn = 0.5 * (lo + hi);
-        if (!done && fabs(xn - xk) < 1e-10) { xres = xn; done = true; }
-        xk = xn;
-        if (__all(done)) break;
-    }
-    sincos(xres, &s, &c);
-    double omc = 1.0 - c;
-    double rho = 1.0 - (ec * c - es * s);       // r / a
-    double A = 1.0 / ome;                       // a / r0
-    double f = 1.0 - A * omc;
-    double g = (ome * s + es * omc) / n;
-    double fd = -sqrt_mu * sa * s / (rho * r0);
-    double gd = 1.0 - omc / rho;
-    out[0] = f * r[0] + g * v[0];
-    out[1] = f * r[1] + g * v[1];
-    out[2] = f * r[2] + g * v[2];
-    out[3] = fd * r[0] + gd * v[0];
-    out[4] = fd * r[1] + gd * v[1];
-    out[5] = fd * r[2] + gd * v[2];
-}
-
 // ---------------------------------------------------------------------------
 // Fast-path variants for the lean step kernel: same mathematics as kepler_fg /
 // kepler_elements on the strong-elliptic domain, but they RETURN FALSE instead of falling
@@ -257,6 +194,98 @@ SSA_DEV void rot_small(double d, double& s, double& c)
     s = s2;
 }
 
+// sinh x and cosh x - 1 without cancellation: Taylor series for |x| < 0.5 (truncation < 1e-19 relative),
+// libm beyond.
+SSA_DEV void sinh_coshm1(double x, double& sh, double& chm1)
+{
+    if (fabs(x) < 0.5) {
+        const double x2 = x * x;
+        sh = x * (1.0 + x2 * (1.0 / 6.0) * (1.0 + x2 * (1.0 / 20.0) * (1.0 + x2 * (1.0 / 42.0) * (1.0 + x2 * (1.0 / 72.0) *
+             (1.0 + x2 * (1.0 / 110.0) * (1.0 + x2 * (1.0 / 156.0) * (1.0 + x2 * (1.0 / 210.0))))))));
+        chm1 = x2 * 0.5 * (1.0 + x2 * (1.0 / 12.0) * (1.0 + x2 * (1.0 / 30.0) * (1.0 + x2 * (1.0 / 56.0) * (1.0 + x2 * (1.0 / 90.0) *
+               (1.0 + x2 * (1.0 / 132.0) * (1.0 + x2 * (1.0 / 182.0) * (1.0 + x2 * (1.0 / 240.0))))))));
+    } else {
+        sh = sinh(x);
+        chm1 = cosh(x) - 1.0;
+    }
+}
+
+// Stumpff functions c2(z) = (1 - cos sqrt z)/z, c3(z) = (sqrt z - sin sqrt z)/sqrt(z)^3 and their
+// hyperbolic continuations; series around z = 0.
+SSA_DEV void stumpff(double z, double& c2, double& c3)
+{
+    if (fabs(z) < 0.5) {
+        c2 = 0.5 - z * (1.0 / 24.0 - z * (1.0 / 720.0 - z * (1.0 / 40320.0 - z * (1.0 / 3628800.0 - z * (1.0 / 479001600.0 -
+             z * (1.0 / 87178291200.0 - z * (1.0 / 20922789888000.0)))))));
+        c3 = 1.0 / 6.0 - z * (1.0 / 120.0 - z * (1.0 / 5040.0 - z * (1.0 / 362880.0 - z * (1.0 / 39916800.0 - z * (1.0 / 6227020800.0 -
+             z * (1.0 / 1307674368000.0 - z * (1.0 / 355687428096000.0)))))));
+    } else if (z > 0.0) {
+        double sz = sqrt(z), sn, cs;
+        sincos(sz, &sn, &cs);
+        c2 = (1.0 - cs) / z;
+        c3 = (sz - sn) / (sz * z);
+    } else {
+        double sz = sqrt(-z), sh, chm1;
+        sinh_coshm1(sz, sh, chm1);
+        c2 = chm1 / (-z);
+        c3 = (sh - sz) / (sz * (-z));
+    }
+}
+
+// Near-parabolic band (0.99 <= ecc <= 1.01; farnocchia.py:876-914, 955-999 use the D / S_x series
+// there): universal-variable Kepler equation  (r.v/sqrt mu) chi^2 c2 + (1 - r0 alpha) chi^3 c3 + r0 chi
+// = sqrt(mu) tof,  z = alpha chi^2, monotone in chi (derivative = r > 0); f,g from the same c2, c3.
+SSA_DEV bool kepler_universal(const double* x, double tof, double r0, double alpha, double rv, double* out)
+{
+    const double* r = x;
+    const double* v = x + 3;
+    const double sqrt_mu = sqrt(MU);
+    const double sig = rv / sqrt_mu, target = sqrt_mu * tof;
+    double chi = target / r0;
+    double lo = -1e300, hi = 1e300, c2 = 0.5, c3 = 1.0 / 6.0, rad = r0;
+    bool done = false;
+    for (int it = 0; it < 60; ++it) {
+        const double chi2 = chi * chi, z = alpha * chi2;
+        stumpff(z, c2, c3);
+        const double Fv = sig * chi2 * c2 + (1.0 - r0 * alpha) * chi2 * chi * c3 + r0 * chi - target;
+        rad = chi2 * c2 + sig * chi * (1.0 - z * c3) + r0 * (1.0 - z * c2);
+        if (Fv > 0.0) hi = chi; else lo = chi;
+        double step = -Fv / rad;
+        const double lim = fabs(chi) + fabs(target) / r0 + 1.0;
+        step = fmin(fmax(step, -lim), lim);
+        double cn = chi + step;
+        if (!(cn >= lo && cn <= hi)) cn = (lo > -1e299 && hi < 1e299) ? 0.5 * (lo + hi) : chi + 0.5 * step;
+        if (!done) {
+            done = fabs(cn - chi) <= 1e-12 * (fabs(cn) + 1.0);
+            chi = cn;
+        }
+        if (__all(done)) break;
+    }
+    const double chi2 = chi * chi, z = alpha * chi2;
+    stumpff(z, c2, c3);
+    rad = chi2 * c2 + sig * chi * (1.0 - z * c3) + r0 * (1.0 - z * c2);
+    const double f = 1.0 - chi2 * c2 / r0;
+    const double g = tof - chi2 * chi * c3 / sqrt_mu;
+    const double fd = sqrt_mu * chi * (z * c3 - 1.0) / (rad * r0);
+    const double gd = 1.0 - chi2 * c2 / rad;
+    out[0] = f * r[0] + g * v[0];
+    out[1] = f * r[1] + g * v[1];
+    out[2] = f * r[2] + g * v[2];
+    out[3] = fd * r[0] + gd * v[0];
+    out[4] = fd * r[1] + gd * v[1];
+    out[5] = fd * r[2] + gd * v[2];
+    return done && (rad > 0.0);
+}
+
+// Strong-elliptic AND strong-hyperbolic branches of farnocchia() in Lagrange f,g form.
+//   elliptic   (ecc < 0.99, farnocchia.py:871-875, 946-954):  x = E - E0,
+//       x - (e cos E0) sin x + (e sin E0)(1 - cos x) = n tof
+//   hyperbolic (ecc > 1.01, farnocchia.py:915-919, 1000-1004): x = F - F0,
+//       (e cosh F0) sinh x - x + (e sinh F0)(cosh x - 1) = n tof
+// with e cos E0 = 1 - r0/a, e sin E0 = r.v/sqrt(mu a) (and their hyperbolic twins with |a|); the
+// state follows from r' = f r + g v, v' = f' r + g' v.  The near-parabolic band in between goes
+// through kepler_universal.  Returns false -- the caller then takes the complete restatement -- only
+// for NaN / degenerate input or when a safeguarded Newton iteration does not converge.
 SSA_DEV bool kepler_fg_fast(const double* x, double tof, double* out)
 {
     const double* r = x;
@@ -265,36 +294,52 @@ SSA_DEV bool kepler_fg_fast(const double* x, double tof, double* out)
     double rr = dot3(r, r), vv = dot3(v, v), rv = dot3(r, v);
     double r0 = sqrt(rr);
     double inv_r0 = 1.0 / r0;
-    double alpha = 2.0 * inv_r0 - vv * inv_mu;  // 1/a
-    double ome = r0 * alpha;                    // r0 / a = 1 - e cos E0
-    double ec = 1.0 - ome;                      // e cos E0
-    double sa = sqrt(alpha);
-    double es = rv * sa * inv_sqrt_mu;          // e sin E0
-    double ecc2 = ec * ec + es * es;
-    bool ok = (alpha > 0.0) && (ecc2 < 0.99 * 0.99);
+    double alpha = 2.0 * inv_r0 - vv * inv_mu;  // 1/a  (< 0: hyperbola)
+    const bool hyper = alpha < 0.0;
+    double beta = fabs(alpha);
+    double sb = sqrt(beta);
+    double q0 = r0 * beta;                      // r0/|a|
+    double ec = hyper ? 1.0 + q0 : 1.0 - q0;    // e cosh F0 | e cos E0
+    double es = rv * sb * inv_sqrt_mu;          // e sinh F0 | e sin E0
+    double ecc2 = hyper ? ec * ec - es * es : ec * ec + es * es;
+    bool ok = hyper ? (ecc2 > 1.01 * 1.01) : (ecc2 < 0.99 * 0.99);
+    const bool band = !ok && (ecc2 >= 0.99 * 0.99) && (ecc2 <= 1.01 * 1.01) && (r0 > 0.0);
+    ok = ok && (beta > 0.0) && (r0 > 0.0);
     // keep out-of-domain lanes numerically harmless (their result is discarded)
-    if (!ok) { alpha = 1e-7; ome = 1.0; ec = 0.0; es = 0.0; sa = sqrt(alpha); }
-    double n = sqrt_mu * alpha * sa;            // mean motion
+    if (!ok) { beta = 1e-7; sb = sqrt(beta); q0 = 1.0; ec = hyper ? 2.0 : 0.0; es = 0.0; }
+    double n = sqrt_mu * beta * sb;             // mean motion
     double Mt = n * tof;
-    double k = rint(Mt * (1.0 / TWO_PI));
-    double Mr = fma(-k, TWO_PI, Mt);            // in [-pi, pi]
-    double inv_ome = 1.0 / ome;
-    double x1 = Mr * inv_ome;
-    double xs = x1 - 0.5 * es * x1 * x1 * inv_ome;
-    double lo = Mr - 2.0, hi = Mr + 2.0;
-    double xk = (fabs(Mr) < 0.5 && xs > lo && xs < hi) ? xs : Mr - es;
-    double s, c;
-    sincos(xk, &s, &c);
+    double Mr = Mt;
+    if (!hyper) {
+        double k = rint(Mt * (1.0 / TWO_PI));
+        Mr = fma(-k, TWO_PI, Mt);               // in [-pi, pi]
+    }
+    double inv_q0 = 1.0 / q0;
+    double x1 = Mr * inv_q0;                    // first order:  G ~ q0 x
+    double xs = x1 - 0.5 * es * x1 * x1 * inv_q0;
+    double lo = hyper ? -1e300 : Mr - 2.0, hi = hyper ? 1e300 : Mr + 2.0;
+    double xk = (fabs(Mr) < 0.5 && xs > lo && xs < hi) ? xs : (hyper ? asinh(Mr / ec) : Mr - es);
+    double s, c;                                // sin x, cos x   |   sinh x, cosh x - 1
+    if (hyper) sinh_coshm1(xk, s, c); else sincos(xk, &s, &c);
     bool done = false;
-    for (int it = 0; it < 50; ++it) {
-        double G = (xk - ec * s + es * (1.0 - c)) - Mr;
-        double dG = 1.0 - ec * c + es * s;
+    for (int it = 0; it < 60; ++it) {
+        double G, dG;
+        if (hyper) {
+            G = (ec * s - xk + es * c) - Mr;
+            dG = ec * (c + 1.0) - 1.0 + es * s;
+        } else {
+            G = (xk - ec * s + es * (1.0 - c)) - Mr;
+            dG = 1.0 - ec * c + es * s;
+        }
         if (G > 0.0) hi = xk; else lo = xk;
-        double xn = xk - G / dG;
+        double dx = -G / dG;
+        if (hyper) dx = fmin(fmax(dx, -1.0), 1.0);   // sinh/cosh grow fast: bounded steps
+        double xn = xk + dx;
         if (!(xn >= lo && xn <= hi)) xn = 0.5 * (lo + hi);
-        double dx = xn - xk;
+        dx = xn - xk;
         if (!done) {
-            if (fabs(dx) <= 0.02) rot_small(dx, s, c);
+            if (hyper) sinh_coshm1(xn, s, c);
+            else if (fabs(dx) <= 0.02) rot_small(dx, s, c);
             else sincos(xn, &s, &c);
             xk = xn;
             done = fabs(dx) < 1e-10;
@@ -302,12 +347,13 @@ SSA_DEV bool kepler_fg_fast(const double* x, double tof, double* out)
         if (__all(done || !ok)) break;
     }
     ok = ok && done;                            // non-convergence -> complete kernel (NaN semantics there)
-    double omc = 1.0 - c;
-    double rho = 1.0 - (ec * c - es * s);       // r / a
+    if (band) return kepler_universal(x, tof, r0, alpha, rv, out);
+    double omc = hyper ? c : 1.0 - c;           // cosh x - 1 | 1 - cos x
+    double rho = hyper ? (ec * (c + 1.0) - 1.0 + es * s) : (1.0 - (ec * c - es * s));   // r/|a|
     double inv_rho = 1.0 / rho;
-    double f = 1.0 - inv_ome * omc;
-    double g = (ome * s + es * omc) / n;
-    double fd = -sqrt_mu * sa * s * inv_rho * inv_r0;
+    double f = 1.0 - inv_q0 * omc;
+    double g = (q0 * s + es * omc) / n;
+    double fd = -sqrt_mu * sb * s * inv_rho * inv_r0;
     double gd = 1.0 - omc * inv_rho;
     out[0] = f * r[0] + g * v[0];
     out[1] = f * r[1] + g * v[1];
@@ -341,6 +387,13 @@ SSA_DEV bool kepler_step_fast(const double* x, double tof, double* out)
 {
     if (PROP == 1) return kepler_fg_fast(x, tof, out);
     return kepler_elements_fast(x, tof, out);
+}
+
+// SSA_PROP_FG with complete semantics: the f,g / universal-variable path, anything it declines (NaN
+// input, no convergence) through the out-of-line restatement of farnocchia().
+SSA_DEV void kepler_fg(const double* x, double tof, double* out)
+{
+    if (!kepler_fg_fast(x, tof, out)) kepler_general(x, tof, out, nullptr);
 }
 
 template <int PROP>

@@ -63,6 +63,8 @@ class HotPathEngine:
         self._p.n_time = self.n_time
         self._lib = _lib.load()
         self._stats_ws = device.stats_workspace(self.E, d)
+        self.work = torch.zeros(self._lib.ssa_env_step_work_bytes(self.m, self.E) // 4, dtype=torch.int32, device=d)
+        self._p.work, self._p.stat_ws, self._p.launch_mask = self.work.data_ptr(), self._stats_ws.data_ptr(), 0
         self._cref = C.byref(self.consts)
         self._pref = C.byref(self._p)
         # element strides of one history slot
@@ -105,7 +107,7 @@ class HotPathEngine:
 
     # ------------------------------------------------------------------ one step
     def launch_step(self, slot_in, slot_out, time_offset, actions_ptr=None, stream=None):
-        """enqueue step kernel + statistics kernel; asynchronous, no host sync."""
+        """enqueue the step (common-path kernel, post kernel, final kernel); asynchronous, no host sync."""
         p = self._p
         p.time_offset = int(time_offset)
         p.x_true_in, p.x_true_out = self._bx_t + slot_in * self._sx, self._bx_t + slot_out * self._sx
@@ -115,14 +117,11 @@ class HotPathEngine:
         p.metrics = self._bm + slot_out * self._sm
         p.upd = self._bu + slot_out * self._su
         p.actions = self.actions.data_ptr() if actions_ptr is None else actions_ptr
+        p.stats = self._bs + slot_out * self._ss
         s = torch.cuda.current_stream().cuda_stream if stream is None else stream
         rc = self._lib.ssa_env_step_f64(self._cref, self._pref, s)
         if rc:
             raise _lib.SsaHipError("ssa_env_step_f64 failed with code %d" % rc)
-        rc = self._lib.ssa_reward_stats_f64(p.metrics, self._p.status, self._bs + slot_out * self._ss,
-                                            self._stats_ws.data_ptr(), self.m, self.E, s)
-        if rc:
-            raise _lib.SsaHipError("ssa_reward_stats_f64 failed with code %d" % rc)
 
     def set_actions(self, actions):
         a = torch.as_tensor(np.asarray(actions, dtype=np.int32).reshape(self.E))
