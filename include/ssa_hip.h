@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SSA_ABI_VERSION 4
+#define SSA_ABI_VERSION 5
 
 /* error codes */
 #define SSA_OK 0
@@ -120,6 +120,9 @@ typedef struct ssa_step_params {
     double *stats;             /* [E][SSA_STAT_STRIDE] reward statistics of this step (O3), may be NULL */
     int32_t *work;             /* ssa_env_step_work_bytes(): exception queue; zero it once before the first call */
     void *stat_ws;             /* ssa_reward_stats_workspace_bytes(): per-block statistics partials */
+    double *aer_out;           /* [E*m][4] aer_obs() of the NEW state (O4: az, el, range, trace P; NaN/inf -> 0.001;
+                                  ssa_tasker_simple_2.py:834-840), may be NULL.  Written by the post kernel, so the
+                                  'aer' observation / the sharded all-gather payload costs no extra launch. */
 } ssa_step_params;
 
 /* ---------------------------------------------------------------- fused hot path

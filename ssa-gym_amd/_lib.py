@@ -31,11 +31,12 @@ class ssa_step_params(C.Structure):
         ("upd", c_dp), ("trans", c_dp), ("env_time", c_dp), ("actions", c_dp), ("z_noise", c_dp),
         ("zn_stride_env", C.c_int64), ("zn_stride_time", C.c_int64),
         ("n_time", C.c_int32), ("launch_mask", C.c_uint32), ("stats", c_dp), ("work", c_dp), ("stat_ws", c_dp),
+        ("aer_out", c_dp),
     ]
 
 
 # constants of include/ssa_hip.h
-ABI_VERSION = 4
+ABI_VERSION = 5
 ST_OK, ST_PREDICT_NAN, ST_PREDICT_LINALG, ST_UPDATE_NAN, ST_UPDATE_LINALG = range(5)
 OBS_AER, OBS_XYZ = 0, 1
 PROP_ELEMENTS, PROP_FG = 0, 1

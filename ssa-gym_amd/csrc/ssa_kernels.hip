@@ -510,6 +510,21 @@ SSA_DEV int robust_chol_row_lds(Tiles& t, double scale, int g, int l)
     return 16;
 }
 
+// O4 for one object (ssa_tasker_simple_2.py:834-840): [hx(x_filter[:3]), trace(P)], NaN/inf -> 0.001
+SSA_DEV void aer_obs_row(const double* x, const double* P, const ssa_step_params& p, const ssa_consts& C, int e, int64_t obj)
+{
+    const int tix = p.env_time[e] + p.time_offset;
+    const double* M = p.trans + (int64_t)((p.n_time > 0) ? tix % p.n_time : 0) * 9;
+    double Mm[9], xx[3] = {x[0], x[1], x[2]}, z[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Mm[i] = M[i];
+    hx_aer(xx, Mm, C.enu, C.obs_itrs, z);
+    const double tr = P[0] + P[7] + P[14] + P[21] + P[28] + P[35];
+    const double v[4] = {z[0], z[1], z[2], tr};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) p.aer_out[obj * 4 + c] = (fabs(v[c]) <= 1.79769313486231570e308) ? v[c] : 0.001;
+}
+
 // One wavefront advances up to 4 objects (one per 16-lane row).
 //   FAST = true : the objects are consecutive (tile I/O); anything beyond the common path -- a
 //                 Cholesky that needs the jitter ladder, a sigma point outside the strong-elliptic
@@ -810,6 +825,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         store_tile(t, p, lane, base, cnt);
     } else {
         store_object(t, p, g, l, obj, valid, e, j, true);
+        if (valid && l == 0 && p.aer_out) aer_obs_row(&t.X[g * 6], &t.P[g * 36], p, C, e, obj);
         if (valid && l == 0) {
             StatAcc a = stat_identity();
             const double dp = t.Met[g * 4 + 0], sp = t.Met[g * 4 + 2];
@@ -860,6 +876,15 @@ __global__ void __launch_bounds__(POST_T) step_post_kernel(const StepK k, StatAc
         if (obj >= 0 && obj / m != e) obj = -1;   // another env's block takes it
         process_wave<PROP, false>(tiles[w], C, p, lane, obj < 0 ? 0 : obj, obj >= 0, 0, 0, acc);
         wave_lds_sync();
+    }
+    if (p.aer_out) {   // O4 for every object of this block's slice that was not re-done above
+        const int32_t* mark = p.work + 4 + N + (int64_t)e * m;
+        for (int64_t i = (int64_t)blockIdx.x * POST_T + tid; i < m; i += (int64_t)nparts * POST_T) {
+            if (mark[i] == 0) {
+                const int64_t obj = (int64_t)e * m + i;
+                aer_obs_row(p.x_out + obj * 6, p.P_out + obj * 36, p, C, e, obj);
+            }
+        }
     }
     if (p.stats) {
         const double* dpos = p.metrics + ((int64_t)e * 4 + 0) * m;

@@ -106,7 +106,7 @@ class HotPathEngine:
         self.status.zero_()
 
     # ------------------------------------------------------------------ one step
-    def launch_step(self, slot_in, slot_out, time_offset, actions_ptr=None, stream=None):
+    def launch_step(self, slot_in, slot_out, time_offset, actions_ptr=None, stream=None, aer_out=0, stats_out=0):
         """enqueue the step (common-path kernel, post kernel, final kernel); asynchronous, no host sync."""
         p = self._p
         p.time_offset = int(time_offset)
@@ -117,7 +117,8 @@ class HotPathEngine:
         p.metrics = self._bm + slot_out * self._sm
         p.upd = self._bu + slot_out * self._su
         p.actions = self.actions.data_ptr() if actions_ptr is None else actions_ptr
-        p.stats = self._bs + slot_out * self._ss
+        p.stats = stats_out if stats_out else self._bs + slot_out * self._ss   # e.g. straight into a send buffer
+        p.aer_out = aer_out
         s = torch.cuda.current_stream().cuda_stream if stream is None else stream
         rc = self._lib.ssa_env_step_f64(self._cref, self._pref, s)
         if rc:

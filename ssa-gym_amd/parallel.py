@@ -52,40 +52,72 @@ class ShardPlan:
 
 
 class ShardedStepper:
-    """one env of m_total objects, one rank per shard."""
+    """one env of m_total objects, one rank per shard.
+
+    Two send/receive buffer pairs alternate.  With `overlap=True` (GPU) the all-gather of step k is
+    issued on a dedicated communication stream behind an event, so RCCL moves step k's payload over
+    xGMI while the compute stream already runs the kernels of step k+1; the compute stream only waits
+    (on an event, not on the host) before it overwrites a payload buffer two steps later."""
 
     def __init__(self, plan, local, group=None):
         self.plan, self.local, self.group = plan, local, group
         dev = local.device
         self.width = 4 * plan.m_pad + STAT_STRIDE
-        self.send = torch.zeros(self.width, dtype=torch.float64, device=dev)
-        self.recv = torch.zeros(plan.world * self.width, dtype=torch.float64, device=dev)
-        self._work = None
+        self.send = [torch.zeros(self.width, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.recv = [torch.zeros(plan.world * self.width, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.k = 0
+        self._gpu = torch.device(dev).type == "cuda"
+        if self._gpu:
+            self.comm = torch.cuda.Stream(device=dev)
+            self._ready = [torch.cuda.Event(), torch.cuda.Event()]
+            self._done = [torch.cuda.Event(), torch.cuda.Event()]
+            self._pending = [False, False]
 
-    def step(self, global_action, async_op=False):
+    def step(self, global_action, overlap=False):
         p = self.plan
-        self.local.step(p.local_action(global_action))           # enqueue kernels (no sync)
-        self.local.pack_into(self.send[:4 * p.m_local], self.send[4 * p.m_pad:])   # aer obs + stats
-        if p.world > 1:
-            self._work = dist.all_gather_into_tensor(self.recv, self.send, group=self.group, async_op=async_op)
+        b = self.k & 1
+        send, recv = self.send[b], self.recv[b]
+        use_dist = dist.is_available() and dist.is_initialized()
+        overlap = overlap and self._gpu and use_dist
+        if overlap and self._pending[b]:
+            torch.cuda.current_stream().wait_event(self._done[b])   # payload of step k-2 has left
+            self._pending[b] = False
+        # kernels of this step write (az, el, range, trP) and the statistics straight into `send`
+        self.local.step(p.local_action(global_action), send[:4 * p.m_local], send[4 * p.m_pad:])
+        if not use_dist:   # single process without a process group
+            recv.copy_(send)
+        elif overlap:
+            self._ready[b].record(torch.cuda.current_stream())
+            self.comm.wait_event(self._ready[b])
+            with torch.cuda.stream(self.comm):
+                dist.all_gather_into_tensor(recv, send, group=self.group)
+                self._done[b].record(self.comm)
+            self._pending[b] = True
         else:
-            self.recv.copy_(self.send)
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+        self.k += 1
 
     def wait(self):
-        if self._work is not None:
-            self._work.wait()
-            self._work = None
+        """make the current stream wait for every all-gather issued so far."""
+        if self._gpu:
+            for b in (0, 1):
+                if self._pending[b]:
+                    torch.cuda.current_stream().wait_event(self._done[b])
+                    self._pending[b] = False
 
-    # ---- views of the reassembled global state (call after the collective has completed)
+    # ---- views of the reassembled global state of the latest step (call after wait())
+    def _latest(self):
+        return self.recv[(self.k - 1) & 1]
+
     def global_obs(self):
         p = self.plan
-        rows = self.recv.view(p.world, self.width)
+        rows = self._latest().view(p.world, self.width)
         return torch.cat([rows[r, :4 * p.sizes[r]] for r in range(p.world)])
 
     def global_stats(self):
         """reduce the per-rank statistics exactly as the single-GPU kernel would have produced them."""
         p = self.plan
-        st = self.recv.view(p.world, self.width)[:, 4 * p.m_pad:].cpu().numpy()
+        st = self._latest().view(p.world, self.width)[:, 4 * p.m_pad:].cpu().numpy()
         out = np.zeros(STAT_STRIDE)
         out[STAT_MAX_DPOS] = np.nan if np.isnan(st[:, STAT_MAX_DPOS]).any() else st[:, STAT_MAX_DPOS].max()
         out[STAT_CNT_LT_1E4] = st[:, STAT_CNT_LT_1E4].sum()
@@ -116,27 +148,24 @@ class HipLocalStepper:
         self._sched = torch.as_tensor(np.asarray(local_actions, dtype=np.int32)).to(self.device)
         self._sched_k0 = self.tick
 
-    def step(self, local_action):
+    def step(self, local_action, obs_out=None, stats_out=None):
+        """enqueue one env step; when given, the post/final kernels write the shard's aer observation
+        block and its reward statistics directly into `obs_out` / `stats_out` (the all-gather payload)."""
         e = self.engine
         self.tick += 1
+        aer = obs_out.data_ptr() if obs_out is not None else 0
+        st = stats_out.data_ptr() if stats_out is not None else 0
         if self._sched is not None:
             k = (self.tick - 1 - self._sched_k0) % self._sched.numel()
-            e.launch_step((self.tick - 1) % e.H, self.tick % e.H, self.tick, actions_ptr=self._sched.data_ptr() + 4 * k)
+            e.launch_step((self.tick - 1) % e.H, self.tick % e.H, self.tick, actions_ptr=self._sched.data_ptr() + 4 * k,
+                          aer_out=aer, stats_out=st)
             return
         self._act[0] = int(local_action)
         e.actions.copy_(self._act)
-        e.launch_step((self.tick - 1) % e.H, self.tick % e.H, self.tick)
+        e.launch_step((self.tick - 1) % e.H, self.tick % e.H, self.tick, aer_out=aer, stats_out=st)
 
     def reset_episode(self, snap, episode_len):
         """start a new episode from a device-resident snapshot: the next step gets time index 1."""
         e = self.engine
         self.tick += (-self.tick) % episode_len          # advance to the next multiple of the episode length
         e.restore(self.tick % e.H, snap)
-
-    def pack_into(self, obs_out, stats_out):
-        from . import device
-        e = self.engine
-        slot = self.tick % e.H
-        M = e.trans[self.tick % e.n_time]
-        device.aer_obs(e.x_filter[slot], e.P_filter[slot], M, self.consts, out=obs_out.view(-1, 4))
-        stats_out.copy_(e.stats[slot, 0])

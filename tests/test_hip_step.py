@@ -334,3 +334,60 @@ def test_full_size_20000_properties(hip):
     np.testing.assert_allclose(energy(a["x_true"]), energy(xt), rtol=1e-13)
     # predicted mean stays within a fraction of sigma of the propagated previous mean
     assert a["stats"][0, hip.lib.STAT_N_FAILED] == 0
+
+
+@pytest.mark.parametrize("propagator", ["fg", "elements"])
+def test_diverged_filter_states_all_conic_branches(hip, oracle, oracle_ld, propagator):
+    """filters that have left the strong-elliptic regime (what a predict-only UKF at alpha=1e-4 does
+    after ~250 steps): hyperbolic, near-parabolic and high-eccentricity states inside the fused step.
+    SSA_PROP_FG handles them in the common-path kernel (hyperbolic f,g / universal variables),
+    SSA_PROP_ELEMENTS through the exception queue + complete kernel; both must agree with the oracle's
+    farnocchia() branches wherever the oracle itself produces a finite prior."""
+    from ssa_gym_amd.catalogue import coe2rv_host
+    rs = np.random.RandomState(23)
+    m = 600
+    ecc = np.concatenate([rs.uniform(0.95, 0.9899, m // 4), rs.uniform(0.9901, 1.0099, m // 4),
+                          rs.uniform(1.0101, 1.05, m // 4), rs.uniform(1.05, 2.5, m // 4)])
+    rp = rs.uniform(6.8e6, 3e7, m)
+    nu_max = np.where(ecc > 1, 0.7 * np.arccos(-1 / np.maximum(ecc, 1.000001)), 2.5)
+    x = coe2rv_host(rp * (1 + ecc), ecc, rs.uniform(0.2, 2.9, m), rs.uniform(0, 6.28, m), rs.uniform(0, 6.28, m),
+                    rs.uniform(-1, 1, m) * nu_max)
+    xt, _, P, g = make_batch(m, seed=24)
+    gpu = run_gpu(hip, xt, x, P, g, [-1], 4, 1e-4, propagator=propagator)
+    f64 = run_oracle(oracle, xt, x, P, g, -1, 4, 1e-4, z_noise3=np.zeros(3))
+    ld = run_oracle(oracle_ld, xt, x, P, g, -1, 4, 1e-4, centred=True, z_noise3=np.zeros(3))
+    ok = (ld["status"] == 0) & (f64["status"] == 0)
+    assert ok.mean() > 0.9
+    if propagator == "elements":      # same branch structure as the reference: same failures
+        assert np.mean(gpu["status"] == f64["status"]) > 0.98
+    both = ok & (gpu["status"] == 0)
+    assert both.mean() > 0.9
+    sub = lambda d: {k: d[k][both] for k in ("x", "P")}   # noqa: E731
+    gp, gv, gP = errs(sub(gpu), sub(ld))
+    rp_, rv_, rP_ = errs(sub(f64), sub(ld))
+    # against the exact value: as good as the reference arithmetic (batch statistics), and in absolute terms
+    assert np.median(gp) <= 3 * np.median(rp_) + 1e-12
+    assert np.quantile(gp, 0.99) <= 3 * np.quantile(rp_, 0.99) + 1e-9
+    assert np.median(gp) < 1e-6
+    assert_states_close(gpu["x_true"], ld["x_true"], 1e-9, "truth")
+
+
+def test_fused_aer_payload_matches_operator(hip, oracle):
+    """the post / final kernels can write the (az, el, range, trace P) block and the statistics straight
+    into a caller buffer (the sharded all-gather payload): identical to the stand-alone O4 / O3 operators."""
+    m = 1000
+    xt, x, P, g = make_batch(m, seed=31)
+    consts = hip.host.make_consts(g["Q"], g["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, g["obs_lla"])
+    eng = hip.engine.HotPathEngine(consts, m, 1, c2t(), np.zeros((1, 480, m, 3)), history=2)
+    eng.load_state(0, xt, x, P)
+    eng.set_actions([17])
+    send = hip.torch.full((4 * m + 8,), -7.0, dtype=hip.torch.float64, device="cuda")
+    eng.launch_step(0, 1, 9, aer_out=send[:4 * m].data_ptr(), stats_out=send[4 * m:].data_ptr())
+    hip.torch.cuda.synchronize()
+    M = eng.trans[9].reshape(3, 3).contiguous()
+    ref = hip.dev.aer_obs(eng.x_filter[1], eng.P_filter[1], M, consts).reshape(-1)
+    assert hip.torch.equal(send[:4 * m], ref)
+    st = hip.dev.reward_stats(eng.metrics[1], eng.status, m, 1)[0]
+    assert hip.torch.equal(send[4 * m:4 * m + 6], st[:6])
+    o = oracle.aer_obs(eng.x_filter[1].cpu().numpy(), eng.P_filter[1].cpu().numpy(), c2t()[9], g["obs_lla"], g["obs_itrs"])
+    np.testing.assert_allclose(send[:4 * m].cpu().numpy(), o, rtol=1e-12, atol=1e-12)

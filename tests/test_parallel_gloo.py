@@ -26,13 +26,15 @@ class OracleLocalStepper:
         self.tick = 0
         self.Wm, self.Wc, self.scale = orc.merwe_weights(1e-4, 2.0, -3)
 
-    def step(self, a):
+    def step(self, a, obs_out=None, stats_out=None):
         self.tick += 1
         ep = self.ep
         zn = ep["z_noise"][self.tick, self.lo + a] if a >= 0 else np.zeros(3)
         r = self.o.env_step(self.xt, self.x, self.P, self.status, 20.0, ep["Q"], ep["R"], self.Wm, self.Wc, self.scale, a,
                             self.c2t[self.tick], ep["obs_lla"], ep["obs_itrs"], -np.pi / 2, zn)
         self.xt, self.x, self.P, self.met = r["x_true"], r["x"], r["P"], r["metrics"]
+        if obs_out is not None:
+            self.pack_into(obs_out, stats_out)
 
     def pack_into(self, obs_out, stats_out):
         ep = self.ep
@@ -61,7 +63,7 @@ def _worker(rank, world, port, q):
     outs = []
     for i in range(1, 6):
         a = [3, 12, 18, 0, 9][i - 1]
-        sh.step(a, async_op=(i % 2 == 0))
+        sh.step(a)
         sh.wait()
         outs.append((sh.global_obs().numpy().copy(), sh.global_stats().copy()))
     if rank == 0:
