@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SSA_ABI_VERSION 5
+#define SSA_ABI_VERSION 6
 
 /* error codes */
 #define SSA_OK 0
@@ -112,9 +112,10 @@ typedef struct ssa_step_params {
     const double *trans;       /* [n_time][3][3] GCRS->ITRS matrices (trans_matrix, :137) */
     const int32_t *env_time;   /* [E] time index i of this step per env (after the increment of :259) */
     const int32_t *actions;    /* [E] object chosen per env, < 0 = no update */
-    const double *z_noise;     /* measurement noise; element (e, i, a) at
-                                  z_noise + e*zn_stride_env + i*zn_stride_time + a*3   (:219-221) */
-    int64_t zn_stride_env, zn_stride_time;
+    const double *z_noise;     /* measurement noise [3] of (env e, time i, object a) at
+                                  z_noise + e*zn_stride_env + i*zn_stride_time + a*zn_stride_obj   (:219-221);
+                                  the reference layout z_noise[n][m][3] has strides (0, 3m, 3) */
+    int64_t zn_stride_env, zn_stride_time, zn_stride_obj;
     int32_t n_time;            /* rows in `trans` / time rows of `z_noise` (index = i % n_time) */
     uint32_t launch_mask;      /* 0 = everything; diagnostic: 1 common-path kernel, 2 post kernel, 4 final */
     double *stats;             /* [E][SSA_STAT_STRIDE] reward statistics of this step (O3), may be NULL */
@@ -168,6 +169,23 @@ int ssa_observe_f64(const double *x_true, const double *x, const double *P, doub
 /* O4  aer_obs(): out[n][4] = hx(x_filter), trace(P); NaN/inf -> 0.001 (ssa_tasker_simple_2.py:834). */
 int ssa_aer_obs_f64(const double *x, const double *P, const double *M, const ssa_consts *c_host, double *out,
                     int64_t n, void *stream);
+
+/* ------------------------------------------------ device-side agent primitives
+ * Per-object scores the reference's heuristic agents compute in Python loops (agents.py:7-81):
+ *   scores[0][j] = trace(P_cur[j])                        agent_naive_greedy / agent_visible_greedy
+ *   scores[1][j] = log(det P_cur[j] / det P_prev[j])      agent_shannon        (NaN if either det <= 0)
+ *   scores[2][j] = |x_cur[j][:3] - x_true[j][:3]|         agent_pos_error_greedy
+ *   scores[3][j] = |x_cur[j][3:] - x_true[j][3:]|         agent_vel_error_greedy
+ *   mask[j]      = elevation(x_true[j]) >= obs_limit      visible_objects()    (:410-425)
+ * P_prev may be NULL (scores[1] = NaN). */
+int ssa_agent_scores_f64(const double *x_true, const double *x_cur, const double *P_cur, const double *P_prev,
+                         const double *M, const ssa_consts *c_host, double *scores, uint8_t *mask, int64_t n,
+                         void *stream);
+/* np.argmax(score[mask]) mapped back to object indices: out[0] = index of the first maximum of `score`
+ * over entries with mask != 0 (mask may be NULL = all), or -1 when no entry is selected / n == 0;
+ * NaN entries are skipped (the reference's agents run under np.errstate and np.argmax would return a
+ * NaN's index; skipping is the documented deviation).  out[1] = the maximum (as double bits). */
+int ssa_masked_argmax_f64(const double *score, const uint8_t *mask, int64_t n, int64_t *out, void *stream);
 
 /* library identification */
 int ssa_abi_version(void);

@@ -29,14 +29,14 @@ class ssa_step_params(C.Structure):
         ("x_true_in", c_dp), ("x_true_out", c_dp), ("x_in", c_dp), ("x_out", c_dp),
         ("P_in", c_dp), ("P_out", c_dp), ("status", c_dp), ("obs", c_dp), ("metrics", c_dp),
         ("upd", c_dp), ("trans", c_dp), ("env_time", c_dp), ("actions", c_dp), ("z_noise", c_dp),
-        ("zn_stride_env", C.c_int64), ("zn_stride_time", C.c_int64),
+        ("zn_stride_env", C.c_int64), ("zn_stride_time", C.c_int64), ("zn_stride_obj", C.c_int64),
         ("n_time", C.c_int32), ("launch_mask", C.c_uint32), ("stats", c_dp), ("work", c_dp), ("stat_ws", c_dp),
         ("aer_out", c_dp),
     ]
 
 
 # constants of include/ssa_hip.h
-ABI_VERSION = 5
+ABI_VERSION = 6
 ST_OK, ST_PREDICT_NAN, ST_PREDICT_LINALG, ST_UPDATE_NAN, ST_UPDATE_LINALG = range(5)
 OBS_AER, OBS_XYZ = 0, 1
 PROP_ELEMENTS, PROP_FG = 0, 1
@@ -61,6 +61,8 @@ SIGNATURES = {
     "ssa_residual_z_aer_f64": (C.c_int, [c_dp, c_dp, c_dp, C.c_int64, c_dp]),
     "ssa_visible_mask_f64": (C.c_int, [c_dp, c_dp, C.POINTER(ssa_consts), c_dp, c_dp, C.c_int64, c_dp]),
     "ssa_observe_f64": (C.c_int, [c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int64, c_dp]),
+    "ssa_agent_scores_f64": (C.c_int, [c_dp, c_dp, c_dp, c_dp, c_dp, C.POINTER(ssa_consts), c_dp, c_dp, C.c_int64, c_dp]),
+    "ssa_masked_argmax_f64": (C.c_int, [c_dp, c_dp, C.c_int64, c_dp, c_dp]),
     "ssa_aer_obs_f64": (C.c_int, [c_dp, c_dp, c_dp, C.POINTER(ssa_consts), c_dp, C.c_int64, c_dp]),
 }
 

@@ -691,7 +691,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                 {
                     double zin[3];
                     if (l == 13) {
-                        const double* zn = p.z_noise + (int64_t)e * p.zn_stride_env + (int64_t)tmod * p.zn_stride_time + (int64_t)act * 3;
+                        const double* zn = p.z_noise + (int64_t)e * p.zn_stride_env + (int64_t)tmod * p.zn_stride_time + (int64_t)act * p.zn_stride_obj;
 #pragma unroll
                         for (int c = 0; c < 3; ++c) zin[c] = z[c] + zn[c];
                     } else {
@@ -1179,6 +1179,97 @@ __global__ void aer_obs_kernel(const double* __restrict__ x, const double* __res
     for (int c = 0; c < 4; ++c) out[i * 4 + c] = (fabs(v[c]) <= 1.79769313486231570e308) ? v[c] : 0.001;
 }
 
+// agents.py score arrays + visibility in one pass (one lane per object)
+__global__ void agent_scores_kernel(const double* __restrict__ xt, const double* __restrict__ x, const double* __restrict__ Pc,
+                                    const double* __restrict__ Pp, const double* __restrict__ M, GeoK g,
+                                    double* __restrict__ scores, uint8_t* __restrict__ mask, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double A[21], U[21];
+    double tr = 0.0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c) A[tri(r, c)] = Pc[i * 36 + r * 6 + c];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) tr += A[tri(c, c)];
+    // log det through the (plain) Cholesky factor: det > 0 for the covariances the filter keeps; anything
+    // else gives NaN, which ssa_masked_argmax_f64 skips
+    double ld_c = __builtin_nan(""), ld_p = __builtin_nan("");
+    if (chol6_upper(A, 0.0, U)) {
+        ld_c = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) ld_c += 2.0 * log(U[tri(c, c)]);
+    }
+    if (Pp) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = r; c < 6; ++c) A[tri(r, c)] = Pp[i * 36 + r * 6 + c];
+        if (chol6_upper(A, 0.0, U)) {
+            ld_p = 0.0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) ld_p += 2.0 * log(U[tri(c, c)]);
+        }
+    }
+    double d[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) d[c] = x[i * 6 + c] - xt[i * 6 + c];
+    scores[i] = tr;
+    scores[n + i] = ld_c - ld_p;
+    scores[2 * n + i] = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    scores[3 * n + i] = sqrt(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+    if (mask) {
+        double Mm[9], xx[3] = {xt[i * 6], xt[i * 6 + 1], xt[i * 6 + 2]}, zz[3];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) Mm[c] = M[c];
+        hx_aer(xx, Mm, g.enu, g.obs, zz);
+        mask[i] = zz[1] >= g.obs_limit ? 1 : 0;
+    }
+}
+// first maximum of score over mask (single block; 8 loads in flight per thread)
+__global__ void __launch_bounds__(1024) masked_argmax_kernel(const double* __restrict__ score, const uint8_t* __restrict__ mask,
+                                                             int64_t n, int64_t* __restrict__ out)
+{
+    const int t = threadIdx.x;
+    double best = 0.0;
+    long long arg = -1;
+    for (int64_t b0 = 0; b0 < n; b0 += 1024 * 8) {
+        double v[8];
+        bool ok[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            int64_t i = b0 + (int64_t)q * 1024 + t;
+            bool in = i < n;
+            v[q] = in ? score[i] : 0.0;
+            ok[q] = in && (mask ? mask[i] != 0 : true);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            int64_t i = b0 + (int64_t)q * 1024 + t;
+            if (ok[q] && v[q] == v[q] && (arg < 0 || v[q] > best)) { best = v[q]; arg = i; }
+        }
+    }
+    __shared__ double sb[1024];
+    __shared__ long long sa[1024];
+    sb[t] = best; sa[t] = arg;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (t < w) {
+            long long a2 = sa[t + w];
+            double b2 = sb[t + w];
+            bool take = a2 >= 0 && (sa[t] < 0 || b2 > sb[t] || (b2 == sb[t] && a2 < sa[t]));
+            if (take) { sb[t] = b2; sa[t] = a2; }
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        out[0] = sa[0];
+        out[1] = __double_as_longlong(sb[0]);
+    }
+}
+
 static GeoK make_geo(const ssa_consts* c)
 {
     GeoK g;
@@ -1348,6 +1439,23 @@ int ssa_aer_obs_f64(const double* x, const double* P, const double* M, const ssa
     if (!x || !P || !M || !c || !out || n < 0) return SSA_E_INVALID;
     if (n == 0) return SSA_OK;
     hipLaunchKernelGGL(aer_obs_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, x, P, M, make_geo(c), out, n);
+    return launch_status();
+}
+
+int ssa_agent_scores_f64(const double* x_true, const double* x_cur, const double* P_cur, const double* P_prev, const double* M,
+                         const ssa_consts* c, double* scores, uint8_t* mask, int64_t n, void* stream)
+{
+    if (n == 0) return SSA_OK;
+    if (!x_true || !x_cur || !P_cur || !scores || !c || n < 0 || (mask && !M)) return SSA_E_INVALID;
+    hipLaunchKernelGGL(agent_scores_kernel, dim3(nblk(n, 64)), dim3(64), 0, (hipStream_t)stream, x_true, x_cur, P_cur, P_prev, M,
+                       make_geo(c), scores, mask, n);
+    return launch_status();
+}
+
+int ssa_masked_argmax_f64(const double* score, const uint8_t* mask, int64_t n, int64_t* out, void* stream)
+{
+    if (!out || n < 0 || (n > 0 && !score)) return SSA_E_INVALID;
+    hipLaunchKernelGGL(masked_argmax_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, score, mask, n, out);
     return launch_status();
 }
 

@@ -26,6 +26,11 @@ def _stream():
 
 
 def as_dev(a, device="cuda", dtype=f64):
+    if not isinstance(a, torch.Tensor):
+        import numpy as np
+        a = np.asarray(a)
+        if not a.flags.writeable or not a.flags.c_contiguous:
+            a = np.array(a, order="C")   # torch refuses read-only / strided numpy views
     return torch.as_tensor(a, dtype=dtype).contiguous().to(device)
 
 
@@ -152,6 +157,29 @@ def reward_stats(metrics, status, n_obj, n_env=1, out=None):
                                         _chk(out, "stats"), ws.data_ptr(), int(n_obj), int(n_env), _stream()),
                "ssa_reward_stats_f64")
     return out
+
+
+def agent_scores(x_true, x_cur, P_cur, P_prev, M, consts, want_mask=True):
+    """agents.py primitives: scores[4, n] (trace P | log det ratio | delta_pos | delta_vel) and the visibility mask."""
+    lib = _lib.load()
+    n = x_cur.shape[0]
+    scores = torch.empty((4, n), dtype=f64, device=x_cur.device)
+    mask = torch.empty(n, dtype=torch.uint8, device=x_cur.device) if want_mask else None
+    _lib.check(lib.ssa_agent_scores_f64(_chk(x_true, "x_true"), _chk(x_cur, "x_cur"), _chk(P_cur, "P_cur"),
+                                        _chk(P_prev, "P_prev") if P_prev is not None else None,
+                                        _chk(M, "M") if want_mask else None, C.byref(consts), _chk(scores, "scores"),
+                                        _chk(mask, "mask", torch.uint8) if want_mask else None, n, _stream()),
+               "ssa_agent_scores_f64")
+    return scores, mask
+
+
+def masked_argmax(score, mask=None):
+    """index of the first maximum of score[mask != 0] (NaN skipped), -1 if nothing is selected."""
+    lib = _lib.load()
+    out = torch.empty(2, dtype=torch.int64, device=score.device)
+    _lib.check(lib.ssa_masked_argmax_f64(_chk(score, "score"), _chk(mask, "mask", torch.uint8) if mask is not None else None,
+                                         score.shape[0], out.data_ptr(), _stream()), "ssa_masked_argmax_f64")
+    return int(out[0].item())
 
 
 def env_step(consts, params):

@@ -26,7 +26,7 @@ f64 = torch.float64
 
 class HotPathEngine:
     def __init__(self, consts, n_obj, n_env, trans, z_noise, history, device_name="cuda",
-                 zn_stride_env=None, zn_stride_time=None):
+                 zn_stride_env=None, zn_stride_time=None, zn_stride_obj=3):
         _lib.load()
         if not torch.cuda.is_available():
             raise _lib.SsaHipError("no GPU visible: the ssa-gym hot path runs on MI355X only (no CPU fallback)")
@@ -60,6 +60,7 @@ class HotPathEngine:
         self._p.env_time = self.env_time0.data_ptr()
         self._p.z_noise = self.z_noise.data_ptr()
         self._p.zn_stride_env, self._p.zn_stride_time = self.zn_stride_env, self.zn_stride_time
+        self._p.zn_stride_obj = int(zn_stride_obj)
         self._p.n_time = self.n_time
         self._lib = _lib.load()
         self._stats_ws = device.stats_workspace(self.E, d)
@@ -88,6 +89,17 @@ class HotPathEngine:
             device.observe(self.x_true[slot, sl], self.x_filter[slot, sl], self.P_filter[slot, sl],
                            obs=self.obs[slot, sl], metrics=self.metrics[slot, e])
         device.reward_stats(self.metrics[slot], self.status, self.m, self.E, out=self.stats[slot])
+
+    def load_env_state(self, slot, e, x_true, x_filter, P_filter):
+        """reset() of ONE environment of a vectorised batch: overwrite its slice of `slot`."""
+        sl = slice(e * self.m, (e + 1) * self.m)
+        self.x_true[slot, sl].copy_(device.as_dev(np.asarray(x_true).reshape(self.m, 6), self.dev))
+        self.x_filter[slot, sl].copy_(device.as_dev(np.asarray(x_filter).reshape(self.m, 6), self.dev))
+        self.P_filter[slot, sl].copy_(device.as_dev(np.ascontiguousarray(np.broadcast_to(P_filter, (self.m, 6, 6))), self.dev))
+        self.status[sl].zero_()
+        device.observe(self.x_true[slot, sl], self.x_filter[slot, sl], self.P_filter[slot, sl],
+                       obs=self.obs[slot, sl], metrics=self.metrics[slot, e])
+        device.reward_stats(self.metrics[slot, e:e + 1], self.status[sl], self.m, 1, out=self.stats[slot, e:e + 1])
 
     def snapshot(self, slot):
         """device-side copy of a history slot (initial state of an episode)."""

@@ -209,6 +209,8 @@ class SSA_Tasker_Env(Env):
         from .. import engine
         self._engine = engine.HotPathEngine(self._consts, self.m, 1, self.trans_matrix, self._z_noise_dev, self._H)
         e = self._engine
+        import torch
+        self._aer_dev = torch.zeros(self.m * 4, dtype=torch.float64, device="cuda")
         self.x_true = _History(self, e.x_true, self.m, (6,))
         self.x_filter = _History(self, e.x_filter, self.m, (6,))
         self.P_filter = _History(self, e.P_filter, self.m, (6, 6))
@@ -272,7 +274,10 @@ class SSA_Tasker_Env(Env):
         if self.obs_returned == 'flatten':
             return e.obs[slot].cpu().numpy().reshape(-1)
         elif self.obs_returned == 'aer':
-            self.observation = self.aer_obs(np.zeros(self.m * 4) if reset else self.observation)
+            if reset:
+                self.observation = self.aer_obs(np.zeros(self.m * 4))
+            else:
+                self.observation[:] = self._aer_dev.cpu().numpy()
             return self.observation
         return e.obs[slot].cpu().numpy()
 
@@ -288,7 +293,8 @@ class SSA_Tasker_Env(Env):
         self.runtime['step prep'] += s - step_s
         # propagate + predict + update + observations/metrics + statistics: two launches (:265-322)
         e.set_actions([int(a)])
-        e.launch_step((i - 1) % e.H, i % e.H, i)
+        # 'aer' observations come out of the post kernel of the same step (no extra launch)
+        e.launch_step((i - 1) % e.H, i % e.H, i, aer_out=self._aer_dev.data_ptr() if self.obs_returned == 'aer' else 0)
         rec = e.upd[i % e.H, 0].cpu().numpy()
         self._fetch_small(i)
         t_dev = time.time()
@@ -396,6 +402,15 @@ class SSA_Tasker_Env(Env):
         viz = self._mask()
         self.runtime['object_visibility'] += time.time() - s
         return viz
+
+    def agent_scores(self):
+        """device tensors (scores[4, m], mask[m]) for the heuristic agents (ssa_gym_amd.agents)."""
+        from .. import device
+        e = self._engine
+        cur, prev = self.i % e.H, (self.i - 1) % e.H
+        M = e.trans[self.i % e.n_time].reshape(3, 3)
+        P_prev = e.P_filter[prev] if self.i >= 1 else None
+        return device.agent_scores(e.x_true[cur], e.x_filter[cur], e.P_filter[cur], P_prev, M, self._consts)
 
     def aer_obs(self, obs):
         """:834-840 -- [az, el, range, trace(P)] per object, NaN/inf -> 0.001."""

@@ -1,0 +1,159 @@
+"""SSA_Tasker_VecEnv: E independent copies of SSA_Tasker_Env advanced by ONE kernel launch per step
+(BASELINE config 5: "20 000 objects x 64 parallel env instances (RLlib vectorised rollout)").
+
+The reference reaches env-level parallelism with one Python process per env (RLlib `num_workers`,
+RLLib_training.py:40-56).  Here the E environments are one batch of E*m objects in HBM; the step
+kernel takes per-env actions and per-env time indices, so envs that terminated are reset in place
+while the others continue (the usual vector-env auto-reset).  Semantics per env are those of
+SSA_Tasker_Env (same reward / done logic, same RNG draw order for reset, seed = base seed + env index);
+measurement noise is drawn on the device per (env, time step) -- only the object the action selects
+consumes noise in a step (ssa_tasker_simple_2.py:301).
+"""
+import numpy as np
+
+from .. import _lib, host
+from . import dynamics, transformations
+from ._gymshim import np_random, spaces
+
+
+class SSA_Tasker_VecEnv:
+    def __init__(self, config, num_envs, seed=0):
+        import torch
+        from .. import engine
+        self.E, self.m, self.n, self.dt = int(num_envs), config['rso_count'], config['steps'], config['time_step']
+        self.obs_returned, self.reward_type = config['obs_returned'], config['reward_type']
+        self.orbits = config['orbits']
+        self.x_sigma = np.array(config['x_sigma'])
+        self.obs_type = config['obs_type']
+        self.z_sigma = (config['z_sigma'] * np.array([host.arcsec2rad, host.arcsec2rad, 1]) if self.obs_type == 'aer'
+                        else np.asarray(config['z_sigma'], dtype=np.float64))
+        self.P_0 = np.diag(self.x_sigma ** 2) if config['P_0'] is None else np.copy(config['P_0'])
+        R = np.diag(self.z_sigma ** 2) if config['R'] is None else np.copy(config['R'])
+        Q = host.Q_discrete_white_noise(dim=2, dt=self.dt, var=config['q_sigma'] ** 2, block_size=3, order_by_dim=False)
+        ids = [dynamics.kernel_id_of(config[k], r) for k, r in (('hx', 'hx'), ('mean_z', 'mean_z'), ('residual_z', 'residual_z'))]
+        dynamics.kernel_id_of(config['fx'], 'fx'), dynamics.kernel_id_of(config['msqrt'], 'msqrt')
+        model = 'aer' if ids[0] == ('hx', 'aer') else 'xyz'
+        obs_lla = np.array(config['observer']) * [host.deg2rad, host.deg2rad, 1]
+        self._consts = host.make_consts(Q, R, config['alpha'], config['beta'], config['kappa'], self.dt,
+                                        np.radians(config['obs_limit']), obs_lla, obs_type=model,
+                                        propagator=config.get('propagator', 'fg'),
+                                        resample=bool(config.get('resample_sigmas', False)),
+                                        update_interval=config['update_interval'])
+        trans = (np.asarray(config['trans_matrix']) if config.get('trans_matrix') is not None
+                 else transformations.trans_matrix_table(config['t_0'], self.dt, self.n))
+        self._gen = torch.Generator(device="cuda").manual_seed(int(seed))
+        self._zs = torch.as_tensor(self.z_sigma, dtype=torch.float64, device="cuda")
+        z = torch.randn((self.E, self.n, 1, 3), dtype=torch.float64, device="cuda", generator=self._gen) * self._zs
+        self._eng = engine.HotPathEngine(self._consts, self.m, self.E, trans, z, history=2,
+                                         zn_stride_env=self.n * 3, zn_stride_time=3, zn_stride_obj=0)
+        self._rng = [np_random(seed + e)[0] for e in range(self.E)]
+        self.single_action_space = spaces.Discrete(self.m)
+        shp = {'flatten': (self.m * 12,), 'aer': (self.m * 4,)}.get(self.obs_returned, (self.m, 12))
+        self.single_observation_space = spaces.Box(low=np.full(shp, -np.inf), high=np.full(shp, np.inf), dtype=np.float64)
+        self.num_envs = self.E
+        self._aer = torch.zeros((self.E * self.m, 4), dtype=torch.float64, device="cuda")
+        self._time = torch.zeros(self.E, dtype=torch.int32)
+        self.i = np.zeros(self.E, dtype=np.int64)       # per-env step index
+        self.tick = 0
+        self.rewards_sum = np.zeros(self.E)
+        self._argmax_prev = np.zeros(self.E, dtype=np.int64)
+        self.reset()
+
+    # ------------------------------------------------------------------
+    def _draw(self, e):
+        rs, N = self._rng[e], self.orbits.shape[0]
+        xt = np.empty((self.m, 6))
+        noise = np.empty((self.m, 6))
+        for j in range(self.m):   # reset() draw order of the reference (:206-209)
+            xt[j] = self.orbits[rs.randint(low=0, high=N), :]
+            noise[j] = rs.normal(size=6) * self.x_sigma
+        return xt, xt + noise
+
+    def _reset_env(self, e, slot):
+        import torch
+        xt, xf = self._draw(e)
+        self._eng.load_env_state(slot, e, xt, xf, self.P_0)
+        self._eng.z_noise[e].copy_(torch.randn((self.n, 1, 3), dtype=torch.float64, device="cuda", generator=self._gen) * self._zs)
+        self.i[e] = 0
+        self.rewards_sum[e] = 0.0
+
+    def reset(self):
+        slot = self.tick % 2
+        for e in range(self.E):
+            self._reset_env(e, slot)
+        self._refresh_stats(slot)
+        return self._obs(slot, reset=True)
+
+    def _refresh_stats(self, slot):
+        st = self._eng.stats[slot].cpu().numpy()
+        self._argmax_prev = st[:, _lib.STAT_ARGMAX_SPOS].astype(np.int64)
+        return st
+
+    def _obs(self, slot, reset=False):
+        e = self._eng
+        if self.obs_returned == 'flatten':
+            return e.obs[slot].cpu().numpy().reshape(self.E, self.m * 12)
+        if self.obs_returned == 'aer':
+            if reset:
+                from .. import device
+                for k in range(self.E):   # reset-time only
+                    sl = slice(k * self.m, (k + 1) * self.m)
+                    M = e.trans[int(self.i[k]) % e.n_time].reshape(3, 3)
+                    device.aer_obs(e.x_filter[slot, sl], e.P_filter[slot, sl], M, self._consts, out=self._aer[sl])
+            return self._aer.cpu().numpy().reshape(self.E, self.m * 4)
+        return e.obs[slot].cpu().numpy().reshape(self.E, self.m, 12)
+
+    def step(self, actions):
+        import torch
+        actions = np.asarray(actions, dtype=np.int64).reshape(self.E)
+        assert np.all((actions >= 0) & (actions < self.m)), "invalid action"
+        e = self._eng
+        argmax_prev = self._argmax_prev
+        self.i += 1
+        self.tick += 1
+        self._time[:] = torch.as_tensor(self.i.astype(np.int32))
+        e.env_time0.copy_(self._time)
+        e.set_actions(actions)
+        sin, sout = (self.tick - 1) % 2, self.tick % 2
+        e.launch_step(sin, sout, 0, aer_out=self._aer.data_ptr() if self.obs_returned == 'aer' else 0)
+        st = self._refresh_stats(sout)
+        mx = st[:, _lib.STAT_MAX_DPOS]
+        rewards = np.zeros(self.E)
+        dones = np.zeros(self.E, dtype=bool)
+        last = self.i + 1 >= self.n
+        if self.reward_type == 'jones':
+            lost, won = mx > 5e6, mx < 3e4
+            dones = lost | won | last
+            rewards[won & ~lost] = 1.0
+        elif self.reward_type == 'trinary':
+            rewards = (st[:, _lib.STAT_CNT_LT_1E4] + st[:, _lib.STAT_CNT_LT_1E7]) / self.m / 2
+            dones = last.copy()
+        elif self.reward_type == 'shaped':
+            lost, won = mx > 5e6, mx < 3e4
+            hit = actions == argmax_prev
+            rewards = np.where(hit, 1.0 / self.n, -1.0 / self.n)
+            rewards[won] = 1.0 - self.rewards_sum[won]
+            rewards[lost] = 0.0
+            dones = lost | won | last
+        self.rewards_sum += rewards
+        obs = self._obs(sout)
+        infos = [{} for _ in range(self.E)]
+        if dones.any():   # auto-reset in place; the returned observation of a finished env is its new first one
+            for k in np.where(dones)[0]:
+                infos[k]['terminal_observation'] = obs[k].copy()
+                self._reset_env(int(k), sout)
+            self._refresh_stats(sout)
+            obs = self._obs(sout, reset=(self.obs_returned == 'aer'))
+        if self.obs_returned != 'flatten':
+            rewards = np.where(np.isfinite(rewards), rewards, 0.5)
+        return obs, rewards, dones, infos
+
+    # inspection helpers (per env)
+    def P_filter(self, e):
+        return self._eng.P_filter[self.tick % 2, e * self.m:(e + 1) * self.m].cpu().numpy()
+
+    def x_filter(self, e):
+        return self._eng.x_filter[self.tick % 2, e * self.m:(e + 1) * self.m].cpu().numpy()
+
+    def x_true(self, e):
+        return self._eng.x_true[self.tick % 2, e * self.m:(e + 1) * self.m].cpu().numpy()
