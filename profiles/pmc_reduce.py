@@ -7,7 +7,7 @@ def per_kernel(d, counter):
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] != counter: continue
         k = r['Kernel_Name']
-        key = 'step' if 'step_kernel' in k else 'propagate' if 'propagate_kernel' in k else 'observe' if 'observe_kernel' in k else None
+        key = 'step' if 'step_fast_kernel' in k else 'propagate' if 'propagate_kernel' in k else 'observe' if 'observe_kernel' in k else None
         if key: acc.setdefault(key, []).append(float(r['Counter_Value']))
     return acc
 fe, wr = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'WRITE_SIZE')

@@ -277,54 +277,48 @@ SSA_DEV bool kepler_universal(const double* x, double tof, double r0, double alp
     return done && (rad > 0.0);
 }
 
-// Strong-elliptic AND strong-hyperbolic branches of farnocchia() in Lagrange f,g form.
+// Strong-elliptic and strong-hyperbolic branches of farnocchia() in Lagrange f,g form.
 //   elliptic   (ecc < 0.99, farnocchia.py:871-875, 946-954):  x = E - E0,
 //       x - (e cos E0) sin x + (e sin E0)(1 - cos x) = n tof
 //   hyperbolic (ecc > 1.01, farnocchia.py:915-919, 1000-1004): x = F - F0,
 //       (e cosh F0) sinh x - x + (e sinh F0)(cosh x - 1) = n tof
 // with e cos E0 = 1 - r0/a, e sin E0 = r.v/sqrt(mu a) (and their hyperbolic twins with |a|); the
 // state follows from r' = f r + g v, v' = f' r + g' v.  The near-parabolic band in between goes
-// through kepler_universal.  Returns false -- the caller then takes the complete restatement -- only
-// for NaN / degenerate input or when a safeguarded Newton iteration does not converge.
-SSA_DEV bool kepler_fg_fast(const double* x, double tof, double* out)
+// through kepler_universal.  `ok` is false only for NaN / degenerate input or when a safeguarded
+// Newton iteration does not converge (the caller then takes the complete restatement).
+//
+// kepler_fg_core<HYP> is the shared body; the elliptic instance is inlined into the kernels, the
+// hyperbolic + band cases live in ONE small out-of-line function (arguments by value) so that the
+// common path keeps its register budget.
+template <bool HYP>
+SSA_DEV bool kepler_fg_core(const double* x, double tof, double r0, double inv_r0, double alpha, double rv, double* out)
 {
     const double* r = x;
     const double* v = x + 3;
-    const double sqrt_mu = sqrt(MU), inv_sqrt_mu = 1.0 / sqrt(MU), inv_mu = 1.0 / MU;
-    double rr = dot3(r, r), vv = dot3(v, v), rv = dot3(r, v);
-    double r0 = sqrt(rr);
-    double inv_r0 = 1.0 / r0;
-    double alpha = 2.0 * inv_r0 - vv * inv_mu;  // 1/a  (< 0: hyperbola)
-    const bool hyper = alpha < 0.0;
+    const double sqrt_mu = sqrt(MU), inv_sqrt_mu = 1.0 / sqrt(MU);
     double beta = fabs(alpha);
     double sb = sqrt(beta);
     double q0 = r0 * beta;                      // r0/|a|
-    double ec = hyper ? 1.0 + q0 : 1.0 - q0;    // e cosh F0 | e cos E0
+    double ec = HYP ? 1.0 + q0 : 1.0 - q0;      // e cosh F0 | e cos E0
     double es = rv * sb * inv_sqrt_mu;          // e sinh F0 | e sin E0
-    double ecc2 = hyper ? ec * ec - es * es : ec * ec + es * es;
-    bool ok = hyper ? (ecc2 > 1.01 * 1.01) : (ecc2 < 0.99 * 0.99);
-    const bool band = !ok && (ecc2 >= 0.99 * 0.99) && (ecc2 <= 1.01 * 1.01) && (r0 > 0.0);
-    ok = ok && (beta > 0.0) && (r0 > 0.0);
-    // keep out-of-domain lanes numerically harmless (their result is discarded)
-    if (!ok) { beta = 1e-7; sb = sqrt(beta); q0 = 1.0; ec = hyper ? 2.0 : 0.0; es = 0.0; }
     double n = sqrt_mu * beta * sb;             // mean motion
     double Mt = n * tof;
     double Mr = Mt;
-    if (!hyper) {
+    if (!HYP) {
         double k = rint(Mt * (1.0 / TWO_PI));
         Mr = fma(-k, TWO_PI, Mt);               // in [-pi, pi]
     }
     double inv_q0 = 1.0 / q0;
     double x1 = Mr * inv_q0;                    // first order:  G ~ q0 x
     double xs = x1 - 0.5 * es * x1 * x1 * inv_q0;
-    double lo = hyper ? -1e300 : Mr - 2.0, hi = hyper ? 1e300 : Mr + 2.0;
-    double xk = (fabs(Mr) < 0.5 && xs > lo && xs < hi) ? xs : (hyper ? asinh(Mr / ec) : Mr - es);
+    double lo = HYP ? -1e300 : Mr - 2.0, hi = HYP ? 1e300 : Mr + 2.0;
+    double xk = (fabs(Mr) < 0.5 && xs > lo && xs < hi) ? xs : (HYP ? asinh(Mr / ec) : Mr - es);
     double s, c;                                // sin x, cos x   |   sinh x, cosh x - 1
-    if (hyper) sinh_coshm1(xk, s, c); else sincos(xk, &s, &c);
+    if (HYP) sinh_coshm1(xk, s, c); else sincos(xk, &s, &c);
     bool done = false;
     for (int it = 0; it < 60; ++it) {
         double G, dG;
-        if (hyper) {
+        if (HYP) {
             G = (ec * s - xk + es * c) - Mr;
             dG = ec * (c + 1.0) - 1.0 + es * s;
         } else {
@@ -333,23 +327,21 @@ SSA_DEV bool kepler_fg_fast(const double* x, double tof, double* out)
         }
         if (G > 0.0) hi = xk; else lo = xk;
         double dx = -G / dG;
-        if (hyper) dx = fmin(fmax(dx, -1.0), 1.0);   // sinh/cosh grow fast: bounded steps
+        if (HYP) dx = fmin(fmax(dx, -1.0), 1.0);   // sinh/cosh grow fast: bounded steps
         double xn = xk + dx;
         if (!(xn >= lo && xn <= hi)) xn = 0.5 * (lo + hi);
         dx = xn - xk;
         if (!done) {
-            if (hyper) sinh_coshm1(xn, s, c);
+            if (HYP) sinh_coshm1(xn, s, c);
             else if (fabs(dx) <= 0.02) rot_small(dx, s, c);
             else sincos(xn, &s, &c);
             xk = xn;
             done = fabs(dx) < 1e-10;
         }
-        if (__all(done || !ok)) break;
+        if (__all(done)) break;
     }
-    ok = ok && done;                            // non-convergence -> complete kernel (NaN semantics there)
-    if (band) return kepler_universal(x, tof, r0, alpha, rv, out);
-    double omc = hyper ? c : 1.0 - c;           // cosh x - 1 | 1 - cos x
-    double rho = hyper ? (ec * (c + 1.0) - 1.0 + es * s) : (1.0 - (ec * c - es * s));   // r/|a|
+    double omc = HYP ? c : 1.0 - c;             // cosh x - 1 | 1 - cos x
+    double rho = HYP ? (ec * (c + 1.0) - 1.0 + es * s) : (1.0 - (ec * c - es * s));   // r/|a|
     double inv_rho = 1.0 / rho;
     double f = 1.0 - inv_q0 * omc;
     double g = (q0 * s + es * omc) / n;
@@ -361,6 +353,42 @@ SSA_DEV bool kepler_fg_fast(const double* x, double tof, double* out)
     out[3] = fd * r[0] + gd * v[0];
     out[4] = fd * r[1] + gd * v[1];
     out[5] = fd * r[2] + gd * v[2];
+    return done;
+}
+
+struct Vec7 { double v[7]; };   // propagated state + ok flag (1.0 / 0.0)
+// hyperbolic f,g or universal-variable band solve for one state (out of line, by value)
+__device__ __noinline__ Vec7 kepler_nonelliptic_v(Vec6 x, double tof, double r0, double alpha, double rv, int band);
+
+SSA_DEV bool kepler_fg_fast(const double* x, double tof, double* out)
+{
+    const double inv_sqrt_mu = 1.0 / sqrt(MU), inv_mu = 1.0 / MU;
+    const double rr = dot3(x, x), vv = dot3(x + 3, x + 3), rv = dot3(x, x + 3);
+    const double r0 = sqrt(rr);
+    const double inv_r0 = 1.0 / r0;
+    const double alpha = 2.0 * inv_r0 - vv * inv_mu;  // 1/a  (< 0: hyperbola)
+    const bool hyper = alpha < 0.0;
+    const double beta = fabs(alpha), q0 = r0 * beta;
+    const double ec = hyper ? 1.0 + q0 : 1.0 - q0;
+    const double es = rv * sqrt(beta) * inv_sqrt_mu;
+    const double ecc2 = hyper ? ec * ec - es * es : ec * ec + es * es;
+    const bool sane = (r0 > 0.0) && (ecc2 == ecc2) && (beta <= 1.79769313486231570e308);
+    const bool ell = sane && !hyper && (ecc2 < 0.99 * 0.99) && (beta > 0.0);
+    const bool hyp = sane && hyper && (ecc2 > 1.01 * 1.01);
+    const bool band = sane && !ell && !hyp && (ecc2 >= 0.99 * 0.99) && (ecc2 <= 1.01 * 1.01);
+    bool ok = false;
+    if (__any(!ell)) {   // whole-wave branch: the call is skipped when every lane is strong-elliptic
+        if (hyp || band) {
+            Vec6 xi;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) xi.v[i] = x[i];
+            Vec7 o = kepler_nonelliptic_v(xi, tof, r0, alpha, rv, band ? 1 : 0);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) out[i] = o.v[i];
+            ok = o.v[6] != 0.0;
+        }
+    }
+    if (ell) ok = kepler_fg_core<false>(x, tof, r0, inv_r0, alpha, rv, out);
     return ok;
 }
 
