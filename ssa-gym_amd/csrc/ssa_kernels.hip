@@ -457,17 +457,6 @@ SSA_DEV StatAcc stat_wave_reduce(StatAcc a)
 // workgroup barrier.)
 SSA_DEV void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// 1/sqrt(v) to double precision from the hardware estimate + two Newton steps.
-SSA_DEV double rsqrt_nr(double v)
-{
-    double y = __builtin_amdgcn_rsq(v);
-    double e = fma(-v * y, y, 1.0);
-    y = fma(0.5 * y, e, y);
-    e = fma(-v * y, y, 1.0);
-    y = fma(0.5 * y, e, y);
-    return y;
-}
-
 // U2 (common case): upper Cholesky of scale*P for the row's object, lane-distributed through LDS:
 // lane c owns column c; step j forms the pivot and row j (LAPACK dpotf2('U') order).  Ten VGPRs
 // instead of the 84 of a per-lane register factorisation.  Returns false (row-uniform) when a
@@ -561,7 +550,12 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     bool need_full = false;   // FAST only: row-uniform "this object needs the complete kernel"
 
     // ---- U1/U2: sigma points
+#if defined(SSA_ABLATE) && (SSA_ABLATE & 2)
+    const int rung = -1;
+    if (l < 6) for (int c = 0; c < 6; ++c) t.U[g * 36 + l * 6 + c] = 1e-3 * t.P[g * 36 + l * 6 + c];
+#else
     const int rung = robust_chol_row_lds(t, C.scale, g, l);
+#endif
     wave_lds_sync();
     const bool chol_fail = (rung == 16);
     const bool is_sigma = (l <= 12);
@@ -581,7 +575,12 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     // branch through the out-of-line complete restatement
     double o[6];
     {
+#if defined(SSA_ABLATE) && (SSA_ABLATE & 1)
+        for (int c = 0; c < 6; ++c) o[c] = s[c] + 1e-3 * C.dt * s[(c + 3) % 6];
+        const bool kep_ok = true;
+#else
         const bool kep_ok = kepler_step_fast<PROP>(s, C.dt, o);
+#endif
         if (FAST) {
             need_full = need_full || (((__ballot(!kep_ok && l < 14) >> (g * 16)) & 0xFFFFull) != 0);
         } else if (!kep_ok) {
@@ -617,7 +616,9 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         if (l == 13) t.T[g * 6 + c] = o[c];   // x_true[i]
     }
     wave_lds_sync();
+#if !(defined(SSA_ABLATE) && (SSA_ABLATE & 4))
     covariance_rows(t, C, g, l);
+#endif
     wave_lds_sync();
 
     int st_new = st_in;
