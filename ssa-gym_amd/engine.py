@@ -118,7 +118,7 @@ class HotPathEngine:
         self.status.zero_()
 
     # ------------------------------------------------------------------ one step
-    def launch_step(self, slot_in, slot_out, time_offset, actions_ptr=None, stream=None, aer_out=0, stats_out=0):
+    def launch_step(self, slot_in, slot_out, time_offset, actions_ptr=None, stream=None, aer_out=0, stats_out=0, upd_out=0):
         """enqueue the step (common-path kernel, post kernel, final kernel); asynchronous, no host sync."""
         p = self._p
         p.time_offset = int(time_offset)
@@ -127,7 +127,7 @@ class HotPathEngine:
         p.P_in, p.P_out = self._bP + slot_in * self._sP, self._bP + slot_out * self._sP
         p.obs = self._bo + slot_out * self._so
         p.metrics = self._bm + slot_out * self._sm
-        p.upd = self._bu + slot_out * self._su
+        p.upd = upd_out if upd_out else self._bu + slot_out * self._su
         p.actions = self.actions.data_ptr() if actions_ptr is None else actions_ptr
         p.stats = stats_out if stats_out else self._bs + slot_out * self._ss   # e.g. straight into a send buffer
         p.aer_out = aer_out

@@ -211,6 +211,14 @@ class SSA_Tasker_Env(Env):
         e = self._engine
         import torch
         self._aer_dev = torch.zeros(self.m * 4, dtype=torch.float64, device="cuda")
+        # host-mapped mailboxes (pinned memory is addressable from the GPU): the kernels read the action
+        # from / write statistics and the update record to host memory directly, so a step needs one
+        # stream synchronisation and one observation copy instead of four blocking transfers
+        self._act_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._stats_host = torch.zeros(_lib.STAT_STRIDE, dtype=torch.float64).pin_memory()
+        self._upd_host = torch.zeros(_lib.UPD_STRIDE, dtype=torch.float64).pin_memory()
+        nobs = self.m * (4 if self.obs_returned == 'aer' else 12)
+        self._obs_host = torch.zeros(nobs, dtype=torch.float64).pin_memory()
         self.x_true = _History(self, e.x_true, self.m, (6,))
         self.x_filter = _History(self, e.x_filter, self.m, (6,))
         self.P_filter = _History(self, e.P_filter, self.m, (6, 6))
@@ -292,11 +300,21 @@ class SSA_Tasker_Env(Env):
         s = time.time()
         self.runtime['step prep'] += s - step_s
         # propagate + predict + update + observations/metrics + statistics: two launches (:265-322)
-        e.set_actions([int(a)])
+        import torch
+        self._act_host[0] = int(a)
         # 'aer' observations come out of the post kernel of the same step (no extra launch)
-        e.launch_step((i - 1) % e.H, i % e.H, i, aer_out=self._aer_dev.data_ptr() if self.obs_returned == 'aer' else 0)
-        rec = e.upd[i % e.H, 0].cpu().numpy()
-        self._fetch_small(i)
+        e.launch_step((i - 1) % e.H, i % e.H, i, actions_ptr=self._act_host.data_ptr(),
+                      aer_out=self._aer_dev.data_ptr() if self.obs_returned == 'aer' else 0,
+                      stats_out=self._stats_host.data_ptr(), upd_out=self._upd_host.data_ptr())
+        src = self._aer_dev if self.obs_returned == 'aer' else e.obs[i % e.H].reshape(-1)
+        big = src.numel() * 8 > (1 << 19)   # large vectors: one pageable D2H beats pinned copy + host memcpy
+        if not big:
+            self._obs_host.copy_(src, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        obs_np = src.cpu().numpy() if big else self._obs_host.numpy().copy()
+        rec = self._upd_host.numpy()
+        self._stats = self._stats_host.numpy().copy()
+        self._argmax_sigma = int(self._stats[_lib.STAT_ARGMAX_SPOS])
         t_dev = time.time()
         self.runtime['perform predictions'] += t_dev - s
         # update bookkeeping (:292-315)
@@ -339,7 +357,12 @@ class SSA_Tasker_Env(Env):
                 self.rewards[i] = -1 / self.n
         if i + 1 >= self.n:
             done = True
-        obs = self._obs_out()
+        obs = obs_np
+        if self.obs_returned == 'aer':
+            self.observation[:] = obs
+            obs = self.observation
+        elif self.obs_returned != 'flatten':
+            obs = obs.reshape(self.m, 12)
         e_t = time.time()
         self.runtime['Observations and Reward'] += e_t - t_dev
         self.runtime['step'] += e_t - step_s
