@@ -85,7 +85,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--objects", type=int, default=20000, help="objects per GPU")
-    ap.add_argument("--propagator", default="fg", choices=["fg", "elements"])
+    ap.add_argument("--propagator", default="fg", choices=["fg", "elements", "j2"],
+                    help="fg / elements: two-body Farnocchia (parity-checked); j2: J2+RK4 extension (no reference counterpart)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -215,7 +216,7 @@ def main():
                 traffic = json.load(open(tj)).get("%s_%d" % (args.propagator, m))
             except Exception:  # noqa: BLE001
                 traffic = None
-        roof = {"bound": "hbm", "kernel": "ssa::step_fast_kernel<%d>" % (1 if args.propagator == "fg" else 0),
+        roof = {"bound": "hbm", "kernel": "ssa::step_fast_kernel<%d>" % {"elements": 0, "fg": 1, "j2": 2}[args.propagator],
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "kernel_ms": round(kern_ms, 5), "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": nl,
@@ -233,9 +234,10 @@ def main():
             "unit": "env-steps/s (20 000-object UKF+propagate steps, summed over GPUs)",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "ssa_tasker_simple-v2 hot path: %d objects/GPU x %d GPU, two-body Farnocchia (%s) + "
+            "config": {"workload": "ssa_tasker_simple-v2 hot path: %d objects/GPU x %d GPU, %s + "
                                    "UKF predict (13 sigma points) + 1 az-el-range update/step%s" %
-                                   (m, world, args.propagator,
+                                   (m, world, {"fg": "two-body Farnocchia (fg)", "elements": "two-body Farnocchia (elements)",
+                                               "j2": "two-body + J2 RK4 propagator (EXTENSION, no reference counterpart; 4 sub-steps)"}[args.propagator],
                                     ", sharded env with RCCL all-gather of (az,el,range,trP) obs + reward stats" if use_dist else ""),
                        "objects_per_gpu": m, "objects_total": m * world, "alpha": 1e-4, "dt_s": 20.0,
                        "propagator": args.propagator, "parallelism": "object-shard x%d" % world},

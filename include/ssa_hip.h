@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SSA_ABI_VERSION 6
+#define SSA_ABI_VERSION 7
 
 /* error codes */
 #define SSA_OK 0
@@ -53,8 +53,10 @@ extern "C" {
 
 /* two-body propagator variant; both evaluate envs/farnocchia.py:1010 farnocchia() */
 #define SSA_PROP_ELEMENTS 0 /* rv2coe -> delta_t_from_nu -> nu_from_delta_t -> coe2rv, operation by operation */
-#define SSA_PROP_FG 1       /* strong-elliptic branch reduced algebraically to Lagrange f,g in the
-                               eccentric-anomaly difference; every other branch falls back to ELEMENTS */
+#define SSA_PROP_FG 1       /* the same branches reduced algebraically to Lagrange f,g (elliptic / hyperbolic
+                               anomaly difference; universal variables in the near-parabolic band) */
+#define SSA_PROP_J2_RK4 2   /* EXTENSION without reference counterpart: two-body + J2 zonal
+                               acceleration, classical RK4 with ssa_consts.rk4_substeps sub-steps per dt */
 
 /* flags of ssa_step_params.flags */
 #define SSA_FLAG_RESAMPLE 1u /* redraw sigma points from the prior before update() (filterpy-master predict()) */
@@ -94,6 +96,9 @@ typedef struct ssa_consts {
     int32_t propagator; /* SSA_PROP_* */
     uint32_t flags;     /* SSA_FLAG_* */
     int32_t update_interval; /* env_config['update_interval'] (:292) */
+    double j2, r_eq;    /* SSA_PROP_J2_RK4: zonal coefficient and equatorial radius [m] (j2 = 0 -> two-body) */
+    int32_t rk4_substeps; /* SSA_PROP_J2_RK4: RK4 steps per dt (>= 1) */
+    int32_t reserved0;
 } ssa_consts;
 
 /* One env step for n_env independent environments of n_obj objects each
@@ -145,6 +150,9 @@ int64_t ssa_reward_stats_workspace_bytes(int32_t n_env);
 /* ----------------------------------------------------- single operators (rows of SURVEY 8a) */
 /* P1-P5  fx_xyz_farnocchia(x, dt) for n states (farnocchia.py:1054). */
 int ssa_propagate_f64(const double *x_in, double *x_out, int64_t n, double dt, int32_t propagator, void *stream);
+/* the J2 + RK4 extension propagator on its own (SSA_PROP_J2_RK4) */
+int ssa_propagate_j2_f64(const double *x_in, double *x_out, int64_t n, double dt, double j2, double r_eq,
+                         int32_t substeps, void *stream);
 /* P2-P4 diagnostics: coe[n][8] = p, ecc, inc, raan, argp, nu0, delta_t0, nu(dt)  (farnocchia.py:165,847,925). */
 int ssa_kepler_elements_f64(const double *x_in, double *coe, int64_t n, double dt, void *stream);
 /* U2  robust_cholesky(A) for n 6x6 matrices: U upper (zeros below), rung[n] = -1 (no jitter),

@@ -20,6 +20,7 @@ class ssa_consts(C.Structure):
         ("enu", C.c_double * 9), ("obs_itrs", C.c_double * 3),
         ("obs_type", C.c_int32), ("propagator", C.c_int32), ("flags", C.c_uint32),
         ("update_interval", C.c_int32),
+        ("j2", C.c_double), ("r_eq", C.c_double), ("rk4_substeps", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -36,10 +37,10 @@ class ssa_step_params(C.Structure):
 
 
 # constants of include/ssa_hip.h
-ABI_VERSION = 6
+ABI_VERSION = 7
 ST_OK, ST_PREDICT_NAN, ST_PREDICT_LINALG, ST_UPDATE_NAN, ST_UPDATE_LINALG = range(5)
 OBS_AER, OBS_XYZ = 0, 1
-PROP_ELEMENTS, PROP_FG = 0, 1
+PROP_ELEMENTS, PROP_FG, PROP_J2_RK4 = 0, 1, 2
 FLAG_RESAMPLE = 1
 UPD_STRIDE, UPD_OBS_TAKEN, UPD_Z_TRUE, UPD_Y, UPD_S, UPD_SIGMAS_H, UPD_VISIBLE, UPD_ACTION = 64, 0, 1, 4, 7, 16, 55, 56
 STAT_STRIDE, STAT_MAX_DPOS, STAT_CNT_LT_1E4, STAT_CNT_LT_1E7, STAT_ARGMAX_SPOS, STAT_N_FAILED, STAT_MAX_SPOS = 8, 0, 1, 2, 3, 4, 5
@@ -53,6 +54,7 @@ SIGNATURES = {
     "ssa_reward_stats_f64": (C.c_int, [c_dp, c_dp, c_dp, c_dp, C.c_int64, C.c_int32, c_dp]),
     "ssa_reward_stats_workspace_bytes": (C.c_int64, [C.c_int32]),
     "ssa_propagate_f64": (C.c_int, [c_dp, c_dp, C.c_int64, C.c_double, C.c_int32, c_dp]),
+    "ssa_propagate_j2_f64": (C.c_int, [c_dp, c_dp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int32, c_dp]),
     "ssa_kepler_elements_f64": (C.c_int, [c_dp, c_dp, C.c_int64, C.c_double, c_dp]),
     "ssa_robust_cholesky6_f64": (C.c_int, [c_dp, c_dp, c_dp, C.c_int64, c_dp]),
     "ssa_sigma_points_f64": (C.c_int, [c_dp, c_dp, C.c_double, c_dp, c_dp, C.c_int64, c_dp]),

@@ -579,11 +579,17 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         for (int c = 0; c < 6; ++c) o[c] = s[c] + 1e-3 * C.dt * s[(c + 3) % 6];
         const bool kep_ok = true;
 #else
-        const bool kep_ok = kepler_step_fast<PROP>(s, C.dt, o);
+        bool kep_ok;
+        if (PROP == 2) {
+            const J2Params jq = {C.j2, C.r_eq, C.rk4_substeps};
+            kep_ok = propagate_j2_rk4(s, C.dt, jq, o);
+        } else {
+            kep_ok = kepler_step_fast<PROP == 2 ? 1 : PROP>(s, C.dt, o);
+        }
 #endif
         if (FAST) {
             need_full = need_full || (((__ballot(!kep_ok && l < 14) >> (g * 16)) & 0xFFFFull) != 0);
-        } else if (!kep_ok) {
+        } else if (!kep_ok && PROP != 2) {
             Vec6 si;
 #pragma unroll
             for (int c = 0; c < 6; ++c) si.v[c] = s[c];
@@ -1025,6 +1031,17 @@ __global__ void propagate_kernel(const double* __restrict__ xin, double* __restr
         for (int c = 0; c < 6; ++c) xout[i * 6 + c] = o[c];
     }
 }
+__global__ void propagate_j2_kernel(const double* __restrict__ xin, double* __restrict__ xout, int64_t n, double dt, J2Params q)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double x[6], o[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) x[c] = xin[i * 6 + c];
+    propagate_j2_rk4(x, dt, q, o);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) xout[i * 6 + c] = o[c];
+}
 __global__ void elements_kernel(const double* __restrict__ xin, double* __restrict__ coe, int64_t n, double dt)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1330,15 +1347,18 @@ int ssa_env_step_f64(const ssa_consts* c, const ssa_step_params* p, void* stream
     StatAcc* parts = (StatAcc*)p->stat_ws;
     hipStream_t s = (hipStream_t)stream;
     const unsigned mask = p->launch_mask ? p->launch_mask : 7u;   // diagnostic: time one launch alone
-    if (c->propagator != SSA_PROP_FG && c->propagator != SSA_PROP_ELEMENTS) return SSA_E_INVALID;
-    const bool fg = c->propagator == SSA_PROP_FG;
+    if (c->propagator != SSA_PROP_FG && c->propagator != SSA_PROP_ELEMENTS && c->propagator != SSA_PROP_J2_RK4) return SSA_E_INVALID;
+    if (c->propagator == SSA_PROP_J2_RK4 && (c->rk4_substeps < 1 || c->rk4_substeps > 4096)) return SSA_E_INVALID;
+    const int prop = c->propagator;
     if (mask & 1u) {
-        if (fg) hipLaunchKernelGGL(step_fast_kernel<1>, grid, block, 0, s, k);
-        else hipLaunchKernelGGL(step_fast_kernel<0>, grid, block, 0, s, k);
+        if (prop == SSA_PROP_FG) hipLaunchKernelGGL(step_fast_kernel<1>, grid, block, 0, s, k);
+        else if (prop == SSA_PROP_ELEMENTS) hipLaunchKernelGGL(step_fast_kernel<0>, grid, block, 0, s, k);
+        else hipLaunchKernelGGL(step_fast_kernel<2>, grid, block, 0, s, k);
     }
     if (mask & 2u) {
-        if (fg) hipLaunchKernelGGL(step_post_kernel<1>, dim3(nparts, p->n_env), dim3(POST_T), 0, s, k, parts, nparts);
-        else hipLaunchKernelGGL(step_post_kernel<0>, dim3(nparts, p->n_env), dim3(POST_T), 0, s, k, parts, nparts);
+        if (prop == SSA_PROP_FG) hipLaunchKernelGGL(step_post_kernel<1>, dim3(nparts, p->n_env), dim3(POST_T), 0, s, k, parts, nparts);
+        else if (prop == SSA_PROP_ELEMENTS) hipLaunchKernelGGL(step_post_kernel<0>, dim3(nparts, p->n_env), dim3(POST_T), 0, s, k, parts, nparts);
+        else hipLaunchKernelGGL(step_post_kernel<2>, dim3(nparts, p->n_env), dim3(POST_T), 0, s, k, parts, nparts);
     }
     // folds the per-block statistics (when requested) and resets the queue for the next step
     if (mask & 4u)
@@ -1376,6 +1396,16 @@ int ssa_propagate_f64(const double* x_in, double* x_out, int64_t n, double dt, i
     if (propagator == SSA_PROP_FG) hipLaunchKernelGGL(propagate_kernel<1>, dim3(nblk(n, 64)), dim3(64), 0, s, x_in, x_out, n, dt);
     else if (propagator == SSA_PROP_ELEMENTS) hipLaunchKernelGGL(propagate_kernel<0>, dim3(nblk(n, 64)), dim3(64), 0, s, x_in, x_out, n, dt);
     else return SSA_E_INVALID;
+    return launch_status();
+}
+
+int ssa_propagate_j2_f64(const double* x_in, double* x_out, int64_t n, double dt, double j2, double r_eq, int32_t substeps,
+                         void* stream)
+{
+    if (n == 0) return SSA_OK;
+    if (!x_in || !x_out || n < 0 || substeps < 1 || substeps > 4096) return SSA_E_INVALID;
+    J2Params q = {j2, r_eq, substeps};
+    hipLaunchKernelGGL(propagate_j2_kernel, dim3(nblk(n, 64)), dim3(64), 0, (hipStream_t)stream, x_in, x_out, n, dt, q);
     return launch_status();
 }
 

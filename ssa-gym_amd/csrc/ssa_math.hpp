@@ -430,6 +430,55 @@ SSA_DEV bool kepler_elements_fast(const double* x, double tof, double* out)
     return ok && (E == E);
 }
 
+// ---------------------------------------------------------------------------
+// SSA_PROP_J2_RK4 -- EXTENSION (the reference has no perturbed propagator on its hot path; its only
+// numerical integrator, fx_xyz_cowell at dynamics.py:168-201, takes the perturbation as `ad` and is
+// never called).  Cowell's formulation: r'' = -mu r/|r|^3 + a_J2 with the J2 acceleration of
+// poliastro.core.perturbations.J2_perturbation (factor 3/2 mu J2 R^2 / r^5 and the 5 z^2/r^2 - {1,1,3} terms),
+// integrated with the classical 4th-order Runge-Kutta scheme in `nsub` equal sub-steps.
+struct J2Params { double j2, r_eq; int nsub; };
+
+SSA_DEV void accel_j2(const double* r, const J2Params& q, double* a)
+{
+    const double r2 = dot3(r, r);
+    const double inv_r = rsqrt_nr(r2);
+    const double inv_r2 = inv_r * inv_r;
+    const double inv_r3 = inv_r2 * inv_r;
+    const double zz = 5.0 * r[2] * r[2] * inv_r2;
+    const double fj = 1.5 * q.j2 * q.r_eq * q.r_eq * inv_r2;      // (3/2) J2 (R/r)^2
+    const double k0 = -MU * inv_r3;
+    a[0] = k0 * r[0] * (1.0 - fj * (zz - 1.0));
+    a[1] = k0 * r[1] * (1.0 - fj * (zz - 1.0));
+    a[2] = k0 * r[2] * (1.0 - fj * (zz - 3.0));
+}
+
+SSA_DEV bool propagate_j2_rk4(const double* x, double tof, const J2Params& q, double* out)
+{
+    double r[3] = {x[0], x[1], x[2]}, v[3] = {x[3], x[4], x[5]};
+    const double h = tof / (double)q.nsub;
+    for (int it = 0; it < q.nsub; ++it) {
+        double k1[3], k2[3], k3[3], k4[3], rt[3], v2[3], v3[3], v4[3];
+        accel_j2(r, q, k1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { rt[c] = r[c] + 0.5 * h * v[c]; v2[c] = v[c] + 0.5 * h * k1[c]; }
+        accel_j2(rt, q, k2);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { rt[c] = r[c] + 0.5 * h * v2[c]; v3[c] = v[c] + 0.5 * h * k2[c]; }
+        accel_j2(rt, q, k3);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { rt[c] = r[c] + h * v3[c]; v4[c] = v[c] + h * k3[c]; }
+        accel_j2(rt, q, k4);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            r[c] += (h / 6.0) * (v[c] + 2.0 * v2[c] + 2.0 * v3[c] + v4[c]);
+            v[c] += (h / 6.0) * (k1[c] + 2.0 * k2[c] + 2.0 * k3[c] + k4[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { out[c] = r[c]; out[3 + c] = v[c]; }
+    return (out[0] == out[0]) && (out[3] == out[3]);
+}
+
 template <int PROP>
 SSA_DEV bool kepler_step_fast(const double* x, double tof, double* out)
 {

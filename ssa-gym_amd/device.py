@@ -44,6 +44,16 @@ def propagate(x, dt, propagator=_lib.PROP_FG, out=None):
     return out
 
 
+def propagate_j2(x, dt, j2, r_eq, substeps, out=None):
+    """extension: two-body + J2, RK4 with `substeps` steps per dt."""
+    lib = _lib.load()
+    n = x.shape[0]
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(lib.ssa_propagate_j2_f64(_chk(x, "x"), _chk(out, "out"), n, float(dt), float(j2), float(r_eq),
+                                        int(substeps), _stream()), "ssa_propagate_j2_f64")
+    return out
+
+
 def kepler_elements(x, dt):
     lib = _lib.load()
     n = x.shape[0]

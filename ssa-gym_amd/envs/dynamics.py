@@ -37,6 +37,9 @@ class _FxFarnocchia(_Operator):
     def __call__(self, x, dt):
         torch, device = _dev()
         xd = device.as_dev(np.asarray(x, dtype=np.float64).reshape(1, 6))
+        if self.propagator == 'j2':
+            nsub = max(1, int(np.ceil(abs(dt) / 5.0)))
+            return device.propagate_j2(xd, float(dt), host.J2_EARTH, host.R_EQ_EARTH, nsub).cpu().numpy().reshape(6)
         prop = {'elements': _lib.PROP_ELEMENTS, 'fg': _lib.PROP_FG}[self.propagator]
         return device.propagate(xd, float(dt), prop).cpu().numpy().reshape(6)
 
@@ -122,6 +125,7 @@ class _RobustCholesky(_Operator):
 
 fx_xyz_farnocchia = _FxFarnocchia('fg')            # default: reduced strong-elliptic form (SSA_PROP_FG)
 fx_xyz_farnocchia_elements = _FxFarnocchia('elements')  # operation-by-operation variant (SSA_PROP_ELEMENTS)
+fx_xyz_j2_rk4 = _FxFarnocchia('j2')                # EXTENSION: two-body + J2, RK4 (no reference counterpart)
 hx_aer_erfa = _HxAer()
 hx_xyz = _HxXyz()
 mean_z_uvw = _MeanZUvw()

@@ -74,8 +74,12 @@ def enu_matrix(obs_lla):
                      [np.cos(lat), 0, np.sin(lat)]])
 
 
+J2_EARTH = 0.00108263      # poliastro Earth.J2 (what the reference's ecosystem would plug into ad=J2_perturbation)
+R_EQ_EARTH = 6378136.6     # poliastro Earth.R [m]
+
+
 def make_consts(Q, R, alpha, beta, kappa, dt, obs_limit_rad, obs_lla, obs_type='aer', propagator='fg',
-                resample=False, update_interval=1):
+                resample=False, update_interval=1, j2=J2_EARTH, r_eq=R_EQ_EARTH, rk4_substeps=None):
     """pack the per-environment constants for the kernels (include/ssa_hip.h: ssa_consts)."""
     Wm, Wc, scale = merwe_weights(alpha, beta, kappa)
     sm, sc = exact_weight_sums(Wm, Wc)
@@ -89,7 +93,10 @@ def make_consts(Q, R, alpha, beta, kappa, dt, obs_limit_rad, obs_lla, obs_type='
     c.enu[:] = enu_matrix(obs_lla).reshape(9)
     c.obs_itrs[:] = lla2ecef(obs_lla)
     c.obs_type = {'aer': _lib.OBS_AER, 'xyz': _lib.OBS_XYZ}[obs_type]
-    c.propagator = {'elements': _lib.PROP_ELEMENTS, 'fg': _lib.PROP_FG}[propagator]
+    c.propagator = {'elements': _lib.PROP_ELEMENTS, 'fg': _lib.PROP_FG, 'j2': _lib.PROP_J2_RK4}[propagator]
+    c.j2, c.r_eq = float(j2), float(r_eq)
+    # RK4 sub-step <= 5 s: local error (n h)^5/120 |r| < 1e-6 m even in LEO
+    c.rk4_substeps = int(rk4_substeps) if rk4_substeps else max(1, int(np.ceil(abs(dt) / 5.0)))
     c.flags = _lib.FLAG_RESAMPLE if resample else 0
     c.update_interval = int(update_interval)
     return c
