@@ -30,13 +30,22 @@ def _find_catalogue():
 
 sample_orbits = _find_catalogue()
 
-env_config = {'steps': 480, 'rso_count': 10, 'time_step': 20., 't_0': datetime(2020, 5, 4, 0, 0, 0), 'obs_limit': -90,
-              'observer': (38.828198, -77.305352, 20.0), 'update_interval': 1, 'obs_type': 'aer',
-              'z_sigma': (1, 1, 1e3), 'x_sigma': tuple([1e5] * 3 + [1e2] * 3), 'q_sigma': 0.000025,
-              'P_0': np.diag(([1e5 ** 2] * 3 + [1e2 ** 2] * 3)), 'R': np.diag(([arcsec2rad ** 2] * 2 + [1e3 ** 2])),
-              'alpha': 0.0001, 'beta': 2., 'kappa': 3 - 6, 'fx': fx, 'hx': hx, 'mean_z': mean_z,
-              'residual_z': residual_z, 'msqrt': robust_cholesky, 'orbits': sample_orbits, 'obs_returned': 'flatten',
-              'reward_type': 'jones'}
+# The reference's default configuration (envs/__init__.py:23-28), key for key: this dict IS the reference's
+# config system -- scripts mutate it in place and hand it to the env -- so the names and defaults are the API.
+_X_SIGMA = (1e5,) * 3 + (1e2,) * 3                      # initial estimate noise [m, m/s]
+env_config = dict(
+    # simulation
+    steps=480, rso_count=10, time_step=20., t_0=datetime(2020, 5, 4, 0, 0, 0),
+    observer=(38.828198, -77.305352, 20.0), obs_limit=-90, update_interval=1,
+    orbits=sample_orbits, obs_returned='flatten', reward_type='jones',
+    # measurement model: az / el in arc seconds, range in metres
+    obs_type='aer', z_sigma=(1, 1, 1e3), R=np.diag([arcsec2rad ** 2, arcsec2rad ** 2, 1e3 ** 2]),
+    # filter
+    x_sigma=_X_SIGMA, P_0=np.diag(np.square(_X_SIGMA)), q_sigma=0.000025,
+    alpha=0.0001, beta=2., kappa=3 - 6,
+    # operator plug points (tokens selecting fused kernel variants, see dynamics.py)
+    fx=fx, hx=hx, mean_z=mean_z, residual_z=residual_z, msqrt=robust_cholesky,
+)
 
 if _gymshim.register is not None:  # pragma: no cover - only with gym / gymnasium installed
     try:

@@ -5,7 +5,6 @@ geometry -- packed into the `ssa_consts` block the kernels take by value.
 None of this is per-step work; it runs in numpy.  Citations: file:line under the
 reference root.
 """
-import ctypes as C
 from fractions import Fraction
 
 import numpy as np
@@ -100,7 +99,3 @@ def make_consts(Q, R, alpha, beta, kappa, dt, obs_limit_rad, obs_lla, obs_type='
     c.flags = _lib.FLAG_RESAMPLE if resample else 0
     c.update_interval = int(update_interval)
     return c
-
-
-def consts_ptr(c):
-    return C.byref(c)

