@@ -101,14 +101,15 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (args.gpus, args.gpus))
-    if rank == 0:
-        ssa_gym_amd.build()
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or "RANK" in os.environ   # under torch.distributed.run even 1 rank goes through RCCL
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        dist.barrier()
+    if rank == 0:
+        ssa_gym_amd.build()          # no-op when the in-tree libssa_hip.so is current
+    if use_dist:
+        dist.barrier()               # nobody loads the library before rank 0 has (re)built it
     _lib.load()
 
     m, K, W = args.objects, args.steps, args.warmup
@@ -223,7 +224,7 @@ def main():
                 "note": "fp64 VALU / latency bound, not HBM bound: ~14 Kepler solves per object-step (SURVEY 8d)"}
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N=1 only
         cpu = cpu_baseline(m)
 
     if rank == 0:
