@@ -248,3 +248,19 @@ def test_history_ring_and_update_interval(envs):
     assert np.asarray(env2.x_true).shape == (20, 6, 6)
     assert np.array_equal(env2.x_true[3], env.x_true[3]) if False else True
     assert env2.x_filter[2].shape == (6, 6) and env2.delta_pos[1:4].shape == (3, 6)
+
+
+def test_second_reset_starts_a_fresh_episode(envs):
+    cfg = dict(envs.env_config)
+    cfg.update(rso_count=5, steps=10, seed=9, reward_type='trinary')
+    env = envs.make(config=cfg)
+    first = env.x_true[0].copy()
+    for k in range(1, 10):
+        obs, r, done, _ = env.step(k % 5)
+    assert done and env.i == 9
+    obs = env.reset()                                   # the RNG stream continues (:193-241): new objects
+    assert env.i == 0 and obs.shape == (60,) and not np.array_equal(env.x_true[0], first)
+    assert np.all(env.rewards == 0) and not env.obs_taken.any() and env.failed_filters_id == []
+    assert np.array_equal(obs.reshape(5, 12)[:, :6], env.x_filter[0])
+    obs, r, done, _ = env.step(2)
+    assert env.i == 1 and env.obs_taken[1] and not done
