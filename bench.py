@@ -124,7 +124,9 @@ def main():
     eng.load_state(0, pb["x_true"], pb["x"], np.broadcast_to(pb["P0"], (m, 6, 6)))
 
     plan = parallel.ShardPlan(m * world, world, rank)
-    local = parallel.HipLocalStepper(eng, consts)
+    # statistics by the two-launch path (max delta_pos, trinary counts, failures: everything the 'jones' and
+    # 'trinary' rewards read); the sharded multi-GPU step needs the post kernel for its payload anyway
+    local = parallel.HipLocalStepper(eng, consts, fast_stats=True)
     # round-robin actions over the GLOBAL catalogue (BASELINE.md protocol): a_i = i mod m_total
     total_steps = W + K
     glob_actions = np.arange(total_steps) % plan.m_total
@@ -199,10 +201,13 @@ def main():
             p.upd, p.stats = eng._bu + sout * eng._su, eng._bs + sout * eng._ss
             p.actions = local._sched.data_ptr() + 4 * (k % local._sched.numel())
             p.launch_mask = 1
+            p.stat_shards = eng.stat_shards.data_ptr()
+            p.aer_out = 0
             evs[k][0].record()
             eng._lib.ssa_env_step_f64(eng._cref, eng._pref, s)
             evs[k][1].record()
             p.launch_mask = 6
+            p.stat_shards = eng.stat_shards.data_ptr()
             eng._lib.ssa_env_step_f64(eng._cref, eng._pref, s)
         torch.cuda.synchronize()
         p.launch_mask = 0

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SSA_ABI_VERSION 7
+#define SSA_ABI_VERSION 8
 
 /* error codes */
 #define SSA_OK 0
@@ -72,6 +72,7 @@ extern "C" {
 #define SSA_UPD_ACTION 56   /* the action this record belongs to (as double), -1 = no update attempted */
 
 /* layout of the per-env reward statistics written by ssa_reward_stats_f64 (doubles) */
+#define SSA_STAT_SHARDS 64  /* accumulator shards per env of the atomics-based statistics path */
 #define SSA_STAT_STRIDE 8
 #define SSA_STAT_MAX_DPOS 0   /* np.max(delta_pos[i])  (NaN-propagating)        (:325-343) */
 #define SSA_STAT_CNT_LT_1E4 1 /* count(delta_pos < 1e4)  } results.py:432        */
@@ -126,6 +127,12 @@ typedef struct ssa_step_params {
     double *stats;             /* [E][SSA_STAT_STRIDE] reward statistics of this step (O3), may be NULL */
     int32_t *work;             /* ssa_env_step_work_bytes(): exception queue; zero it once before the first call */
     void *stat_ws;             /* ssa_reward_stats_workspace_bytes(): per-block statistics partials */
+    uint64_t *stat_shards;     /* [E][SSA_STAT_SHARDS][4] zero-initialised device words, or NULL.  When given (and
+                                  aer_out is NULL, propagator != ELEMENTS) the common-path kernel accumulates max
+                                  delta_pos / trinary counts / failures itself with sharded atomics and a one-wave
+                                  fold kernel writes `stats`: two launches per step instead of three.  arg-max
+                                  sigma_pos (only the 'shaped' reward needs it) is then NOT computed:
+                                  stats[SSA_STAT_ARGMAX_SPOS] = -1, stats[SSA_STAT_MAX_SPOS] = NaN. */
     double *aer_out;           /* [E*m][4] aer_obs() of the NEW state (O4: az, el, range, trace P; NaN/inf -> 0.001;
                                   ssa_tasker_simple_2.py:834-840), may be NULL.  Written by the post kernel, so the
                                   'aer' observation / the sharded all-gather payload costs no extra launch. */

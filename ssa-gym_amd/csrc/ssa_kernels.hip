@@ -587,9 +587,16 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
             kep_ok = kepler_step_fast<PROP == 2 ? 1 : PROP>(s, C.dt, o);
         }
 #endif
-        if (FAST) {
+        if (PROP != 0) {
+            // SSA_PROP_FG / J2: the solvers cover every conic; they decline only NaN / degenerate input or a
+            // non-converging iteration, which IS a NaN result (farnocchia.py:353) -> 'predict returned nan'
+            if (!kep_ok) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) o[c] = __builtin_nan("");
+            }
+        } else if (FAST) {
             need_full = need_full || (((__ballot(!kep_ok && l < 14) >> (g * 16)) & 0xFFFFull) != 0);
-        } else if (!kep_ok && PROP != 2) {
+        } else if (!kep_ok) {
             Vec6 si;
 #pragma unroll
             for (int c = 0; c < 6; ++c) si.v[c] = s[c];
@@ -830,7 +837,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                 const int pos = atomicAdd(p.work, 1);
                 if ((int64_t)pos < (int64_t)p.n_env * p.n_obj) p.work[4 + pos] = (int32_t)obj;   // capacity = every object once
             }
-            if (valid) p.work[4 + p.n_env * p.n_obj + obj] = need_full ? 1 : 0;   // mark: excluded from the slice statistics
+            if (valid && PROP == 0) p.work[4 + p.n_env * p.n_obj + obj] = need_full ? 1 : 0;   // mark: excluded from the slice statistics
         }
     }
     if (l == 0) t.St[g] = st_new;
@@ -839,6 +846,31 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     wave_lds_sync();
     if (FAST) {
         store_tile(t, p, lane, base, cnt);
+        if (p.stat_shards && !p.aer_out && PROP != 0 && lane == 0) {
+            // O3 by sharded atomics: max delta_pos (as ordered bits: non-negative doubles and NaN order like
+            // unsigned integers, so NaN wins exactly as in np.max), trinary counts, failures
+            int64_t e_cur = -1;
+            unsigned long long mx = 0ull, cnts = 0ull, nf = 0ull;
+            for (int gg = 0; gg <= cnt; ++gg) {
+                const int64_t eg = (gg < cnt) ? (base + gg) / p.n_obj : -2;
+                if (eg != e_cur) {
+                    if (e_cur >= 0) {
+                        unsigned long long* sh = (unsigned long long*)p.stat_shards + ((e_cur * SSA_STAT_SHARDS) + (blockIdx.x & (SSA_STAT_SHARDS - 1))) * 4;
+                        atomicMax(sh, mx);
+                        atomicAdd(sh + 1, cnts);
+                        if (nf) atomicAdd(sh + 2, nf);
+                    }
+                    e_cur = eg; mx = 0ull; cnts = 0ull; nf = 0ull;
+                }
+                if (gg < cnt) {
+                    const double dp = t.Met[gg * 4 + 0];
+                    unsigned long long bits = (unsigned long long)__double_as_longlong(dp) & 0x7fffffffffffffffull;
+                    mx = bits > mx ? bits : mx;
+                    cnts += (unsigned long long)(dp < 1e4) + ((unsigned long long)(dp < 1e7) << 32);
+                    nf += t.St[gg] != 0;
+                }
+            }
+        }
     } else {
         store_object(t, p, g, l, obj, valid, e, j, true);
         if (valid && l == 0 && p.aer_out) aer_obs_row(&t.X[g * 6], &t.P[g * 36], p, C, e, obj);
@@ -896,7 +928,7 @@ __global__ void __launch_bounds__(POST_T) step_post_kernel(const StepK k, StatAc
     if (p.aer_out) {   // O4 for every object of this block's slice that was not re-done above
         const int32_t* mark = p.work + 4 + N + (int64_t)e * m;
         for (int64_t i = (int64_t)blockIdx.x * POST_T + tid; i < m; i += (int64_t)nparts * POST_T) {
-            if (mark[i] == 0) {
+            if (PROP != 0 || mark[i] == 0) {
                 const int64_t obj = (int64_t)e * m + i;
                 aer_obs_row(p.x_out + obj * 6, p.P_out + obj * 36, p, C, e, obj);
             }
@@ -917,7 +949,7 @@ __global__ void __launch_bounds__(POST_T) step_post_kernel(const StepK k, StatAc
                 dp[q] = in ? dpos[i] : 0.0;
                 sp[q] = in ? spos[i] : -2.0;
                 sv[q] = in ? st[i] : 0;
-                mk[q] = in ? mark[i] : 1;
+                mk[q] = in ? (PROP == 0 ? mark[i] : 0) : 1;
             }
 #pragma unroll
             for (int q = 0; q < POST_ILP; ++q) {
@@ -1320,6 +1352,32 @@ extern "C" {
 int ssa_abi_version(void) { return SSA_ABI_VERSION; }
 const char* ssa_build_info(void) { return "libssa_hip gfx950 fp64 (" __DATE__ " " __TIME__ ")"; }
 
+// one wave per env: folds the SSA_STAT_SHARDS accumulators of the atomics path into stats and clears them
+__global__ void __launch_bounds__(64) reward_fold_kernel(unsigned long long* __restrict__ shards, double* __restrict__ stats, int64_t m)
+{
+    const int e = blockIdx.x, t = threadIdx.x;
+    unsigned long long* sh = shards + ((int64_t)e * SSA_STAT_SHARDS + t) * 4;
+    unsigned long long mx = sh[0], cn = sh[1], nf = sh[2];
+    sh[0] = 0ull; sh[1] = 0ull; sh[2] = 0ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long m2 = __shfl_down(mx, off, 64), c2 = __shfl_down(cn, off, 64), n2 = __shfl_down(nf, off, 64);
+        mx = m2 > mx ? m2 : mx;
+        cn += c2;
+        nf += n2;
+    }
+    if (t == 0 && stats) {
+        double* o = stats + (int64_t)e * SSA_STAT_STRIDE;
+        o[SSA_STAT_MAX_DPOS] = __longlong_as_double((long long)mx);
+        o[SSA_STAT_CNT_LT_1E4] = (double)(cn & 0xffffffffull);
+        o[SSA_STAT_CNT_LT_1E7] = (double)(cn >> 32);
+        o[SSA_STAT_ARGMAX_SPOS] = -1.0;
+        o[SSA_STAT_N_FAILED] = (double)nf;
+        o[SSA_STAT_MAX_SPOS] = __builtin_nan("");
+        o[6] = 0.0; o[7] = 0.0;
+    }
+}
+
 static int post_parts(int64_t n_obj, int32_t n_env)
 {
     int64_t want = (n_obj + (int64_t)POST_T * POST_ILP - 1) / ((int64_t)POST_T * POST_ILP);
@@ -1354,6 +1412,12 @@ int ssa_env_step_f64(const ssa_consts* c, const ssa_step_params* p, void* stream
         if (prop == SSA_PROP_FG) hipLaunchKernelGGL(step_fast_kernel<1>, grid, block, 0, s, k);
         else if (prop == SSA_PROP_ELEMENTS) hipLaunchKernelGGL(step_fast_kernel<0>, grid, block, 0, s, k);
         else hipLaunchKernelGGL(step_fast_kernel<2>, grid, block, 0, s, k);
+    }
+    const bool fast_stats = p->stat_shards && !p->aer_out && prop != SSA_PROP_ELEMENTS;
+    if (fast_stats) {   // statistics were accumulated by the common-path kernel: fold, done (2 launches)
+        if (mask & 6u)
+            hipLaunchKernelGGL(reward_fold_kernel, dim3(p->n_env), dim3(64), 0, s, (unsigned long long*)p->stat_shards, p->stats, p->n_obj);
+        return launch_status();
     }
     if (mask & 2u) {
         if (prop == SSA_PROP_FG) hipLaunchKernelGGL(step_post_kernel<1>, dim3(nparts, p->n_env), dim3(POST_T), 0, s, k, parts, nparts);

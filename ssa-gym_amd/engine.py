@@ -66,6 +66,7 @@ class HotPathEngine:
         self._stats_ws = device.stats_workspace(self.E, d)
         self.work = torch.zeros(self._lib.ssa_env_step_work_bytes(self.m, self.E) // 4, dtype=torch.int32, device=d)
         self._p.work, self._p.stat_ws, self._p.launch_mask = self.work.data_ptr(), self._stats_ws.data_ptr(), 0
+        self.stat_shards = torch.zeros((self.E, _lib.STAT_SHARDS, 4), dtype=torch.int64, device=d)
         self._cref = C.byref(self.consts)
         self._pref = C.byref(self._p)
         # element strides of one history slot
@@ -118,7 +119,8 @@ class HotPathEngine:
         self.status.zero_()
 
     # ------------------------------------------------------------------ one step
-    def launch_step(self, slot_in, slot_out, time_offset, actions_ptr=None, stream=None, aer_out=0, stats_out=0, upd_out=0):
+    def launch_step(self, slot_in, slot_out, time_offset, actions_ptr=None, stream=None, aer_out=0, stats_out=0, upd_out=0,
+                    fast_stats=False):
         """enqueue the step (common-path kernel, post kernel, final kernel); asynchronous, no host sync."""
         p = self._p
         p.time_offset = int(time_offset)
@@ -131,6 +133,8 @@ class HotPathEngine:
         p.actions = self.actions.data_ptr() if actions_ptr is None else actions_ptr
         p.stats = stats_out if stats_out else self._bs + slot_out * self._ss   # e.g. straight into a send buffer
         p.aer_out = aer_out
+        # two-launch path (no arg-max of sigma_pos): see include/ssa_hip.h ssa_step_params.stat_shards
+        p.stat_shards = self.stat_shards.data_ptr() if fast_stats else 0
         s = torch.cuda.current_stream().cuda_stream if stream is None else stream
         rc = self._lib.ssa_env_step_f64(self._cref, self._pref, s)
         if rc:

@@ -305,7 +305,8 @@ class SSA_Tasker_Env(Env):
         # 'aer' observations come out of the post kernel of the same step (no extra launch)
         e.launch_step((i - 1) % e.H, i % e.H, i, actions_ptr=self._act_host.data_ptr(),
                       aer_out=self._aer_dev.data_ptr() if self.obs_returned == 'aer' else 0,
-                      stats_out=self._stats_host.data_ptr(), upd_out=self._upd_host.data_ptr())
+                      stats_out=self._stats_host.data_ptr(), upd_out=self._upd_host.data_ptr(),
+                      fast_stats=(self.reward_type != 'shaped'))   # only 'shaped' needs argmax(sigma_pos) (:346)
         src = self._aer_dev if self.obs_returned == 'aer' else e.obs[i % e.H].reshape(-1)
         big = src.numel() * 8 > (1 << 19)   # large vectors: one pageable D2H beats pinned copy + host memcpy
         if not big:

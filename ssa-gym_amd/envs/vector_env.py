@@ -115,7 +115,8 @@ class SSA_Tasker_VecEnv:
         e.env_time0.copy_(self._time)
         e.set_actions(actions)
         sin, sout = (self.tick - 1) % 2, self.tick % 2
-        e.launch_step(sin, sout, 0, aer_out=self._aer.data_ptr() if self.obs_returned == 'aer' else 0)
+        e.launch_step(sin, sout, 0, aer_out=self._aer.data_ptr() if self.obs_returned == 'aer' else 0,
+                      fast_stats=(self.reward_type != 'shaped'))
         st = self._refresh_stats(sout)
         mx = st[:, _lib.STAT_MAX_DPOS]
         rewards = np.zeros(self.E)

@@ -136,8 +136,9 @@ class ShardedStepper:
 class HipLocalStepper:
     """LocalStepper over the HIP engine (the only one the product uses)."""
 
-    def __init__(self, engine, consts):
+    def __init__(self, engine, consts, fast_stats=False):
         self.engine, self.consts = engine, consts
+        self.fast_stats = fast_stats   # two-launch step (no arg-max of sigma_pos); ignored when a payload is requested
         self.device = engine.dev
         self.tick = 0
         self._act = torch.zeros(1, dtype=torch.int32)
@@ -158,11 +159,11 @@ class HipLocalStepper:
         if self._sched is not None:
             k = (self.tick - 1 - self._sched_k0) % self._sched.numel()
             e.launch_step((self.tick - 1) % e.H, self.tick % e.H, self.tick, actions_ptr=self._sched.data_ptr() + 4 * k,
-                          aer_out=aer, stats_out=st)
+                          aer_out=aer, stats_out=st, fast_stats=self.fast_stats)
             return
         self._act[0] = int(local_action)
         e.actions.copy_(self._act)
-        e.launch_step((self.tick - 1) % e.H, self.tick % e.H, self.tick, aer_out=aer, stats_out=st)
+        e.launch_step((self.tick - 1) % e.H, self.tick % e.H, self.tick, aer_out=aer, stats_out=st, fast_stats=self.fast_stats)
 
     def reset_episode(self, snap, episode_len):
         """start a new episode from a device-resident snapshot: the next step gets time index 1."""

@@ -391,3 +391,36 @@ def test_fused_aer_payload_matches_operator(hip, oracle):
     assert hip.torch.equal(send[4 * m:4 * m + 6], st[:6])
     o = oracle.aer_obs(eng.x_filter[1].cpu().numpy(), eng.P_filter[1].cpu().numpy(), c2t()[9], g["obs_lla"], g["obs_itrs"])
     np.testing.assert_allclose(send[:4 * m].cpu().numpy(), o, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("E,m", [(1, 2003), (3, 50), (2, 4)])
+def test_two_launch_statistics_path_matches_exact_path(hip, E, m):
+    """ssa_step_params.stat_shards: max delta_pos / trinary counts / failures accumulated by the common-path
+    kernel with sharded atomics must equal the post+final kernels' values (arg-max is documented as absent),
+    and the filter state must be identical -- including envs that straddle a wavefront (m % 4 != 0), a NaN
+    metric and failed filters."""
+    xt, x, P, g = make_batch(E * m, seed=41)
+    x[1, 0] = np.nan                               # -> predict NaN failure in env 0
+    P[E * m - 1] = -1e18 * np.eye(6)               # -> LinAlgError in the last env
+    xt[2, 0] = np.nan                              # NaN truth -> NaN delta_pos propagates into max (np.max semantics)
+    consts = hip.host.make_consts(g["Q"], g["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, g["obs_lla"])
+    outs = []
+    for fast in (False, True):
+        eng = hip.engine.HotPathEngine(consts, m, E, c2t(), np.zeros((E, 480, m, 3)), history=2)
+        eng.load_state(0, xt, x, P)
+        eng.set_actions([(3 * e + 1) % m for e in range(E)])
+        eng.launch_step(0, 1, 2, fast_stats=fast)
+        eng.set_actions([(3 * e + 2) % m for e in range(E)])
+        eng.launch_step(1, 0, 3, fast_stats=fast)      # second step: shards were cleared by the fold kernel
+        hip.torch.cuda.synchronize()
+        outs.append((eng.stats[0].cpu().numpy(), eng.x_filter[0].cpu().numpy(), eng.P_filter[0].cpu().numpy(),
+                     eng.status.cpu().numpy(), eng.metrics[0].cpu().numpy()))
+    (s0, x0, P0, st0, m0), (s1, x1, P1, st1, m1) = outs
+    assert np.array_equal(st0, st1) and np.array_equal(x0, x1, equal_nan=True) and np.array_equal(P0, P1, equal_nan=True)
+    L = hip.lib
+    for e in range(E):
+        for k in (L.STAT_MAX_DPOS, L.STAT_CNT_LT_1E4, L.STAT_CNT_LT_1E7, L.STAT_N_FAILED):
+            assert np.array_equal(s0[e, k], s1[e, k], equal_nan=True), (e, k, s0[e], s1[e])
+        assert s1[e, L.STAT_ARGMAX_SPOS] == -1.0 and np.isnan(s1[e, L.STAT_MAX_SPOS])
+        assert s0[e, L.STAT_ARGMAX_SPOS] == np.nanargmax(np.where(np.isnan(m0[e, 2]), np.inf, m0[e, 2]))
+    assert np.isnan(s0[0, L.STAT_MAX_DPOS]) and s0[0, L.STAT_N_FAILED] >= 1 and s0[E - 1, L.STAT_N_FAILED] >= 1
