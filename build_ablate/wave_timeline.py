@@ -1,0 +1,67 @@
+"""Per-wave phase timeline of step_fast_kernel (diagnostic build -DSSA_TRACE -> build_ablate/libs/trace.so).
+
+    cp build_ablate/libs/trace.so ssa-gym_amd/libssa_hip.so && python build_ablate/wave_timeline.py
+
+Each wavefront stamps the 100 MHz wall clock (s_memrealtime) at the phase boundaries of process_wave; the
+script prints when waves start/end relative to the first one, the mean time per phase, and how the 5000
+wavefronts of a 20 000-object step were spread over XCDs / CUs / SIMDs."""
+import ctypes as C, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.argv = ['bench.py']
+import bench
+from ssa_gym_amd import host, engine, parallel, _lib
+
+m = int(os.environ.get("M", 20000))
+pb = bench.build_problem(m, seed=100)
+consts = host.make_consts(pb["Q"], pb["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, pb["obs_lla"], obs_type='aer',
+                          propagator=os.environ.get("PROP", "fg"))
+z = torch.zeros((1, 480, m, 3), dtype=torch.float64, device='cuda')
+eng = engine.HotPathEngine(consts, m, 1, pb["trans"], z, history=2)
+eng.load_state(0, pb["x_true"], pb["x"], np.broadcast_to(pb["P0"], (m, 6, 6)))
+local = parallel.HipLocalStepper(eng, consts, fast_stats=True)
+local.load_schedule(np.arange(400) % m)
+for k in range(int(os.environ.get("STEPS", 100))):
+    local.step(-1)
+torch.cuda.synchronize()
+lib = _lib.load()
+nb = (m + 3) // 4
+buf = np.zeros((16384, 16), dtype=np.uint64)
+lib.ssa_debug_trace_copy.argtypes = [C.c_void_p, C.c_int64]
+assert lib.ssa_debug_trace_copy(buf.ctypes.data, buf.nbytes) == 0
+tr = buf[:nb].astype(np.int64)
+t = tr[:, :10] * 10.0   # ns
+t0 = t[:, 0].min()
+names = ["load", "chol", "kepler", "UT-mean", "cov", "update", "observe", "store", "stats"]
+print("waves %d; first start -> last end: %.2f us" % (nb, (t[:, 9].max() - t0) / 1e3))
+st = (t[:, 0] - t0) / 1e3
+en = (t[:, 9] - t0) / 1e3
+print("start time  percentiles [us] 0/25/50/75/90/99/100:", np.percentile(st, [0, 25, 50, 75, 90, 99, 100]).round(2))
+print("end   time  percentiles [us] 0/25/50/75/90/99/100:", np.percentile(en, [0, 25, 50, 75, 90, 99, 100]).round(2))
+life = en - st
+print("wave lifetime [us] mean %.2f  p50 %.2f  p99 %.2f" % (life.mean(), np.median(life), np.percentile(life, 99)))
+early = st < 1.0
+for lab, sel in (("waves started < 1 us", early), ("waves started >= 1 us", ~early)):
+    if sel.sum() == 0:
+        continue
+    d = np.diff(t[sel], axis=1) / 1e3
+    print("%s: n=%d  lifetime %.2f us" % (lab, sel.sum(), life[sel].mean()))
+    for k, nme in enumerate(names):
+        print("    %-8s %6.2f us (p90 %6.2f)" % (nme, d[:, k].mean(), np.percentile(d[:, k], 90)))
+hw = tr[:, 15] & 0xffffffff
+xcc = (tr[:, 15] >> 32) & 0xf
+simd = (hw >> 4) & 3
+cu = (hw >> 8) & 15
+se = (hw >> 13) & 7
+wave = hw & 15
+print("XCC histogram:", np.bincount(xcc, minlength=8))
+key = xcc * 10000 + se * 1000 + cu * 10 + simd
+u, c = np.unique(key, return_counts=True)
+print("distinct (xcc,se,cu,simd): %d ; waves per SIMD min/mean/max: %d / %.2f / %d" % (len(u), c.min(), c.mean(), c.max()))
+ucu, ccu = np.unique(xcc * 10000 + se * 1000 + cu * 10, return_counts=True)
+print("distinct CUs: %d ; waves per CU min/mean/max: %d / %.2f / %d" % (len(ucu), ccu.min(), ccu.mean(), ccu.max()))
+# concurrency over time
+grid = np.linspace(0, en.max(), 60)
+conc = [(int(((st <= g) & (en > g)).sum())) for g in grid]
+print("resident waves over time:", conc)

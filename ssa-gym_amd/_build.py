@@ -28,8 +28,12 @@ def build_library(force=False, verbose=False, extra_flags=()):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libssa_hip.so")
+    # -disable-machine-licm: the step kernel is one long straight-line body inside a tile loop (plus Newton /
+    # ladder loops); MachineLICM hoists its literals, argument scalars and LDS addresses out of those loops
+    # and the register allocator then spills them (16 VGPR + 48 SGPR spills, 220 B scratch per lane with it;
+    # none without at 4 waves/SIMD) -- see DESIGN.md section 7
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-shared",
-           "-ffp-contract=fast", *extra_flags, "-o", LIB + ".tmp", SRC]
+           "-ffp-contract=fast", "-mllvm", "-disable-machine-licm", *extra_flags, "-o", LIB + ".tmp", SRC]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -238,6 +238,7 @@ __device__ static void kepler_general_impl(const double* x, double tof, double* 
     }
 }
 
+template <int TAG>
 __device__ __noinline__ Vec7 kepler_nonelliptic_v(Vec6 x, double tof, double r0, double alpha, double rv, int band)
 {
     Vec7 o;
@@ -320,22 +321,40 @@ SSA_DEV void store_object(const Tiles& t, const ssa_step_params& p, int g, int l
 // Wave-contiguous tile I/O: the 4 objects of a wavefront are consecutive, so P / x / x_true / obs are
 // single contiguous spans (1152 / 192 / 192 / 384 B) moved as 16-byte lanes -- whole cache lines per
 // instruction instead of four 288-byte pieces.  `cnt` = valid objects in the tile (1..4).
-SSA_DEV void load_tile(Tiles& t, const ssa_step_params& p, int lane, int64_t base, int cnt)
+// The tile's inputs travel global -> registers -> LDS in two halves, so that a wavefront that advances
+// several tiles can have the NEXT tile's loads in flight while it works on the current one:
+//   tile_issue : 16-byte wave-contiguous loads into 8 VGPRs.  `main` = P entries [2 lane, 2 lane + 2);
+//                `aux` by lane: 0-7 the tail of P | 32-43 x_filter | 48-59 x_true | 60-63 status (bits)
+//   tile_commit: registers -> LDS tiles (rows beyond `cnt` are zero / marked failed)
+struct TileRegs { double2 main, aux; };
+SSA_DEV void tile_issue(TileRegs& r, const ssa_step_params& p, int lane, int64_t base, int cnt)
 {
+    const double2 zero = make_double2(0.0, 0.0);
+    r.main = zero;
+    r.aux = zero;
+    if (cnt <= 0) return;
     const double2* P2 = reinterpret_cast<const double2*>(p.P_in + base * 36);
-    double2* tP = reinterpret_cast<double2*>(t.P);
-    for (int i = lane; i < 72; i += 64) tP[i] = (i < cnt * 18) ? P2[i] : make_double2(0.0, 0.0);
-    if (lane < 12) {
-        const double2* X2 = reinterpret_cast<const double2*>(p.x_in + base * 6);
-        reinterpret_cast<double2*>(t.X)[lane] = (lane < cnt * 3) ? X2[lane] : make_double2(0.0, 0.0);
-    } else if (lane >= 16 && lane < 28) {
-        const int i = lane - 16;
-        const double2* T2 = reinterpret_cast<const double2*>(p.x_true_in + base * 6);
-        reinterpret_cast<double2*>(t.T)[i] = (i < cnt * 3) ? T2[i] : make_double2(0.0, 0.0);
-    } else if (lane >= 32 && lane < 36) {
+    if (lane < cnt * 18) r.main = P2[lane];
+    if (lane < 8) {
+        if (64 + lane < cnt * 18) r.aux = P2[64 + lane];
+    } else if (lane >= 32 && lane < 44) {
         const int i = lane - 32;
-        t.St[i] = (i < cnt) ? p.status[base + i] : SSA_ST_PREDICT_NAN;
+        if (i < cnt * 3) r.aux = reinterpret_cast<const double2*>(p.x_in + base * 6)[i];
+    } else if (lane >= 48 && lane < 60) {
+        const int i = lane - 48;
+        if (i < cnt * 3) r.aux = reinterpret_cast<const double2*>(p.x_true_in + base * 6)[i];
+    } else if (lane >= 60) {
+        const int i = lane - 60;
+        r.aux.x = __hiloint2double(0, (i < cnt) ? p.status[base + i] : SSA_ST_PREDICT_NAN);
     }
+}
+SSA_DEV void tile_commit(Tiles& t, const TileRegs& r, int lane)
+{
+    reinterpret_cast<double2*>(t.P)[lane] = r.main;
+    if (lane < 8) reinterpret_cast<double2*>(t.P)[64 + lane] = r.aux;
+    else if (lane >= 32 && lane < 44) reinterpret_cast<double2*>(t.X)[lane - 32] = r.aux;
+    else if (lane >= 48 && lane < 60) reinterpret_cast<double2*>(t.T)[lane - 48] = r.aux;
+    else if (lane >= 60) t.St[lane - 60] = __double2loint(r.aux.x);
 }
 SSA_DEV void store_tile(const Tiles& t, const ssa_step_params& p, int lane, int64_t base, int cnt)
 {
@@ -359,7 +378,7 @@ SSA_DEV void store_tile(const Tiles& t, const ssa_step_params& p, int lane, int6
         const int kk = lane >> 2, jj = lane & 3;
         if (jj < cnt) {
             const int64_t obj = base + jj;
-            const int64_t e = obj / p.n_obj, j = obj - e * p.n_obj;
+            const int64_t e = (p.n_env > 1) ? (int64_t)((uint32_t)obj / (uint32_t)p.n_obj) : 0, j = obj - e * p.n_obj;
             p.metrics[(e * 4 + kk) * p.n_obj + j] = t.Met[jj * 4 + kk];
         }
     }
@@ -455,7 +474,19 @@ SSA_DEV StatAcc stat_wave_reduce(StatAcc a)
 // lane's later LDS reads" only needs the compiler not to move accesses across this point and the
 // outstanding DS operations to have completed.  (Usable inside row-divergent branches, unlike a
 // workgroup barrier.)
-SSA_DEV void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+SSA_DEV void wave_lds_sync()
+{
+#ifdef SSA_LDS_WAIT   // the former form: additionally drains the DS queue (not needed, see above)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+    // wavefront-scope fence: no instruction on gfx9 (the DS unit executes one wavefront's operations in
+    // issue order, so a lane's read issued after another lane's write observes it); it only pins the
+    // compiler's ordering of the LDS accesses around this point
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+#endif
+}
 
 // U2 (common case): upper Cholesky of scale*P for the row's object, lane-distributed through LDS:
 // lane c owns column c; step j forms the pivot and row j (LAPACK dpotf2('U') order).  Ten VGPRs
@@ -523,6 +554,13 @@ SSA_DEV void aer_obs_row(const double* x, const double* P, const ssa_step_params
     for (int c = 0; c < 4; ++c) p.aer_out[obj * 4 + c] = (fabs(v[c]) <= 1.79769313486231570e308) ? v[c] : 0.001;
 }
 
+#ifdef SSA_TRACE   // diagnostic build only (build_ablate/wave_timeline.py): per-wave phase timestamps, 100 MHz wall clock
+__device__ unsigned long long g_trace[16384 * 16];
+#define SSA_TR(k) do { if (FAST && lane == 0 && tile < 16384) g_trace[tile * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define SSA_TR(k) do { } while (0)
+#endif
+
 // One wavefront advances up to 4 objects (one per 16-lane row).
 //   FAST = true : the objects are consecutive (tile I/O); anything beyond the common path -- a
 //                 Cholesky that needs the jitter ladder, a sigma point outside the strong-elliptic
@@ -532,18 +570,28 @@ SSA_DEV void aer_obs_row(const double* x, const double* P, const ssa_step_params
 //                 metrics are folded into `acc` (reward statistics of queued objects).
 template <int PROP, bool FAST>
 SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& p, int lane, int64_t obj, bool valid,
-                          int64_t base, int cnt, StatAcc& acc)
+                          int64_t base, int cnt, StatAcc& acc, TileRegs& pf, int64_t next_base, int next_cnt, int tile)
 {
     const int g = lane >> 4, l = lane & 15;
-    const int e = valid ? (int)(obj / p.n_obj) : 0;
+    // env of the object: no division for the single-env case, a 32-bit one otherwise (n_env * n_obj < 2^31)
+    const int e = (valid && p.n_env > 1) ? (int)((uint32_t)obj / (uint32_t)p.n_obj) : 0;
     const int64_t j = valid ? obj - (int64_t)e * p.n_obj : 0;
     // the action / time index of this object's env, fetched early (used after the transform)
     const int act = valid ? p.actions[e] : -1;
     const int tix = valid ? p.env_time[e] + p.time_offset : 0;
+    SSA_TR(0);
+#ifdef SSA_TRACE
+    if (FAST && lane == 0 && tile < 16384) {
+        unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_trace[tile * 16 + 15] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
 
-    if (FAST) load_tile(t, p, lane, base, cnt);
+    if (FAST) tile_commit(t, pf, lane);   // the tile's inputs were requested one tile ago (or by the kernel prologue)
     else load_object(t, p, g, l, valid ? obj : 0, valid);
     wave_lds_sync();
+    SSA_TR(1);
 
     const int st_in = t.St[g];
     const bool active = valid && st_in == SSA_ST_OK;
@@ -557,6 +605,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     const int rung = robust_chol_row_lds(t, C.scale, g, l);
 #endif
     wave_lds_sync();
+    SSA_TR(2);
     const bool chol_fail = (rung == 16);
     const bool is_sigma = (l <= 12);
     const bool is_pm = (l >= 1 && l <= 12);
@@ -584,7 +633,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
             const J2Params jq = {C.j2, C.r_eq, C.rk4_substeps};
             kep_ok = propagate_j2_rk4(s, C.dt, jq, o);
         } else {
-            kep_ok = kepler_step_fast<PROP == 2 ? 1 : PROP>(s, C.dt, o);
+            kep_ok = kepler_step_fast<PROP == 2 ? 1 : PROP, FAST ? 1 : 0>(s, C.dt, o);
         }
 #endif
         if (PROP != 0) {
@@ -606,6 +655,9 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         }
     }
     wave_lds_sync();   // every lane has consumed t.X / t.T / t.U
+    SSA_TR(3);
+    // the next tile's inputs: in flight during the transform / covariance / observation / store of this one
+    if (FAST) tile_issue(pf, p, lane, next_base, next_cnt);
 
     // ---- U3: unscented transform, centred form of x = dot(Wm, sigmas_f):
     //   x = sigma_0' + m',   m' = (sum(Wm) - 1) sigma_0' + Wi sum_{i>=1} (sigma_i' - sigma_0')
@@ -629,10 +681,12 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         if (l == 13) t.T[g * 6 + c] = o[c];   // x_true[i]
     }
     wave_lds_sync();
+    SSA_TR(4);
 #if !(defined(SSA_ABLATE) && (SSA_ABLATE & 4))
     covariance_rows(t, C, g, l);
 #endif
     wave_lds_sync();
+    SSA_TR(5);
 
     int st_new = st_in;
     if (active) {
@@ -816,6 +870,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
 
     // ---- F1: failed filters carry the sentinels (ssa_tasker_simple_2.py:157-158, 369-382)
     wave_lds_sync();
+    SSA_TR(6);
     if (valid && st_new != SSA_ST_OK && st_in == SSA_ST_OK) {
         for (int idx = l; idx < 36; idx += 16) {
             int a = idx / 6, b = idx - a * 6;
@@ -844,18 +899,24 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     wave_lds_sync();
     observe_rows(t, g, l);
     wave_lds_sync();
+    SSA_TR(7);
     if (FAST) {
         store_tile(t, p, lane, base, cnt);
+        SSA_TR(8);
         if (p.stat_shards && !p.aer_out && PROP != 0 && lane == 0) {
             // O3 by sharded atomics: max delta_pos (as ordered bits: non-negative doubles and NaN order like
             // unsigned integers, so NaN wins exactly as in np.max), trinary counts, failures
             int64_t e_cur = -1;
             unsigned long long mx = 0ull, cnts = 0ull, nf = 0ull;
+            const int64_t e_first = (p.n_env > 1) ? (int64_t)((uint32_t)base / (uint32_t)p.n_obj) : 0;
+            int64_t j_run = base - e_first * p.n_obj, e_run = e_first;   // (env, index) of row gg, advanced without dividing
             for (int gg = 0; gg <= cnt; ++gg) {
-                const int64_t eg = (gg < cnt) ? (base + gg) / p.n_obj : -2;
+                while (j_run >= p.n_obj) { j_run -= p.n_obj; ++e_run; }
+                const int64_t eg = (gg < cnt) ? e_run : -2;
+                ++j_run;
                 if (eg != e_cur) {
                     if (e_cur >= 0) {
-                        unsigned long long* sh = (unsigned long long*)p.stat_shards + ((e_cur * SSA_STAT_SHARDS) + (blockIdx.x & (SSA_STAT_SHARDS - 1))) * 4;
+                        unsigned long long* sh = (unsigned long long*)p.stat_shards + ((e_cur * SSA_STAT_SHARDS) + (tile & (SSA_STAT_SHARDS - 1))) * 4;
                         atomicMax(sh, mx);
                         atomicAdd(sh + 1, cnts);
                         if (nf) atomicAdd(sh + 2, nf);
@@ -871,6 +932,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                 }
             }
         }
+        SSA_TR(9);
     } else {
         store_object(t, p, g, l, obj, valid, e, j, true);
         if (valid && l == 0 && p.aer_out) aer_obs_row(&t.X[g * 6], &t.P[g * 36], p, C, e, obj);
@@ -885,19 +947,40 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     }
 }
 
-#ifndef SSA_STEP_WAVES
-#define SSA_STEP_WAVES 4   // minimum waves per SIMD the register allocator must leave room for (<= 128 VGPRs; 5 spills)
-#endif
+// Grid-stride over tiles: wavefront w advances tiles w, w + G, w + 2G, ... (G = gridDim.x, chosen by the
+// launcher so that every wavefront is resident at once and all get the same number of tiles) with the
+// next tile's loads issued while the current one is being worked on.
+//
+typedef const __attribute__((address_space(4))) StepK* KernargPtr;
 template <int PROP>
-__global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(const StepK k)
+__global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(const StepK k_arg, int ntiles)
 {
     __shared__ Tiles t;
-    const int lane = threadIdx.x;
-    const int64_t total = (int64_t)k.p.n_env * k.p.n_obj;
-    const int64_t base = (int64_t)blockIdx.x * OBJ_PER_WAVE;
-    const int cnt = (int)((total - base) < OBJ_PER_WAVE ? (total - base) : OBJ_PER_WAVE);
+    int lane = threadIdx.x;
+    const int64_t total = (int64_t)k_arg.p.n_env * k_arg.p.n_obj;
     StatAcc unused = stat_identity();
-    process_wave<PROP, true>(t, k.c, k.p, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, unused);
+    TileRegs pf;
+    int tile = blockIdx.x;
+    {
+        const int64_t b0 = (int64_t)tile * OBJ_PER_WAVE;
+        tile_issue(pf, k_arg.p, lane, b0, tile < ntiles ? (int)((total - b0) < OBJ_PER_WAVE ? (total - b0) : OBJ_PER_WAVE) : 0);
+    }
+    KernargPtr kp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    for (; tile < ntiles; tile += gridDim.x) {
+        // the body must compile like a one-tile kernel: re-derive the argument block and the lane id per
+        // tile, so that the ~100 argument scalars and the lane-derived LDS addresses are produced on demand
+        // instead of being hoisted out of the loop into registers that spill
+        asm volatile("" : "+s"(kp));
+        asm volatile("" : "+v"(lane));
+        const StepK& k = *(const StepK*)kp;
+        const int64_t base = (int64_t)tile * OBJ_PER_WAVE;
+        const int cnt = (int)((total - base) < OBJ_PER_WAVE ? (total - base) : OBJ_PER_WAVE);
+        const int nt = tile + gridDim.x;
+        const int64_t nbase = (int64_t)nt * OBJ_PER_WAVE;
+        const int ncnt = nt < ntiles ? (int)((total - nbase) < OBJ_PER_WAVE ? (total - nbase) : OBJ_PER_WAVE) : 0;
+        process_wave<PROP, true>(t, k.c, k.p, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, unused, pf, nbase, ncnt, tile);
+        wave_lds_sync();   // the tile's LDS reads (store) precede the next tile's commit
+    }
 }
 
 // Post kernel, grid (nparts, n_env) x 256 threads: (1) the queued objects of this env with complete
@@ -916,13 +999,14 @@ __global__ void __launch_bounds__(POST_T) step_post_kernel(const StepK k, StatAc
     const int e = blockIdx.y;
     const int64_t m = p.n_obj, N = (int64_t)p.n_env * p.n_obj;
     StatAcc acc = stat_identity();
+    TileRegs pf_unused;
     const int n_listed = (int)((int64_t)p.work[0] < N ? (int64_t)p.work[0] : N);
     const int waves_total = nparts * (POST_T / 64);
     for (int it = blockIdx.x * (POST_T / 64) + w; it * OBJ_PER_WAVE < n_listed; it += waves_total) {
         const int idx = it * OBJ_PER_WAVE + (lane >> 4);
         int64_t obj = (idx < n_listed) ? (int64_t)p.work[4 + idx] : -1;
         if (obj >= 0 && obj / m != e) obj = -1;   // another env's block takes it
-        process_wave<PROP, false>(tiles[w], C, p, lane, obj < 0 ? 0 : obj, obj >= 0, 0, 0, acc);
+        process_wave<PROP, false>(tiles[w], C, p, lane, obj < 0 ? 0 : obj, obj >= 0, 0, 0, acc, pf_unused, 0, 0, 0);
         wave_lds_sync();
     }
     if (p.aer_out) {   // O4 for every object of this block's slice that was not re-done above
@@ -1350,6 +1434,9 @@ using namespace ssa;
 extern "C" {
 
 int ssa_abi_version(void) { return SSA_ABI_VERSION; }
+#ifdef SSA_TRACE
+int ssa_debug_trace_copy(void* host, int64_t nbytes) { return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), (size_t)nbytes) == hipSuccess ? 0 : -1; }
+#endif
 const char* ssa_build_info(void) { return "libssa_hip gfx950 fp64 (" __DATE__ " " __TIME__ ")"; }
 
 // one wave per env: folds the SSA_STAT_SHARDS accumulators of the atomics path into stats and clears them
@@ -1378,6 +1465,16 @@ __global__ void __launch_bounds__(64) reward_fold_kernel(unsigned long long* __r
     }
 }
 
+static int device_cu_count()
+{
+    static int cached = 0;   // per process: one GPU per process (the launcher model of this library)
+    if (cached <= 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached = n;
+    }
+    return cached;
+}
 static int post_parts(int64_t n_obj, int32_t n_env)
 {
     int64_t want = (n_obj + (int64_t)POST_T * POST_ILP - 1) / ((int64_t)POST_T * POST_ILP);
@@ -1400,7 +1497,11 @@ int ssa_env_step_f64(const ssa_consts* c, const ssa_step_params* p, void* stream
     k.p = *p;
     const int64_t total = (int64_t)p->n_env * p->n_obj;
     if (total >= ((int64_t)1 << 31)) return SSA_E_INVALID;
-    dim3 grid(nblk(total, OBJ_PER_WAVE)), block(64);
+    // tiles per wavefront T = ceil(tiles / resident wavefront slots); G = ceil(tiles / T) wavefronts
+    const int64_t ntiles = (total + OBJ_PER_WAVE - 1) / OBJ_PER_WAVE;
+    const int64_t slots = (int64_t)device_cu_count() * 4 * SSA_STEP_WAVES;
+    const int64_t per_wave = (ntiles + slots - 1) / slots;
+    dim3 grid((unsigned)((ntiles + per_wave - 1) / per_wave)), block(64);
     const int nparts = post_parts(p->n_obj, p->n_env);
     StatAcc* parts = (StatAcc*)p->stat_ws;
     hipStream_t s = (hipStream_t)stream;
@@ -1409,9 +1510,9 @@ int ssa_env_step_f64(const ssa_consts* c, const ssa_step_params* p, void* stream
     if (c->propagator == SSA_PROP_J2_RK4 && (c->rk4_substeps < 1 || c->rk4_substeps > 4096)) return SSA_E_INVALID;
     const int prop = c->propagator;
     if (mask & 1u) {
-        if (prop == SSA_PROP_FG) hipLaunchKernelGGL(step_fast_kernel<1>, grid, block, 0, s, k);
-        else if (prop == SSA_PROP_ELEMENTS) hipLaunchKernelGGL(step_fast_kernel<0>, grid, block, 0, s, k);
-        else hipLaunchKernelGGL(step_fast_kernel<2>, grid, block, 0, s, k);
+        if (prop == SSA_PROP_FG) hipLaunchKernelGGL(step_fast_kernel<1>, grid, block, 0, s, k, (int)ntiles);
+        else if (prop == SSA_PROP_ELEMENTS) hipLaunchKernelGGL(step_fast_kernel<0>, grid, block, 0, s, k, (int)ntiles);
+        else hipLaunchKernelGGL(step_fast_kernel<2>, grid, block, 0, s, k, (int)ntiles);
     }
     const bool fast_stats = p->stat_shards && !p->aer_out && prop != SSA_PROP_ELEMENTS;
     if (fast_stats) {   // statistics were accumulated by the common-path kernel: fold, done (2 launches)

@@ -6,6 +6,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#ifndef SSA_STEP_WAVES
+#define SSA_STEP_WAVES 5   // waves per SIMD the step kernel (and its out-of-line callees) must leave room for:
+                           // 96 VGPRs; 256 CUs x 4 SIMDs x 5 = 5120 resident wavefronts = 20 480 objects in one round
+#endif
 namespace ssa {
 
 constexpr double MU = 398600441800000.0;  // farnocchia.py:1060 (k hard-coded)
@@ -378,8 +382,11 @@ SSA_DEV bool kepler_fg_core(const double* x, double tof, double r0, double inv_r
 
 struct Vec7 { double v[7]; };   // propagated state + ok flag (1.0 / 0.0)
 // hyperbolic f,g or universal-variable band solve for one state (out of line, by value)
+// (TAG gives the step kernel its own instance, so that the callee inherits that kernel's register budget)
+template <int TAG>
 __device__ __noinline__ Vec7 kepler_nonelliptic_v(Vec6 x, double tof, double r0, double alpha, double rv, int band);
 
+template <int TAG = 0>
 SSA_DEV bool kepler_fg_fast(const double* x, double tof, double* out)
 {
     const double inv_sqrt_mu = 1.0 / sqrt(MU), inv_mu = 1.0 / MU;
@@ -402,7 +409,7 @@ SSA_DEV bool kepler_fg_fast(const double* x, double tof, double* out)
             Vec6 xi;
 #pragma unroll
             for (int i = 0; i < 6; ++i) xi.v[i] = x[i];
-            Vec7 o = kepler_nonelliptic_v(xi, tof, r0, alpha, rv, band ? 1 : 0);
+            Vec7 o = kepler_nonelliptic_v<TAG>(xi, tof, r0, alpha, rv, band ? 1 : 0);
 #pragma unroll
             for (int i = 0; i < 6; ++i) out[i] = o.v[i];
             ok = o.v[6] != 0.0;
@@ -479,10 +486,10 @@ SSA_DEV bool propagate_j2_rk4(const double* x, double tof, const J2Params& q, do
     return (out[0] == out[0]) && (out[3] == out[3]);
 }
 
-template <int PROP>
+template <int PROP, int TAG = 0>
 SSA_DEV bool kepler_step_fast(const double* x, double tof, double* out)
 {
-    if (PROP == 1) return kepler_fg_fast(x, tof, out);
+    if (PROP == 1) return kepler_fg_fast<TAG>(x, tof, out);
     return kepler_elements_fast(x, tof, out);
 }
 
