@@ -179,12 +179,14 @@ def main():
     # of the fused step kernel alone (no statistics kernel, no collective)
     roof = None
     if rank == 0:
-        # whole steps as in the timed region, with an event pair around every launch of the dominant
-        # kernel (launch_mask splits the call: 1 = common-path kernel, 6 = post + final kernels)
+        # whole steps as in the timed region; every launch of the dominant kernel is timed by its own
+        # dispatch timestamps (HIP events bound to the launch, on the launch stream)
         p = eng._p
         nl = min(K, 480)
         s = torch.cuda.current_stream().cuda_stream
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nl)]
+        import ctypes
+        ms = ctypes.c_float(0.0)
+        tot_ms = 0.0
         tick = local.tick
         torch.cuda.synchronize()
         for k in range(nl):
@@ -200,19 +202,20 @@ def main():
             p.obs, p.metrics = eng._bo + sout * eng._so, eng._bm + sout * eng._sm
             p.upd, p.stats = eng._bu + sout * eng._su, eng._bs + sout * eng._ss
             p.actions = local._sched.data_ptr() + 4 * (k % local._sched.numel())
-            p.launch_mask = 1
+            p.launch_mask = 0
             p.stat_shards = eng.stat_shards.data_ptr()
             p.aer_out = 0
-            evs[k][0].record()
-            eng._lib.ssa_env_step_f64(eng._cref, eng._pref, s)
-            evs[k][1].record()
-            p.launch_mask = 6
-            p.stat_shards = eng.stat_shards.data_ptr()
-            eng._lib.ssa_env_step_f64(eng._cref, eng._pref, s)
+            # the whole step as in the timed region, back to back; slot k times launch k by its dispatch timestamps
+            rc = eng._lib.ssa_env_step_profiled_f64(eng._cref, eng._pref, s, k)
+            if rc != 0:
+                raise SystemExit("ssa_env_step_profiled_f64 failed: %d" % rc)
         torch.cuda.synchronize()
-        p.launch_mask = 0
+        for k in range(nl):
+            if eng._lib.ssa_env_step_profile_ms(k, ctypes.byref(ms)) != 0:
+                raise SystemExit("ssa_env_step_profile_ms failed")
+            tot_ms += ms.value
         local.tick = tick
-        kern_ms = sum(a.elapsed_time(b) for a, b in evs) / nl
+        kern_ms = tot_ms / nl
         alg_bytes = ALG_BYTES_PER_OBJECT_STEP * m
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic = None

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SSA_ABI_VERSION 8
+#define SSA_ABI_VERSION 9
 
 /* error codes */
 #define SSA_OK 0
@@ -144,6 +144,15 @@ typedef struct ssa_step_params {
  * that re-does the queued objects with complete semantics and reduces the reward statistics per
  * block; (3) a one-wave kernel that folds the statistics and resets the queue. */
 int ssa_env_step_f64(const ssa_consts *c_host, const ssa_step_params *p_host, void *stream);
+/* Same step, with the dominant launch (the common-path kernel) bracketed by the event pair `slot`
+ * (0 <= slot < SSA_PROFILE_SLOTS) bound to that dispatch: ssa_env_step_profile_ms() then returns the kernel's
+ * duration from its own begin/end timestamps -- what rocprofv3 --kernel-trace reports -- without the queue having
+ * been drained between launches.  Measurement aid of bench.py's roofline line (an event pair recorded around the
+ * call would add the queue latency of the records, ~10 us). */
+#define SSA_PROFILE_SLOTS 1024
+int ssa_env_step_profiled_f64(const ssa_consts *c_host, const ssa_step_params *p_host, void *stream, int32_t slot);
+/* waits for slot's kernel and writes its duration in milliseconds */
+int ssa_env_step_profile_ms(int32_t slot, float *kernel_ms);
 /* bytes of the int32 `work` buffer for n_env environments of n_obj objects */
 int64_t ssa_env_step_work_bytes(int64_t n_obj, int32_t n_env);
 

@@ -23,7 +23,7 @@ consts = host.make_consts(pb["Q"], pb["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, pb[
 z = torch.zeros((1, 480, m, 3), dtype=torch.float64, device='cuda')
 eng = engine.HotPathEngine(consts, m, 1, pb["trans"], z, history=2)
 eng.load_state(0, pb["x_true"], pb["x"], np.broadcast_to(pb["P0"], (m, 6, 6)))
-local = parallel.HipLocalStepper(eng, consts)
+local = parallel.HipLocalStepper(eng, consts, fast_stats=True)
 local.load_schedule(np.arange(400) % m)
 for k in range(200):          # healthy part of an episode
     local.step(-1)

@@ -10,6 +10,7 @@
 // with block-contiguous (fully coalesced) global loads and stores; the 13-point mean is a
 // DPP row reduction; the covariance outer products run from LDS.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/ssa_hip.h"
@@ -568,7 +569,7 @@ __device__ unsigned long long g_trace[16384 * 16];
 //                 status left untouched.  No out-of-line calls -> small register budget.
 //   FAST = false: complete semantics for arbitrary objects (the queue), per-row I/O; the row's
 //                 metrics are folded into `acc` (reward statistics of queued objects).
-template <int PROP, bool FAST>
+template <int PROP, bool FAST, bool MULTI>
 SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& p, int lane, int64_t obj, bool valid,
                           int64_t base, int cnt, StatAcc& acc, TileRegs& pf, int64_t next_base, int next_cnt, int tile)
 {
@@ -588,7 +589,10 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     }
 #endif
 
-    if (FAST) tile_commit(t, pf, lane);   // the tile's inputs were requested one tile ago (or by the kernel prologue)
+    if (FAST) {
+        if (!MULTI) tile_issue(pf, p, lane, base, cnt);   // one tile per wavefront: plain load, no staging registers kept
+        tile_commit(t, pf, lane);                        // MULTI: requested one tile ago (or by the kernel prologue)
+    }
     else load_object(t, p, g, l, valid ? obj : 0, valid);
     wave_lds_sync();
     SSA_TR(1);
@@ -657,7 +661,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     wave_lds_sync();   // every lane has consumed t.X / t.T / t.U
     SSA_TR(3);
     // the next tile's inputs: in flight during the transform / covariance / observation / store of this one
-    if (FAST) tile_issue(pf, p, lane, next_base, next_cnt);
+    if (FAST && MULTI) tile_issue(pf, p, lane, next_base, next_cnt);
 
     // ---- U3: unscented transform, centred form of x = dot(Wm, sigmas_f):
     //   x = sigma_0' + m',   m' = (sum(Wm) - 1) sigma_0' + Wi sum_{i>=1} (sigma_i' - sigma_0')
@@ -951,8 +955,10 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
 // launcher so that every wavefront is resident at once and all get the same number of tiles) with the
 // next tile's loads issued while the current one is being worked on.
 //
+// MULTI = false is the one-tile-per-wavefront instance (every launch up to 20 480 objects): no loop, no staging
+// registers.
 typedef const __attribute__((address_space(4))) StepK* KernargPtr;
-template <int PROP>
+template <int PROP, bool MULTI>
 __global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(const StepK k_arg, int ntiles)
 {
     __shared__ Tiles t;
@@ -961,6 +967,12 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(const Ste
     StatAcc unused = stat_identity();
     TileRegs pf;
     int tile = blockIdx.x;
+    if (!MULTI) {
+        const int64_t base = (int64_t)tile * OBJ_PER_WAVE;
+        const int cnt = (int)((total - base) < OBJ_PER_WAVE ? (total - base) : OBJ_PER_WAVE);
+        process_wave<PROP, true, false>(t, k_arg.c, k_arg.p, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, unused, pf, 0, 0, tile);
+        return;
+    }
     {
         const int64_t b0 = (int64_t)tile * OBJ_PER_WAVE;
         tile_issue(pf, k_arg.p, lane, b0, tile < ntiles ? (int)((total - b0) < OBJ_PER_WAVE ? (total - b0) : OBJ_PER_WAVE) : 0);
@@ -969,7 +981,7 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(const Ste
     for (; tile < ntiles; tile += gridDim.x) {
         // the body must compile like a one-tile kernel: re-derive the argument block and the lane id per
         // tile, so that the ~100 argument scalars and the lane-derived LDS addresses are produced on demand
-        // instead of being hoisted out of the loop into registers that spill
+        // instead of being carried around the loop in registers
         asm volatile("" : "+s"(kp));
         asm volatile("" : "+v"(lane));
         const StepK& k = *(const StepK*)kp;
@@ -978,7 +990,7 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(const Ste
         const int nt = tile + gridDim.x;
         const int64_t nbase = (int64_t)nt * OBJ_PER_WAVE;
         const int ncnt = nt < ntiles ? (int)((total - nbase) < OBJ_PER_WAVE ? (total - nbase) : OBJ_PER_WAVE) : 0;
-        process_wave<PROP, true>(t, k.c, k.p, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, unused, pf, nbase, ncnt, tile);
+        process_wave<PROP, true, true>(t, k.c, k.p, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, unused, pf, nbase, ncnt, tile);
         wave_lds_sync();   // the tile's LDS reads (store) precede the next tile's commit
     }
 }
@@ -1006,7 +1018,7 @@ __global__ void __launch_bounds__(POST_T) step_post_kernel(const StepK k, StatAc
         const int idx = it * OBJ_PER_WAVE + (lane >> 4);
         int64_t obj = (idx < n_listed) ? (int64_t)p.work[4 + idx] : -1;
         if (obj >= 0 && obj / m != e) obj = -1;   // another env's block takes it
-        process_wave<PROP, false>(tiles[w], C, p, lane, obj < 0 ? 0 : obj, obj >= 0, 0, 0, acc, pf_unused, 0, 0, 0);
+        process_wave<PROP, false, false>(tiles[w], C, p, lane, obj < 0 ? 0 : obj, obj >= 0, 0, 0, acc, pf_unused, 0, 0, 0);
         wave_lds_sync();
     }
     if (p.aer_out) {   // O4 for every object of this block's slice that was not re-done above
@@ -1485,7 +1497,7 @@ static int post_parts(int64_t n_obj, int32_t n_env)
     return (int)want;
 }
 
-int ssa_env_step_f64(const ssa_consts* c, const ssa_step_params* p, void* stream)
+static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stream, hipEvent_t ev0, hipEvent_t ev1)
 {
     if (!c || !p || p->n_obj <= 0 || p->n_env <= 0) return SSA_E_INVALID;
     if (!p->x_true_in || !p->x_true_out || !p->x_in || !p->x_out || !p->P_in || !p->P_out || !p->status ||
@@ -1509,10 +1521,17 @@ int ssa_env_step_f64(const ssa_consts* c, const ssa_step_params* p, void* stream
     if (c->propagator != SSA_PROP_FG && c->propagator != SSA_PROP_ELEMENTS && c->propagator != SSA_PROP_J2_RK4) return SSA_E_INVALID;
     if (c->propagator == SSA_PROP_J2_RK4 && (c->rk4_substeps < 1 || c->rk4_substeps > 4096)) return SSA_E_INVALID;
     const int prop = c->propagator;
-    if (mask & 1u) {
-        if (prop == SSA_PROP_FG) hipLaunchKernelGGL(step_fast_kernel<1>, grid, block, 0, s, k, (int)ntiles);
-        else if (prop == SSA_PROP_ELEMENTS) hipLaunchKernelGGL(step_fast_kernel<0>, grid, block, 0, s, k, (int)ntiles);
-        else hipLaunchKernelGGL(step_fast_kernel<2>, grid, block, 0, s, k, (int)ntiles);
+    if (mask & 1u) {   // (ev0, ev1: dispatch timestamps of this kernel for ssa_env_step_profiled_f64, else null)
+        const int nt = (int)ntiles;
+        if (per_wave == 1) {
+            if (prop == SSA_PROP_FG) hipExtLaunchKernelGGL((step_fast_kernel<1, false>), grid, block, 0, s, ev0, ev1, 0, k, nt);
+            else if (prop == SSA_PROP_ELEMENTS) hipExtLaunchKernelGGL((step_fast_kernel<0, false>), grid, block, 0, s, ev0, ev1, 0, k, nt);
+            else hipExtLaunchKernelGGL((step_fast_kernel<2, false>), grid, block, 0, s, ev0, ev1, 0, k, nt);
+        } else {
+            if (prop == SSA_PROP_FG) hipExtLaunchKernelGGL((step_fast_kernel<1, true>), grid, block, 0, s, ev0, ev1, 0, k, nt);
+            else if (prop == SSA_PROP_ELEMENTS) hipExtLaunchKernelGGL((step_fast_kernel<0, true>), grid, block, 0, s, ev0, ev1, 0, k, nt);
+            else hipExtLaunchKernelGGL((step_fast_kernel<2, true>), grid, block, 0, s, ev0, ev1, 0, k, nt);
+        }
     }
     const bool fast_stats = p->stat_shards && !p->aer_out && prop != SSA_PROP_ELEMENTS;
     if (fast_stats) {   // statistics were accumulated by the common-path kernel: fold, done (2 launches)
@@ -1530,6 +1549,30 @@ int ssa_env_step_f64(const ssa_consts* c, const ssa_step_params* p, void* stream
         hipLaunchKernelGGL(reward_final_kernel, dim3(p->n_env), dim3(64), 0, s, (const StatAcc*)parts, p->stats,
                            p->stats ? nparts : 0, p->work);
     return launch_status();
+}
+int ssa_env_step_f64(const ssa_consts* c, const ssa_step_params* p, void* stream)
+{
+    return step_launch(c, p, stream, nullptr, nullptr);
+}
+// dispatch-timestamp event pairs, created on first use (a ring, so that back-to-back launches can be timed
+// without draining the queue after each of them)
+static hipEvent_t g_prof_ev[SSA_PROFILE_SLOTS][2];
+static bool g_prof_made[SSA_PROFILE_SLOTS];
+int ssa_env_step_profiled_f64(const ssa_consts* c, const ssa_step_params* p, void* stream, int32_t slot)
+{
+    if (slot < 0 || slot >= SSA_PROFILE_SLOTS) return SSA_E_INVALID;
+    if (!g_prof_made[slot]) {
+        if (hipEventCreate(&g_prof_ev[slot][0]) != hipSuccess || hipEventCreate(&g_prof_ev[slot][1]) != hipSuccess) return SSA_E_LAUNCH;
+        g_prof_made[slot] = true;
+    }
+    return step_launch(c, p, stream, g_prof_ev[slot][0], g_prof_ev[slot][1]);
+}
+int ssa_env_step_profile_ms(int32_t slot, float* kernel_ms)
+{
+    if (slot < 0 || slot >= SSA_PROFILE_SLOTS || !kernel_ms || !g_prof_made[slot]) return SSA_E_INVALID;
+    if (hipEventSynchronize(g_prof_ev[slot][1]) != hipSuccess ||
+        hipEventElapsedTime(kernel_ms, g_prof_ev[slot][0], g_prof_ev[slot][1]) != hipSuccess) return SSA_E_LAUNCH;
+    return SSA_OK;
 }
 int64_t ssa_env_step_work_bytes(int64_t n_obj, int32_t n_env)
 {

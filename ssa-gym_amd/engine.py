@@ -58,6 +58,14 @@ class HotPathEngine:
         self._p.status = self.status.data_ptr()
         self._p.trans = self.trans.data_ptr()
         self._p.env_time = self.env_time0.data_ptr()
+        # the kernel indexes z_noise[e*stride_env + (i % n_time)*stride_time + a*stride_obj + 0..2]: check the extent here
+        need = (self.E - 1) * self.zn_stride_env + (self.n_time - 1) * self.zn_stride_time + (self.m - 1) * int(zn_stride_obj) + 3
+        if min(self.zn_stride_env, self.zn_stride_time, int(zn_stride_obj)) < 0 or self.z_noise.numel() < need \
+                or self.z_noise.dtype != torch.float64 or not self.z_noise.is_contiguous():
+            raise _lib.SsaHipError("z_noise: %d contiguous float64 values needed for (n_env=%d, n_time=%d, n_obj=%d) with strides "
+                                   "(%d, %d, %d), got %s of %d" % (need, self.E, self.n_time, self.m, self.zn_stride_env,
+                                                                   self.zn_stride_time, int(zn_stride_obj), self.z_noise.dtype,
+                                                                   self.z_noise.numel()))
         self._p.z_noise = self.z_noise.data_ptr()
         self._p.zn_stride_env, self._p.zn_stride_time = self.zn_stride_env, self.zn_stride_time
         self._p.zn_stride_obj = int(zn_stride_obj)

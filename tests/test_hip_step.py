@@ -424,3 +424,63 @@ def test_two_launch_statistics_path_matches_exact_path(hip, E, m):
         assert s1[e, L.STAT_ARGMAX_SPOS] == -1.0 and np.isnan(s1[e, L.STAT_MAX_SPOS])
         assert s0[e, L.STAT_ARGMAX_SPOS] == np.nanargmax(np.where(np.isnan(m0[e, 2]), np.inf, m0[e, 2]))
     assert np.isnan(s0[0, L.STAT_MAX_DPOS]) and s0[0, L.STAT_N_FAILED] >= 1 and s0[E - 1, L.STAT_N_FAILED] >= 1
+
+
+@pytest.mark.parametrize("E,m,fast", [(1, 61443, False), (1, 61443, True), (8, 7001, True), (3, 20001, False)])
+def test_multi_tile_wavefronts_equal_single_tile_results(hip, E, m, fast):
+    """Above 20 480 objects a wavefront advances several tiles (grid-stride, next tile's loads in flight).
+    An object's result must not depend on the batch it travels in: every env of a large batch is compared
+    BITWISE with the same env run alone where one wavefront owns exactly one tile (<= 20 480 objects),
+    statistics included; ragged sizes put the last tile and the env boundaries inside a wavefront's tile."""
+    L = hip.lib
+    xt, x, P, g = make_batch(E * m, seed=77)
+    x[5, 1] = np.nan                                    # a failure, so statistics are not all-zero
+    consts = hip.host.make_consts(g["Q"], g["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, g["obs_lla"])
+    acts = [(977 * e + 13) % m for e in range(E)]
+    n_time = c2t().shape[0]
+
+    def run(lo, n_env, n_obj, actions):
+        zn = hip.torch.zeros((n_time, n_obj, 3), dtype=hip.torch.float64, device="cuda")   # shared by the envs (stride 0)
+        eng = hip.engine.HotPathEngine(consts, n_obj, n_env, c2t(), zn, history=2, zn_stride_env=0)
+        sl = slice(lo, lo + n_env * n_obj)
+        eng.load_state(0, xt[sl], x[sl], P[sl])
+        eng.set_actions(actions)
+        eng.launch_step(0, 1, 2, fast_stats=fast)
+        hip.torch.cuda.synchronize()
+        return [t.cpu().numpy() for t in (eng.x_true[1], eng.x_filter[1], eng.P_filter[1], eng.obs[1], eng.metrics[1],
+                                          eng.status, eng.stats[1])]
+    big = run(0, E, m, acts)
+    chunk = 20000 if m > 20000 else m                   # one tile per wavefront below 20 480 objects
+    for e in range(E):
+        if m <= 20480:
+            ref = run(e * m, 1, m, [acts[e]])
+            for k in (0, 1, 2, 3, 5):
+                assert np.array_equal(big[k].reshape((E, m) + big[k].shape[1:])[e] if k != 5 else big[5].reshape(E, m)[e],
+                                      ref[k].reshape((m,) + ref[k].shape[1:]) if k != 5 else ref[5].reshape(m), equal_nan=True), (e, k)
+            assert np.array_equal(big[4][e], ref[4][0], equal_nan=True)
+            for s in (L.STAT_MAX_DPOS, L.STAT_CNT_LT_1E4, L.STAT_CNT_LT_1E7, L.STAT_N_FAILED):
+                assert np.array_equal(big[6][e, s], ref[6][0, s], equal_nan=True), (e, s)
+        else:
+            # pieces of the env (the selected object's piece gets the action, the others none)
+            for lo in range(0, m, chunk):
+                n = min(chunk, m - lo)
+                a = acts[e] - lo if lo <= acts[e] < lo + n else -1
+                ref = run(e * m + lo, 1, n, [a])
+                for k in (0, 1, 2, 3):
+                    assert np.array_equal(big[k].reshape((E, m) + big[k].shape[1:])[e, lo:lo + n], ref[k].reshape((n,) + ref[k].shape[1:]),
+                                          equal_nan=True), (e, lo, k)
+                assert np.array_equal(big[5].reshape(E, m)[e, lo:lo + n], ref[5].reshape(n))
+                assert np.array_equal(big[4][e][:, lo:lo + n], ref[4][0], equal_nan=True)
+    mt = big[4]                                          # statistics of the large batch against numpy on its metrics
+    for e in range(E):
+        assert np.array_equal(big[6][e, L.STAT_MAX_DPOS], np.max(mt[e, 0]), equal_nan=True)
+        assert big[6][e, L.STAT_CNT_LT_1E4] == np.sum(mt[e, 0] < 1e4) and big[6][e, L.STAT_CNT_LT_1E7] == np.sum(mt[e, 0] < 1e7)
+        assert big[6][e, L.STAT_N_FAILED] == np.sum(big[5].reshape(E, m)[e] != 0)
+
+
+def test_engine_rejects_short_noise_table(hip):
+    """operand extents are checked on the host before anything is launched (a short z_noise would be read out of bounds)."""
+    xt, x, P, g = make_batch(8, seed=3)
+    consts = hip.host.make_consts(g["Q"], g["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, g["obs_lla"])
+    with pytest.raises(hip.lib.SsaHipError):
+        hip.engine.HotPathEngine(consts, 4, 2, c2t(), np.zeros((1, 4, 4, 3)), history=2)
