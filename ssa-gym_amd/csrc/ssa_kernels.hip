@@ -907,7 +907,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     if (FAST) {
         store_tile(t, p, lane, base, cnt);
         SSA_TR(8);
-        if (p.stat_shards && !p.aer_out && PROP != 0 && lane == 0) {
+        if (p.stat_shards && PROP != 0 && lane == 0) {
             // O3 by sharded atomics: max delta_pos (as ordered bits: non-negative doubles and NaN order like
             // unsigned integers, so NaN wins exactly as in np.max), trinary counts, failures
             int64_t e_cur = -1;
@@ -995,6 +995,35 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(const Ste
     }
 }
 
+// folds the SSA_STAT_SHARDS accumulators of the atomics path of env e into stats and clears them (one wavefront)
+SSA_DEV void fold_stat_shards(unsigned long long* __restrict__ shards, double* __restrict__ stats, int e, int lane)
+{
+    unsigned long long* sh = shards + ((int64_t)e * SSA_STAT_SHARDS + lane) * 4;
+    unsigned long long mx = sh[0], cn = sh[1], nf = sh[2];
+    sh[0] = 0ull; sh[1] = 0ull; sh[2] = 0ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long m2 = __shfl_down(mx, off, 64), c2 = __shfl_down(cn, off, 64), n2 = __shfl_down(nf, off, 64);
+        mx = m2 > mx ? m2 : mx;
+        cn += c2;
+        nf += n2;
+    }
+    if (lane == 0 && stats) {
+        double* o = stats + (int64_t)e * SSA_STAT_STRIDE;
+        o[SSA_STAT_MAX_DPOS] = __longlong_as_double((long long)mx);
+        o[SSA_STAT_CNT_LT_1E4] = (double)(cn & 0xffffffffull);
+        o[SSA_STAT_CNT_LT_1E7] = (double)(cn >> 32);
+        o[SSA_STAT_ARGMAX_SPOS] = -1.0;
+        o[SSA_STAT_N_FAILED] = (double)nf;
+        o[SSA_STAT_MAX_SPOS] = __builtin_nan("");
+        o[6] = 0.0; o[7] = 0.0;
+    }
+}
+__global__ void __launch_bounds__(64) reward_fold_kernel(unsigned long long* __restrict__ shards, double* __restrict__ stats)
+{
+    fold_stat_shards(shards, stats, blockIdx.x, threadIdx.x);
+}
+
 // Post kernel, grid (nparts, n_env) x 256 threads: (1) the queued objects of this env with complete
 // semantics, 4 per wavefront per iteration; (2) this block's slice of the env's reward statistics
 // (queued objects are skipped there -- `mark` -- and folded in by the wavefront that re-did them);
@@ -1030,7 +1059,10 @@ __global__ void __launch_bounds__(POST_T) step_post_kernel(const StepK k, StatAc
             }
         }
     }
-    if (p.stats) {
+    if (p.stat_shards && PROP != 0) {
+        // statistics were accumulated by the common-path kernel (complete before this launch): fold them here
+        if (blockIdx.x == 0 && w == 0) fold_stat_shards((unsigned long long*)p.stat_shards, p.stats, e, lane);
+    } else if (p.stats) {
         const double* dpos = p.metrics + ((int64_t)e * 4 + 0) * m;
         const double* spos = p.metrics + ((int64_t)e * 4 + 2) * m;
         const int32_t* st = p.status + (int64_t)e * m;
@@ -1451,32 +1483,6 @@ int ssa_debug_trace_copy(void* host, int64_t nbytes) { return hipMemcpyFromSymbo
 #endif
 const char* ssa_build_info(void) { return "libssa_hip gfx950 fp64 (" __DATE__ " " __TIME__ ")"; }
 
-// one wave per env: folds the SSA_STAT_SHARDS accumulators of the atomics path into stats and clears them
-__global__ void __launch_bounds__(64) reward_fold_kernel(unsigned long long* __restrict__ shards, double* __restrict__ stats, int64_t m)
-{
-    const int e = blockIdx.x, t = threadIdx.x;
-    unsigned long long* sh = shards + ((int64_t)e * SSA_STAT_SHARDS + t) * 4;
-    unsigned long long mx = sh[0], cn = sh[1], nf = sh[2];
-    sh[0] = 0ull; sh[1] = 0ull; sh[2] = 0ull;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        unsigned long long m2 = __shfl_down(mx, off, 64), c2 = __shfl_down(cn, off, 64), n2 = __shfl_down(nf, off, 64);
-        mx = m2 > mx ? m2 : mx;
-        cn += c2;
-        nf += n2;
-    }
-    if (t == 0 && stats) {
-        double* o = stats + (int64_t)e * SSA_STAT_STRIDE;
-        o[SSA_STAT_MAX_DPOS] = __longlong_as_double((long long)mx);
-        o[SSA_STAT_CNT_LT_1E4] = (double)(cn & 0xffffffffull);
-        o[SSA_STAT_CNT_LT_1E7] = (double)(cn >> 32);
-        o[SSA_STAT_ARGMAX_SPOS] = -1.0;
-        o[SSA_STAT_N_FAILED] = (double)nf;
-        o[SSA_STAT_MAX_SPOS] = __builtin_nan("");
-        o[6] = 0.0; o[7] = 0.0;
-    }
-}
-
 static int device_cu_count()
 {
     static int cached = 0;   // per process: one GPU per process (the launcher model of this library)
@@ -1533,10 +1539,10 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
             else hipExtLaunchKernelGGL((step_fast_kernel<2, true>), grid, block, 0, s, ev0, ev1, 0, k, nt);
         }
     }
-    const bool fast_stats = p->stat_shards && !p->aer_out && prop != SSA_PROP_ELEMENTS;
-    if (fast_stats) {   // statistics were accumulated by the common-path kernel: fold, done (2 launches)
+    const bool fast_stats = p->stat_shards && prop != SSA_PROP_ELEMENTS;   // statistics by the common-path kernel's atomics
+    if (fast_stats && !p->aer_out) {   // no payload: a one-wave fold finishes the step (2 launches)
         if (mask & 6u)
-            hipLaunchKernelGGL(reward_fold_kernel, dim3(p->n_env), dim3(64), 0, s, (unsigned long long*)p->stat_shards, p->stats, p->n_obj);
+            hipLaunchKernelGGL(reward_fold_kernel, dim3(p->n_env), dim3(64), 0, s, (unsigned long long*)p->stat_shards, p->stats);
         return launch_status();
     }
     if (mask & 2u) {
@@ -1544,6 +1550,7 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
         else if (prop == SSA_PROP_ELEMENTS) hipLaunchKernelGGL(step_post_kernel<0>, dim3(nparts, p->n_env), dim3(POST_T), 0, s, k, parts, nparts);
         else hipLaunchKernelGGL(step_post_kernel<2>, dim3(nparts, p->n_env), dim3(POST_T), 0, s, k, parts, nparts);
     }
+    if (fast_stats) return launch_status();   // payload + fold were the post kernel's job (2 launches)
     // folds the per-block statistics (when requested) and resets the queue for the next step
     if (mask & 4u)
         hipLaunchKernelGGL(reward_final_kernel, dim3(p->n_env), dim3(64), 0, s, (const StatAcc*)parts, p->stats,

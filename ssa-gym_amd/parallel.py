@@ -124,6 +124,9 @@ class ShardedStepper:
         out[STAT_CNT_LT_1E7] = st[:, STAT_CNT_LT_1E7].sum()
         out[STAT_N_FAILED] = st[:, STAT_N_FAILED].sum()
         sp = st[:, STAT_MAX_SPOS]
+        if (st[:, STAT_ARGMAX_SPOS] < 0).any():      # atomics statistics path: arg-max of sigma_pos not computed
+            out[STAT_MAX_SPOS], out[STAT_ARGMAX_SPOS] = np.nan, -1.0
+            return out
         if np.isnan(sp).any():                       # np.argmax: first NaN wins
             r = int(np.where(np.isnan(sp))[0][0])
         else:
@@ -138,7 +141,7 @@ class HipLocalStepper:
 
     def __init__(self, engine, consts, fast_stats=False):
         self.engine, self.consts = engine, consts
-        self.fast_stats = fast_stats   # two-launch step (no arg-max of sigma_pos); ignored when a payload is requested
+        self.fast_stats = fast_stats   # statistics by the common-path kernel's atomics: two launches, no arg-max of sigma_pos
         self.device = engine.dev
         self.tick = 0
         self._act = torch.zeros(1, dtype=torch.int32)

@@ -393,8 +393,9 @@ def test_fused_aer_payload_matches_operator(hip, oracle):
     np.testing.assert_allclose(send[:4 * m].cpu().numpy(), o, rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("payload", [False, True])
 @pytest.mark.parametrize("E,m", [(1, 2003), (3, 50), (2, 4)])
-def test_two_launch_statistics_path_matches_exact_path(hip, E, m):
+def test_two_launch_statistics_path_matches_exact_path(hip, E, m, payload):
     """ssa_step_params.stat_shards: max delta_pos / trinary counts / failures accumulated by the common-path
     kernel with sharded atomics must equal the post+final kernels' values (arg-max is documented as absent),
     and the filter state must be identical -- including envs that straddle a wavefront (m % 4 != 0), a NaN
@@ -408,15 +409,18 @@ def test_two_launch_statistics_path_matches_exact_path(hip, E, m):
     for fast in (False, True):
         eng = hip.engine.HotPathEngine(consts, m, E, c2t(), np.zeros((E, 480, m, 3)), history=2)
         eng.load_state(0, xt, x, P)
+        aer = hip.torch.zeros((E * m, 4), dtype=hip.torch.float64, device="cuda")   # O4 payload: the fold then rides in the post kernel
+        ap = aer.data_ptr() if payload else 0
         eng.set_actions([(3 * e + 1) % m for e in range(E)])
-        eng.launch_step(0, 1, 2, fast_stats=fast)
+        eng.launch_step(0, 1, 2, fast_stats=fast, aer_out=ap)
         eng.set_actions([(3 * e + 2) % m for e in range(E)])
-        eng.launch_step(1, 0, 3, fast_stats=fast)      # second step: shards were cleared by the fold kernel
+        eng.launch_step(1, 0, 3, fast_stats=fast, aer_out=ap)   # second step: the shards were cleared by the fold
         hip.torch.cuda.synchronize()
         outs.append((eng.stats[0].cpu().numpy(), eng.x_filter[0].cpu().numpy(), eng.P_filter[0].cpu().numpy(),
-                     eng.status.cpu().numpy(), eng.metrics[0].cpu().numpy()))
-    (s0, x0, P0, st0, m0), (s1, x1, P1, st1, m1) = outs
+                     eng.status.cpu().numpy(), eng.metrics[0].cpu().numpy(), aer.cpu().numpy()))
+    (s0, x0, P0, st0, m0, a0), (s1, x1, P1, st1, m1, a1) = outs
     assert np.array_equal(st0, st1) and np.array_equal(x0, x1, equal_nan=True) and np.array_equal(P0, P1, equal_nan=True)
+    assert np.array_equal(a0, a1) and (not payload or np.abs(a0).max() > 0)
     L = hip.lib
     for e in range(E):
         for k in (L.STAT_MAX_DPOS, L.STAT_CNT_LT_1E4, L.STAT_CNT_LT_1E7, L.STAT_N_FAILED):
