@@ -504,18 +504,25 @@ SSA_DEV bool chol_row_lds(Tiles& t, double scale, double jit, int g, int l)
         if (idx < 36) ok = ok && (fabs(Pg[idx]) <= 1.79769313486231570e308);
     }
     ok = ((__ballot(!ok) >> (g * 16)) & 0xFFFFull) == 0;
+    // Lane c keeps its own column of U in registers (it wrote every entry of it itself); the only cross-lane
+    // traffic is column j read by the whole row at step j -- and from those values every lane forms the
+    // pivot redundantly, with the operations of the owning lane (same bits), instead of a broadcast.
+    const int lc = l < 6 ? l : 5;   // lanes 6..15 shadow column 5 (their stores are masked)
+    double uc[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-        double v = 1.0;
-        if (l >= j && l < 6) {
-            v = scale * Pg[j * 6 + l] + ((l == j) ? jit : 0.0);
+        double v = scale * Pg[j * 6 + lc] + ((lc == j) ? jit : 0.0);
+        double ajj = scale * Pg[j * 7] + jit;
 #pragma unroll
-            for (int i = 0; i < j; ++i) v = fma(-Ug[i * 6 + j], Ug[i * 6 + l], v);
+        for (int i = 0; i < j; ++i) {
+            const double uij = Ug[i * 6 + j];
+            v = fma(-uij, uc[i], v);
+            ajj = fma(-uij, uij, ajj);
         }
-        const double ajj = row_bcast(v, j);
         ok = ok && (ajj > 0.0);
         const double y = rsqrt_nr(ajj);
-        if (l < 6) Ug[j * 6 + l] = (l == j) ? ajj * y : (l > j ? v * y : 0.0);
+        uc[j] = (lc == j) ? ajj * y : (lc > j ? v * y : 0.0);
+        if (l < 6) Ug[j * 6 + l] = uc[j];
         wave_lds_sync();
     }
     return ok;
