@@ -126,7 +126,10 @@ def main():
     plan = parallel.ShardPlan(m * world, world, rank)
     # statistics by the two-launch path (max delta_pos, trinary counts, failures: everything the 'jones' and
     # 'trinary' rewards read); the sharded multi-GPU step needs the post kernel for its payload anyway
-    local = parallel.HipLocalStepper(eng, consts, fast_stats=True)
+    # One launch per step on a single GPU: the statistics of step k are folded by extra wavefronts riding in step
+    # k+1's launch (the last one by flush() before the closing fence), so every step's statistics exist when the
+    # timed region ends.  The sharded multi-GPU step needs them in its all-gather payload and folds at once.
+    local = parallel.HipLocalStepper(eng, consts, fast_stats=True, defer_fold=True)
     # round-robin actions over the GLOBAL catalogue (BASELINE.md protocol): a_i = i mod m_total
     total_steps = W + K
     glob_actions = np.arange(total_steps) % plan.m_total
@@ -141,17 +144,18 @@ def main():
     ep_len = n_time
     state = {"i": 0, "overlap": False}
 
-    def one_step(k):
+    def one_step(k, profile_slot=None, local_only=False):
         if state["i"] == ep_len - 1:
             local.reset_episode(snap, ep_len)
             state["i"] = 0
         state["i"] += 1
-        if sharded is not None:
+        if sharded is not None and not local_only:
             sharded.step(int(glob_actions[k]), overlap=state["overlap"])
         else:
-            local.step(-1)   # action comes from the pre-staged schedule
+            local.step(-1, profile_slot=profile_slot)   # action comes from the pre-staged schedule
 
     def fence():
+        local.flush()
         if sharded is not None:
             sharded.wait()
         torch.cuda.synchronize()
@@ -201,43 +205,15 @@ def main():
     # of the fused step kernel alone (no statistics kernel, no collective)
     roof = None
     if rank == 0:
-        # whole steps as in the timed region; every launch of the dominant kernel is timed by its own
-        # dispatch timestamps (HIP events bound to the launch, on the launch stream)
-        p = eng._p
-        nl = min(K, 480)
-        s = torch.cuda.current_stream().cuda_stream
-        import ctypes
-        ms = ctypes.c_float(0.0)
-        tot_ms = 0.0
-        tick = local.tick
+        # whole steps exactly as in the timed region, back to back; launch k of the dominant kernel is timed by the
+        # HIP event pair bound to that dispatch (on the launch stream)
+        nl = min(K, 480, _lib.PROFILE_SLOTS)
         torch.cuda.synchronize()
-        for k in range(nl):
-            if tick % ep_len == ep_len - 1:   # episode boundary: restore the initial state
-                tick += 1
-                eng.restore(tick % 2, snap)
-            tick += 1
-            p.time_offset = tick
-            sin, sout = (tick - 1) % 2, tick % 2
-            p.x_true_in, p.x_true_out = eng._bx_t + sin * eng._sx, eng._bx_t + sout * eng._sx
-            p.x_in, p.x_out = eng._bx + sin * eng._sx, eng._bx + sout * eng._sx
-            p.P_in, p.P_out = eng._bP + sin * eng._sP, eng._bP + sout * eng._sP
-            p.obs, p.metrics = eng._bo + sout * eng._so, eng._bm + sout * eng._sm
-            p.upd, p.stats = eng._bu + sout * eng._su, eng._bs + sout * eng._ss
-            p.actions = local._sched.data_ptr() + 4 * (k % local._sched.numel())
-            p.launch_mask = 0
-            p.stat_shards = eng.stat_shards.data_ptr()
-            p.aer_out = 0
-            # the whole step as in the timed region, back to back; slot k times launch k by its dispatch timestamps
-            rc = eng._lib.ssa_env_step_profiled_f64(eng._cref, eng._pref, s, k)
-            if rc != 0:
-                raise SystemExit("ssa_env_step_profiled_f64 failed: %d" % rc)
+        for k in range(nl):   # (sharded runs: the same kernel, timed on the local stepper without the collective)
+            one_step(0, profile_slot=k, local_only=True)
+        local.flush()
         torch.cuda.synchronize()
-        for k in range(nl):
-            if eng._lib.ssa_env_step_profile_ms(k, ctypes.byref(ms)) != 0:
-                raise SystemExit("ssa_env_step_profile_ms failed")
-            tot_ms += ms.value
-        local.tick = tick
-        kern_ms = tot_ms / nl
+        kern_ms = sum(eng.profile_ms(k) for k in range(nl)) / nl
         alg_bytes = ALG_BYTES_PER_OBJECT_STEP * m
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic = None

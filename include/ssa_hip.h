@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SSA_ABI_VERSION 9
+#define SSA_ABI_VERSION 10
 
 /* error codes */
 #define SSA_OK 0
@@ -123,7 +123,8 @@ typedef struct ssa_step_params {
                                   the reference layout z_noise[n][m][3] has strides (0, 3m, 3) */
     int64_t zn_stride_env, zn_stride_time, zn_stride_obj;
     int32_t n_time;            /* rows in `trans` / time rows of `z_noise` (index = i % n_time) */
-    uint32_t launch_mask;      /* 0 = everything; diagnostic: 1 common-path kernel, 2 post kernel, 4 final */
+    uint32_t launch_mask;      /* 0 = everything; diagnostic: 1 common-path kernel, 2 post kernel, 4 final;
+                                  SSA_LAUNCH_DEFER_FOLD (8): see stat_shards_prev */
     double *stats;             /* [E][SSA_STAT_STRIDE] reward statistics of this step (O3), may be NULL */
     int32_t *work;             /* ssa_env_step_work_bytes(): exception queue; zero it once before the first call */
     void *stat_ws;             /* ssa_reward_stats_workspace_bytes(): per-block statistics partials */
@@ -133,6 +134,12 @@ typedef struct ssa_step_params {
                                   fold kernel writes `stats`: two launches per step instead of three.  arg-max
                                   sigma_pos (only the 'shaped' reward needs it) is then NOT computed:
                                   stats[SSA_STAT_ARGMAX_SPOS] = -1, stats[SSA_STAT_MAX_SPOS] = NaN. */
+    uint64_t *stat_shards_prev;/* deferred fold (with SSA_LAUNCH_DEFER_FOLD in launch_mask): the shard set the PREVIOUS step
+                                  accumulated into, or NULL.  The step kernel then carries n_env extra wavefronts that fold
+                                  it into stats_prev and clear it while the objects of THIS step are being advanced, and
+                                  this step's own statistics stay in stat_shards (no fold launch: ONE launch per step) until
+                                  the next step passes them here or ssa_stats_fold_f64() folds them.  Alternate two sets. */
+    double *stats_prev;        /* [E][SSA_STAT_STRIDE] destination of that fold */
     double *aer_out;           /* [E*m][4] aer_obs() of the NEW state (O4: az, el, range, trace P; NaN/inf -> 0.001;
                                   ssa_tasker_simple_2.py:834-840), may be NULL.  Written by the post kernel, so the
                                   'aer' observation / the sharded all-gather payload costs no extra launch. */
@@ -150,9 +157,13 @@ int ssa_env_step_f64(const ssa_consts *c_host, const ssa_step_params *p_host, vo
  * been drained between launches.  Measurement aid of bench.py's roofline line (an event pair recorded around the
  * call would add the queue latency of the records, ~10 us). */
 #define SSA_PROFILE_SLOTS 1024
+#define SSA_LAUNCH_DEFER_FOLD 8u
 int ssa_env_step_profiled_f64(const ssa_consts *c_host, const ssa_step_params *p_host, void *stream, int32_t slot);
 /* waits for slot's kernel and writes its duration in milliseconds */
 int ssa_env_step_profile_ms(int32_t slot, float *kernel_ms);
+/* folds a shard set into stats[n_env][SSA_STAT_STRIDE] and clears it: the last step of a deferred-fold sequence,
+ * or whenever the host wants the statistics of the step just launched */
+int ssa_stats_fold_f64(uint64_t *stat_shards, double *stats, int32_t n_env, void *stream);
 /* bytes of the int32 `work` buffer for n_env environments of n_obj objects */
 int64_t ssa_env_step_work_bytes(int64_t n_obj, int32_t n_env);
 

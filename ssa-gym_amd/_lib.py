@@ -32,12 +32,12 @@ class ssa_step_params(C.Structure):
         ("upd", c_dp), ("trans", c_dp), ("env_time", c_dp), ("actions", c_dp), ("z_noise", c_dp),
         ("zn_stride_env", C.c_int64), ("zn_stride_time", C.c_int64), ("zn_stride_obj", C.c_int64),
         ("n_time", C.c_int32), ("launch_mask", C.c_uint32), ("stats", c_dp), ("work", c_dp), ("stat_ws", c_dp),
-        ("stat_shards", c_dp), ("aer_out", c_dp),
+        ("stat_shards", c_dp), ("stat_shards_prev", c_dp), ("stats_prev", c_dp), ("aer_out", c_dp),
     ]
 
 
 # constants of include/ssa_hip.h
-ABI_VERSION = 9
+ABI_VERSION = 10
 ST_OK, ST_PREDICT_NAN, ST_PREDICT_LINALG, ST_UPDATE_NAN, ST_UPDATE_LINALG = range(5)
 OBS_AER, OBS_XYZ = 0, 1
 PROP_ELEMENTS, PROP_FG, PROP_J2_RK4 = 0, 1, 2
@@ -45,6 +45,7 @@ FLAG_RESAMPLE = 1
 UPD_STRIDE, UPD_OBS_TAKEN, UPD_Z_TRUE, UPD_Y, UPD_S, UPD_SIGMAS_H, UPD_VISIBLE, UPD_ACTION = 64, 0, 1, 4, 7, 16, 55, 56
 STAT_SHARDS = 64
 PROFILE_SLOTS = 1024
+LAUNCH_DEFER_FOLD = 8
 STAT_STRIDE, STAT_MAX_DPOS, STAT_CNT_LT_1E4, STAT_CNT_LT_1E7, STAT_ARGMAX_SPOS, STAT_N_FAILED, STAT_MAX_SPOS = 8, 0, 1, 2, 3, 4, 5
 
 # every symbol the header declares, with its ctypes signature
@@ -54,6 +55,7 @@ SIGNATURES = {
     "ssa_env_step_f64": (C.c_int, [C.POINTER(ssa_consts), C.POINTER(ssa_step_params), c_dp]),
     "ssa_env_step_profiled_f64": (C.c_int, [C.POINTER(ssa_consts), C.POINTER(ssa_step_params), c_dp, C.c_int32]),
     "ssa_env_step_profile_ms": (C.c_int, [C.c_int32, C.POINTER(C.c_float)]),
+    "ssa_stats_fold_f64": (C.c_int, [c_dp, c_dp, C.c_int32, c_dp]),
     "ssa_env_step_work_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
     "ssa_reward_stats_f64": (C.c_int, [c_dp, c_dp, c_dp, c_dp, C.c_int64, C.c_int32, c_dp]),
     "ssa_reward_stats_workspace_bytes": (C.c_int64, [C.c_int32]),

@@ -958,50 +958,6 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     }
 }
 
-// Grid-stride over tiles: wavefront w advances tiles w, w + G, w + 2G, ... (G = gridDim.x, chosen by the
-// launcher so that every wavefront is resident at once and all get the same number of tiles) with the
-// next tile's loads issued while the current one is being worked on.
-//
-// MULTI = false is the one-tile-per-wavefront instance (every launch up to 20 480 objects): no loop, no staging
-// registers.
-typedef const __attribute__((address_space(4))) StepK* KernargPtr;
-template <int PROP, bool MULTI>
-__global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(const StepK k_arg, int ntiles)
-{
-    __shared__ Tiles t;
-    int lane = threadIdx.x;
-    const int64_t total = (int64_t)k_arg.p.n_env * k_arg.p.n_obj;
-    StatAcc unused = stat_identity();
-    TileRegs pf;
-    int tile = blockIdx.x;
-    if (!MULTI) {
-        const int64_t base = (int64_t)tile * OBJ_PER_WAVE;
-        const int cnt = (int)((total - base) < OBJ_PER_WAVE ? (total - base) : OBJ_PER_WAVE);
-        process_wave<PROP, true, false>(t, k_arg.c, k_arg.p, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, unused, pf, 0, 0, tile);
-        return;
-    }
-    {
-        const int64_t b0 = (int64_t)tile * OBJ_PER_WAVE;
-        tile_issue(pf, k_arg.p, lane, b0, tile < ntiles ? (int)((total - b0) < OBJ_PER_WAVE ? (total - b0) : OBJ_PER_WAVE) : 0);
-    }
-    KernargPtr kp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    for (; tile < ntiles; tile += gridDim.x) {
-        // the body must compile like a one-tile kernel: re-derive the argument block and the lane id per
-        // tile, so that the ~100 argument scalars and the lane-derived LDS addresses are produced on demand
-        // instead of being carried around the loop in registers
-        asm volatile("" : "+s"(kp));
-        asm volatile("" : "+v"(lane));
-        const StepK& k = *(const StepK*)kp;
-        const int64_t base = (int64_t)tile * OBJ_PER_WAVE;
-        const int cnt = (int)((total - base) < OBJ_PER_WAVE ? (total - base) : OBJ_PER_WAVE);
-        const int nt = tile + gridDim.x;
-        const int64_t nbase = (int64_t)nt * OBJ_PER_WAVE;
-        const int ncnt = nt < ntiles ? (int)((total - nbase) < OBJ_PER_WAVE ? (total - nbase) : OBJ_PER_WAVE) : 0;
-        process_wave<PROP, true, true>(t, k.c, k.p, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, unused, pf, nbase, ncnt, tile);
-        wave_lds_sync();   // the tile's LDS reads (store) precede the next tile's commit
-    }
-}
-
 // folds the SSA_STAT_SHARDS accumulators of the atomics path of env e into stats and clears them (one wavefront)
 SSA_DEV void fold_stat_shards(unsigned long long* __restrict__ shards, double* __restrict__ stats, int e, int lane)
 {
@@ -1029,6 +985,54 @@ SSA_DEV void fold_stat_shards(unsigned long long* __restrict__ shards, double* _
 __global__ void __launch_bounds__(64) reward_fold_kernel(unsigned long long* __restrict__ shards, double* __restrict__ stats)
 {
     fold_stat_shards(shards, stats, blockIdx.x, threadIdx.x);
+}
+
+// Grid-stride over tiles: wavefront w advances tiles w, w + G, w + 2G, ... (G = gridDim.x, chosen by the
+// launcher so that every wavefront is resident at once and all get the same number of tiles) with the
+// next tile's loads issued while the current one is being worked on.
+//
+// MULTI = false is the one-tile-per-wavefront instance (every launch up to 20 480 objects): no loop, no staging
+// registers.
+typedef const __attribute__((address_space(4))) StepK* KernargPtr;
+template <int PROP, bool MULTI>
+__global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(const StepK k_arg, int ntiles, int nwork)
+{
+    __shared__ Tiles t;
+    int lane = threadIdx.x;
+    if ((int)blockIdx.x >= nwork) {   // deferred fold of the previous step's statistics: one extra wavefront per env
+        fold_stat_shards((unsigned long long*)k_arg.p.stat_shards_prev, k_arg.p.stats_prev, (int)blockIdx.x - nwork, lane);
+        return;
+    }
+    const int64_t total = (int64_t)k_arg.p.n_env * k_arg.p.n_obj;
+    StatAcc unused = stat_identity();
+    TileRegs pf;
+    int tile = blockIdx.x;
+    if (!MULTI) {
+        const int64_t base = (int64_t)tile * OBJ_PER_WAVE;
+        const int cnt = (int)((total - base) < OBJ_PER_WAVE ? (total - base) : OBJ_PER_WAVE);
+        process_wave<PROP, true, false>(t, k_arg.c, k_arg.p, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, unused, pf, 0, 0, tile);
+        return;
+    }
+    {
+        const int64_t b0 = (int64_t)tile * OBJ_PER_WAVE;
+        tile_issue(pf, k_arg.p, lane, b0, tile < ntiles ? (int)((total - b0) < OBJ_PER_WAVE ? (total - b0) : OBJ_PER_WAVE) : 0);
+    }
+    KernargPtr kp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    for (; tile < ntiles; tile += nwork) {
+        // the body must compile like a one-tile kernel: re-derive the argument block and the lane id per
+        // tile, so that the ~100 argument scalars and the lane-derived LDS addresses are produced on demand
+        // instead of being carried around the loop in registers
+        asm volatile("" : "+s"(kp));
+        asm volatile("" : "+v"(lane));
+        const StepK& k = *(const StepK*)kp;
+        const int64_t base = (int64_t)tile * OBJ_PER_WAVE;
+        const int cnt = (int)((total - base) < OBJ_PER_WAVE ? (total - base) : OBJ_PER_WAVE);
+        const int nt = tile + nwork;
+        const int64_t nbase = (int64_t)nt * OBJ_PER_WAVE;
+        const int ncnt = nt < ntiles ? (int)((total - nbase) < OBJ_PER_WAVE ? (total - nbase) : OBJ_PER_WAVE) : 0;
+        process_wave<PROP, true, true>(t, k.c, k.p, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, unused, pf, nbase, ncnt, tile);
+        wave_lds_sync();   // the tile's LDS reads (store) precede the next tile's commit
+    }
 }
 
 // Post kernel, grid (nparts, n_env) x 256 threads: (1) the queued objects of this env with complete
@@ -1526,29 +1530,33 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
     const int64_t ntiles = (total + OBJ_PER_WAVE - 1) / OBJ_PER_WAVE;
     const int64_t slots = (int64_t)device_cu_count() * 4 * SSA_STEP_WAVES;
     const int64_t per_wave = (ntiles + slots - 1) / slots;
-    dim3 grid((unsigned)((ntiles + per_wave - 1) / per_wave)), block(64);
+    const int nwork = (int)((ntiles + per_wave - 1) / per_wave);
+    const bool fast_stats = p->stat_shards && c->propagator != SSA_PROP_ELEMENTS;   // statistics by the common-path kernel's atomics
+    const bool defer = fast_stats && !p->aer_out && (p->launch_mask & SSA_LAUNCH_DEFER_FOLD);
+    if (defer && p->stat_shards_prev && (!p->stats_prev || p->stat_shards_prev == p->stat_shards)) return SSA_E_INVALID;
+    const int nfold = (defer && p->stat_shards_prev) ? p->n_env : 0;
+    dim3 grid((unsigned)(nwork + nfold)), block(64);
     const int nparts = post_parts(p->n_obj, p->n_env);
     StatAcc* parts = (StatAcc*)p->stat_ws;
     hipStream_t s = (hipStream_t)stream;
-    const unsigned mask = p->launch_mask ? p->launch_mask : 7u;   // diagnostic: time one launch alone
+    const unsigned mask = (p->launch_mask & 7u) ? (p->launch_mask & 7u) : 7u;   // diagnostic: time one launch alone
     if (c->propagator != SSA_PROP_FG && c->propagator != SSA_PROP_ELEMENTS && c->propagator != SSA_PROP_J2_RK4) return SSA_E_INVALID;
     if (c->propagator == SSA_PROP_J2_RK4 && (c->rk4_substeps < 1 || c->rk4_substeps > 4096)) return SSA_E_INVALID;
     const int prop = c->propagator;
     if (mask & 1u) {   // (ev0, ev1: dispatch timestamps of this kernel for ssa_env_step_profiled_f64, else null)
         const int nt = (int)ntiles;
         if (per_wave == 1) {
-            if (prop == SSA_PROP_FG) hipExtLaunchKernelGGL((step_fast_kernel<1, false>), grid, block, 0, s, ev0, ev1, 0, k, nt);
-            else if (prop == SSA_PROP_ELEMENTS) hipExtLaunchKernelGGL((step_fast_kernel<0, false>), grid, block, 0, s, ev0, ev1, 0, k, nt);
-            else hipExtLaunchKernelGGL((step_fast_kernel<2, false>), grid, block, 0, s, ev0, ev1, 0, k, nt);
+            if (prop == SSA_PROP_FG) hipExtLaunchKernelGGL((step_fast_kernel<1, false>), grid, block, 0, s, ev0, ev1, 0, k, nt, nwork);
+            else if (prop == SSA_PROP_ELEMENTS) hipExtLaunchKernelGGL((step_fast_kernel<0, false>), grid, block, 0, s, ev0, ev1, 0, k, nt, nwork);
+            else hipExtLaunchKernelGGL((step_fast_kernel<2, false>), grid, block, 0, s, ev0, ev1, 0, k, nt, nwork);
         } else {
-            if (prop == SSA_PROP_FG) hipExtLaunchKernelGGL((step_fast_kernel<1, true>), grid, block, 0, s, ev0, ev1, 0, k, nt);
-            else if (prop == SSA_PROP_ELEMENTS) hipExtLaunchKernelGGL((step_fast_kernel<0, true>), grid, block, 0, s, ev0, ev1, 0, k, nt);
-            else hipExtLaunchKernelGGL((step_fast_kernel<2, true>), grid, block, 0, s, ev0, ev1, 0, k, nt);
+            if (prop == SSA_PROP_FG) hipExtLaunchKernelGGL((step_fast_kernel<1, true>), grid, block, 0, s, ev0, ev1, 0, k, nt, nwork);
+            else if (prop == SSA_PROP_ELEMENTS) hipExtLaunchKernelGGL((step_fast_kernel<0, true>), grid, block, 0, s, ev0, ev1, 0, k, nt, nwork);
+            else hipExtLaunchKernelGGL((step_fast_kernel<2, true>), grid, block, 0, s, ev0, ev1, 0, k, nt, nwork);
         }
     }
-    const bool fast_stats = p->stat_shards && prop != SSA_PROP_ELEMENTS;   // statistics by the common-path kernel's atomics
-    if (fast_stats && !p->aer_out) {   // no payload: a one-wave fold finishes the step (2 launches)
-        if (mask & 6u)
+    if (fast_stats && !p->aer_out) {   // no payload: a one-wave fold finishes the step (2 launches), unless deferred (1 launch)
+        if ((mask & 6u) && !defer)
             hipLaunchKernelGGL(reward_fold_kernel, dim3(p->n_env), dim3(64), 0, s, (unsigned long long*)p->stat_shards, p->stats);
         return launch_status();
     }
@@ -1587,6 +1595,12 @@ int ssa_env_step_profile_ms(int32_t slot, float* kernel_ms)
     if (hipEventSynchronize(g_prof_ev[slot][1]) != hipSuccess ||
         hipEventElapsedTime(kernel_ms, g_prof_ev[slot][0], g_prof_ev[slot][1]) != hipSuccess) return SSA_E_LAUNCH;
     return SSA_OK;
+}
+int ssa_stats_fold_f64(uint64_t* stat_shards, double* stats, int32_t n_env, void* stream)
+{
+    if (!stat_shards || !stats || n_env <= 0) return SSA_E_INVALID;
+    hipLaunchKernelGGL(reward_fold_kernel, dim3(n_env), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)stat_shards, stats);
+    return launch_status();
 }
 int64_t ssa_env_step_work_bytes(int64_t n_obj, int32_t n_env)
 {

@@ -74,7 +74,11 @@ class HotPathEngine:
         self._stats_ws = device.stats_workspace(self.E, d)
         self.work = torch.zeros(self._lib.ssa_env_step_work_bytes(self.m, self.E) // 4, dtype=torch.int32, device=d)
         self._p.work, self._p.stat_ws, self._p.launch_mask = self.work.data_ptr(), self._stats_ws.data_ptr(), 0
-        self.stat_shards = torch.zeros((self.E, _lib.STAT_SHARDS, 4), dtype=torch.int64, device=d)
+        # statistics accumulators of the atomics path; two sets, alternated when the fold is deferred
+        self._shard_sets = torch.zeros((2, self.E, _lib.STAT_SHARDS, 4), dtype=torch.int64, device=d)
+        self.stat_shards = self._shard_sets[0]
+        self._shard_cur = 0
+        self._fold_pending = None      # (shard set index, stats destination) of a step whose fold was deferred
         self._cref = C.byref(self.consts)
         self._pref = C.byref(self._p)
         # element strides of one history slot
@@ -128,8 +132,10 @@ class HotPathEngine:
 
     # ------------------------------------------------------------------ one step
     def launch_step(self, slot_in, slot_out, time_offset, actions_ptr=None, stream=None, aer_out=0, stats_out=0, upd_out=0,
-                    fast_stats=False):
-        """enqueue the step (common-path kernel, post kernel, final kernel); asynchronous, no host sync."""
+                    fast_stats=False, defer_fold=False, profile_slot=None):
+        """enqueue the step; asynchronous, no host sync.  fast_stats: statistics by the step kernel's atomics (two
+        launches, no arg-max of sigma_pos).  defer_fold (with fast_stats, no payload): ONE launch -- this step's
+        statistics are folded by extra wavefronts of the NEXT deferred step, or by flush_stats()."""
         p = self._p
         p.time_offset = int(time_offset)
         p.x_true_in, p.x_true_out = self._bx_t + slot_in * self._sx, self._bx_t + slot_out * self._sx
@@ -142,11 +148,46 @@ class HotPathEngine:
         p.stats = stats_out if stats_out else self._bs + slot_out * self._ss   # e.g. straight into a send buffer
         p.aer_out = aer_out
         # two-launch path (no arg-max of sigma_pos): see include/ssa_hip.h ssa_step_params.stat_shards
-        p.stat_shards = self.stat_shards.data_ptr() if fast_stats else 0
         s = torch.cuda.current_stream().cuda_stream if stream is None else stream
-        rc = self._lib.ssa_env_step_f64(self._cref, self._pref, s)
+        defer = bool(defer_fold and fast_stats and not aer_out and self.consts.propagator != _lib.PROP_ELEMENTS)
+        if not defer and self._fold_pending is not None:
+            self.flush_stats(s)       # a deferred step is followed by an immediate one: fold it first (same stream, in order)
+        p.stat_shards = self._shard_sets[self._shard_cur].data_ptr() if fast_stats else 0
+        p.launch_mask = _lib.LAUNCH_DEFER_FOLD if defer else 0
+        if defer and self._fold_pending is not None:
+            p.stat_shards_prev = self._shard_sets[self._fold_pending[0]].data_ptr()
+            p.stats_prev = self._fold_pending[1]
+        else:
+            p.stat_shards_prev, p.stats_prev = 0, 0
+        if profile_slot is None:
+            rc = self._lib.ssa_env_step_f64(self._cref, self._pref, s)
+        else:   # the dominant launch bracketed by event pair `profile_slot` (read back with profile_ms)
+            rc = self._lib.ssa_env_step_profiled_f64(self._cref, self._pref, s, int(profile_slot))
+        p.launch_mask = 0
         if rc:
             raise _lib.SsaHipError("ssa_env_step_f64 failed with code %d" % rc)
+        if defer:
+            self._fold_pending = (self._shard_cur, int(p.stats))
+            self._shard_cur ^= 1
+
+    def profile_ms(self, slot):
+        """duration [ms] of the dominant kernel of the step launched with profile_slot=slot (waits for it)."""
+        ms = C.c_float(0.0)
+        rc = self._lib.ssa_env_step_profile_ms(int(slot), C.byref(ms))
+        if rc:
+            raise _lib.SsaHipError("ssa_env_step_profile_ms failed with code %d" % rc)
+        return float(ms.value)
+
+    def flush_stats(self, stream=None):
+        """fold the statistics of the last deferred step (no-op when nothing is pending)."""
+        if self._fold_pending is None:
+            return
+        s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        k, dst = self._fold_pending
+        rc = self._lib.ssa_stats_fold_f64(self._shard_sets[k].data_ptr(), dst, self.E, s)
+        self._fold_pending = None
+        if rc:
+            raise _lib.SsaHipError("ssa_stats_fold_f64 failed with code %d" % rc)
 
     def set_actions(self, actions):
         a = torch.as_tensor(np.asarray(actions, dtype=np.int32).reshape(self.E))

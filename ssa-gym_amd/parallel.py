@@ -139,9 +139,12 @@ class ShardedStepper:
 class HipLocalStepper:
     """LocalStepper over the HIP engine (the only one the product uses)."""
 
-    def __init__(self, engine, consts, fast_stats=False):
+    def __init__(self, engine, consts, fast_stats=False, defer_fold=False):
         self.engine, self.consts = engine, consts
         self.fast_stats = fast_stats   # statistics by the common-path kernel's atomics: two launches, no arg-max of sigma_pos
+        # one launch per step: the statistics of step k are folded by extra wavefronts of step k+1 (flush() folds the
+        # last one).  For consumers that read the statistics in bulk; a closed loop reads them every step (no deferral).
+        self.defer_fold = defer_fold
         self.device = engine.dev
         self.tick = 0
         self._act = torch.zeros(1, dtype=torch.int32)
@@ -152,7 +155,11 @@ class HipLocalStepper:
         self._sched = torch.as_tensor(np.asarray(local_actions, dtype=np.int32)).to(self.device)
         self._sched_k0 = self.tick
 
-    def step(self, local_action, obs_out=None, stats_out=None):
+    def flush(self):
+        """fold the statistics of the last deferred step."""
+        self.engine.flush_stats()
+
+    def step(self, local_action, obs_out=None, stats_out=None, profile_slot=None):
         """enqueue one env step; when given, the post/final kernels write the shard's aer observation
         block and its reward statistics directly into `obs_out` / `stats_out` (the all-gather payload)."""
         e = self.engine
@@ -162,14 +169,17 @@ class HipLocalStepper:
         if self._sched is not None:
             k = (self.tick - 1 - self._sched_k0) % self._sched.numel()
             e.launch_step((self.tick - 1) % e.H, self.tick % e.H, self.tick, actions_ptr=self._sched.data_ptr() + 4 * k,
-                          aer_out=aer, stats_out=st, fast_stats=self.fast_stats)
+                          aer_out=aer, stats_out=st, fast_stats=self.fast_stats, defer_fold=self.defer_fold,
+                          profile_slot=profile_slot)
             return
         self._act[0] = int(local_action)
         e.actions.copy_(self._act)
-        e.launch_step((self.tick - 1) % e.H, self.tick % e.H, self.tick, aer_out=aer, stats_out=st, fast_stats=self.fast_stats)
+        e.launch_step((self.tick - 1) % e.H, self.tick % e.H, self.tick, aer_out=aer, stats_out=st, fast_stats=self.fast_stats,
+                      defer_fold=self.defer_fold, profile_slot=profile_slot)
 
     def reset_episode(self, snap, episode_len):
         """start a new episode from a device-resident snapshot: the next step gets time index 1."""
         e = self.engine
+        e.flush_stats()                                  # the last step of the finished episode
         self.tick += (-self.tick) % episode_len          # advance to the next multiple of the episode length
         e.restore(self.tick % e.H, snap)

@@ -488,3 +488,35 @@ def test_engine_rejects_short_noise_table(hip):
     consts = hip.host.make_consts(g["Q"], g["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, g["obs_lla"])
     with pytest.raises(hip.lib.SsaHipError):
         hip.engine.HotPathEngine(consts, 4, 2, c2t(), np.zeros((1, 4, 4, 3)), history=2)
+
+
+@pytest.mark.parametrize("E,m", [(1, 2003), (3, 50), (2, 30001)])
+def test_deferred_statistics_fold_equals_immediate_fold(hip, E, m):
+    """One launch per step: with defer_fold the statistics of step k are folded by extra wavefronts riding in
+    step k+1's launch (flush_stats() folds the last; an immediate step after a deferred one folds it first).
+    Every step's statistics and the whole filter state must equal the fold-kernel path's."""
+    xt, x, P, g = make_batch(E * m, seed=91)
+    x[7, 2] = np.nan
+    consts = hip.host.make_consts(g["Q"], g["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, g["obs_lla"])
+    n_time = c2t().shape[0]
+    K = 6
+    outs = []
+    for mode in ("immediate", "deferred", "mixed"):
+        zn = hip.torch.zeros((n_time, m, 3), dtype=hip.torch.float64, device="cuda")
+        eng = hip.engine.HotPathEngine(consts, m, E, c2t(), zn, history=K + 1, zn_stride_env=0)
+        eng.load_state(0, xt, x, P)
+        for k in range(1, K + 1):
+            eng.set_actions([(5 * e + k) % m for e in range(E)])
+            defer = mode == "deferred" or (mode == "mixed" and k in (1, 2, 4))   # 3 and 5 fold their predecessor first
+            eng.launch_step(k - 1, k, k, fast_stats=True, defer_fold=defer)
+        eng.flush_stats()
+        eng.flush_stats()                                  # idempotent
+        hip.torch.cuda.synchronize()
+        outs.append((eng.stats.cpu().numpy(), eng.x_filter[K].cpu().numpy(), eng.P_filter[K].cpu().numpy(),
+                     eng.status.cpu().numpy(), eng._shard_sets.cpu().numpy()))
+    for o in outs[1:]:
+        assert np.array_equal(outs[0][0][1:], o[0][1:], equal_nan=True)      # statistics of steps 1..K
+        for a, b in zip(outs[0][1:4], o[1:4]):
+            assert np.array_equal(a, b, equal_nan=True)
+        assert not o[4].any()                                                # every shard set folded and cleared
+    assert outs[0][0][1, 0, hip.lib.STAT_MAX_DPOS] > 1e19 and outs[0][0][K, 0, hip.lib.STAT_N_FAILED] >= 1   # the NaN state failed: sentinels
