@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--propagator", default="fg", choices=["fg", "elements", "j2"],
                     help="fg / elements: two-body Farnocchia (parity-checked); j2: J2+RK4 extension (no reference counterpart)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rollout", type=int, default=60,
+                    help="steps per launch of the additional open-loop rollout measurement (0 = skip); never `value`")
     args = ap.parse_args()
 
     import torch
@@ -229,6 +231,33 @@ def main():
                 "kernel_ms": round(kern_ms, 5), "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": nl,
                 "note": "fp64 VALU / latency bound, not HBM bound: ~14 Kepler solves per object-step (SURVEY 8d)"}
 
+    # ---- additional line (never `value`): the same K steps through ssa_env_rollout_f64, `--rollout` steps per
+    # launch -- what an open-loop schedule such as this protocol's round-robin allows (state resident in LDS across
+    # the steps of a launch; every step's outputs still written)
+    roll = None
+    if rank == 0 and world == 1 and not use_dist and args.rollout > 0 and args.propagator != "elements":
+        R = args.rollout
+
+        def roll_steps(n):
+            done = 0
+            while done < n:
+                if state["i"] == ep_len - 1:
+                    local.reset_episode(snap, ep_len)
+                    state["i"] = 0
+                kk = min(R, n - done, ep_len - 1 - state["i"])
+                local.rollout(kk)
+                state["i"] += kk
+                done += kk
+        roll_steps(W)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        roll_steps(K)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        roll = {"steps_per_launch": R, "value": round(K / el * (m / 20000.0), 2), "ms_per_step": round(1e3 * el / K, 5),
+                "failed_filters": int((eng.status != 0).sum().item()),
+                "note": "open-loop schedule only (actions of a launch known up front); bit-identical to per-step launches"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N=1 only
         cpu = cpu_baseline(m)
@@ -253,7 +282,7 @@ def main():
                        "allgather_warmup_probe": allgather_probe},
             "object_steps_per_sec": round(steps_per_s * m * world, 1),
             "failed_filters": n_failed,
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "rollout": roll,
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(steps_per_s * world / cpu["value"], 1)

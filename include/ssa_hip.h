@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SSA_ABI_VERSION 10
+#define SSA_ABI_VERSION 11
 
 /* error codes */
 #define SSA_OK 0
@@ -161,6 +161,30 @@ int ssa_env_step_f64(const ssa_consts *c_host, const ssa_step_params *p_host, vo
 int ssa_env_step_profiled_f64(const ssa_consts *c_host, const ssa_step_params *p_host, void *stream, int32_t slot);
 /* waits for slot's kernel and writes its duration in milliseconds */
 int ssa_env_step_profile_ms(int32_t slot, float *kernel_ms);
+/* ---------------------------------------------------------------- rollout: K steps in one launch
+ * For open-loop action schedules (the reference's round-robin / random agents, agents.py, and filter-only runs): the
+ * K calls ssa_env_step_f64 would make, with every step's outputs written to that step's slot of the history rings and
+ * results bit-identical to them, but each wavefront keeps its objects' state in LDS across the steps (an object's
+ * trajectory depends on no other object).  `first` is the parameter block of the FIRST step (n_obj, n_env, time_offset,
+ * status, trans, env_time, z_noise and strides, n_time, work; its in/out/stats pointers are ignored).  Propagators FG
+ * and J2 only.  Two launches: the rollout kernel and a fold of the per-step statistics. */
+typedef struct ssa_rollout_params {
+    int32_t n_steps;           /* K >= 1 */
+    int32_t history;           /* H >= 2: depth of the rings below */
+    int32_t slot_out;          /* step k (0-based) reads slot (slot_out + k - 1) mod H and writes slot (slot_out + k) mod H */
+    int32_t reserved;
+    double *x_true_ring;       /* [H][E*m][6]   slot 0 of each ring */
+    double *x_ring;            /* [H][E*m][6] */
+    double *P_ring;            /* [H][E*m][6][6] */
+    double *obs_ring;          /* [H][E*m][12] */
+    double *metrics_ring;      /* [H][E][4][m] */
+    double *upd_ring;          /* [H][E][SSA_UPD_STRIDE] or NULL */
+    double *stats_ring;        /* [H][E][SSA_STAT_STRIDE]; only the last H steps' statistics survive, as in any ring */
+    const int32_t *actions;    /* [K][E] */
+    uint64_t *stat_shards;     /* [K][E][SSA_STAT_SHARDS][4] zero-initialised; cleared again by the fold */
+} ssa_rollout_params;
+int ssa_env_rollout_f64(const ssa_consts *c_host, const ssa_step_params *first, const ssa_rollout_params *r, void *stream);
+
 /* folds a shard set into stats[n_env][SSA_STAT_STRIDE] and clears it: the last step of a deferred-fold sequence,
  * or whenever the host wants the statistics of the step just launched */
 int ssa_stats_fold_f64(uint64_t *stat_shards, double *stats, int32_t n_env, void *stream);

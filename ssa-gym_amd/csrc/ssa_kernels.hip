@@ -576,7 +576,9 @@ __device__ unsigned long long g_trace[16384 * 16];
 //                 status left untouched.  No out-of-line calls -> small register budget.
 //   FAST = false: complete semantics for arbitrary objects (the queue), per-row I/O; the row's
 //                 metrics are folded into `acc` (reward statistics of queued objects).
-template <int PROP, bool FAST, bool MULTI>
+// TILE (FAST only): 0 = the tile is loaded here; 1 = it was prefetched (commit now, request the next one after the
+// Kepler stage); 2 = the tiles already hold the state (a rollout's later steps)
+template <int PROP, bool FAST, int TILE>
 SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& p, int lane, int64_t obj, bool valid,
                           int64_t base, int cnt, StatAcc& acc, TileRegs& pf, int64_t next_base, int next_cnt, int tile)
 {
@@ -597,8 +599,8 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
 #endif
 
     if (FAST) {
-        if (!MULTI) tile_issue(pf, p, lane, base, cnt);   // one tile per wavefront: plain load, no staging registers kept
-        tile_commit(t, pf, lane);                        // MULTI: requested one tile ago (or by the kernel prologue)
+        if (TILE == 0) tile_issue(pf, p, lane, base, cnt);   // one tile per wavefront: plain load, no staging registers kept
+        if (TILE != 2) tile_commit(t, pf, lane);            // TILE 1: requested one tile ago (or by the kernel prologue)
     }
     else load_object(t, p, g, l, valid ? obj : 0, valid);
     wave_lds_sync();
@@ -668,7 +670,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     wave_lds_sync();   // every lane has consumed t.X / t.T / t.U
     SSA_TR(3);
     // the next tile's inputs: in flight during the transform / covariance / observation / store of this one
-    if (FAST && MULTI) tile_issue(pf, p, lane, next_base, next_cnt);
+    if (FAST && TILE == 1) tile_issue(pf, p, lane, next_base, next_cnt);
 
     // ---- U3: unscented transform, centred form of x = dot(Wm, sigmas_f):
     //   x = sigma_0' + m',   m' = (sum(Wm) - 1) sigma_0' + Wi sum_{i>=1} (sigma_i' - sigma_0')
@@ -1010,7 +1012,7 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(const Ste
     if (!MULTI) {
         const int64_t base = (int64_t)tile * OBJ_PER_WAVE;
         const int cnt = (int)((total - base) < OBJ_PER_WAVE ? (total - base) : OBJ_PER_WAVE);
-        process_wave<PROP, true, false>(t, k_arg.c, k_arg.p, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, unused, pf, 0, 0, tile);
+        process_wave<PROP, true, 0>(t, k_arg.c, k_arg.p, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, unused, pf, 0, 0, tile);
         return;
     }
     {
@@ -1030,9 +1032,80 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(const Ste
         const int nt = tile + nwork;
         const int64_t nbase = (int64_t)nt * OBJ_PER_WAVE;
         const int ncnt = nt < ntiles ? (int)((total - nbase) < OBJ_PER_WAVE ? (total - nbase) : OBJ_PER_WAVE) : 0;
-        process_wave<PROP, true, true>(t, k.c, k.p, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, unused, pf, nbase, ncnt, tile);
+        process_wave<PROP, true, 1>(t, k.c, k.p, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, unused, pf, nbase, ncnt, tile);
         wave_lds_sync();   // the tile's LDS reads (store) precede the next tile's commit
     }
+}
+
+// Rollout: K consecutive env steps of the same objects in ONE launch.  An object's trajectory depends on no other
+// object (the single update per step touches only the selected one; the statistics are reductions), so a wavefront
+// loads its tile once and advances it K steps with state, covariance, truth and status resident in LDS, writing every
+// step's outputs to that step's ring slot exactly as K single-step launches would; per-step statistics go to per-step
+// shard sets, folded by rollout_fold_kernel.  Needs the actions of all K steps up front (open-loop schedules).
+struct RollK {   // ONE kernel argument, so that the per-step re-derivation below can address both halves
+    StepK k;
+    ssa_rollout_params r;
+};
+template <int PROP>
+__global__ void __launch_bounds__(64, SSA_STEP_WAVES) rollout_kernel(const RollK a, int ntiles, int nwork)
+{
+    const StepK& k_arg = a.k;
+    __shared__ Tiles t;
+    int lane = threadIdx.x;
+    const int64_t total = (int64_t)k_arg.p.n_env * k_arg.p.n_obj;
+    const int E = k_arg.p.n_env, H = a.r.history, K = a.r.n_steps;
+    const int64_t sx = total * 6, sP = total * 36, so_ = total * 12, sm = (int64_t)E * 4 * k_arg.p.n_obj, su = (int64_t)E * SSA_UPD_STRIDE;
+    StatAcc unused = stat_identity();
+    TileRegs pf;
+    typedef const __attribute__((address_space(4))) RollK* RollArgPtr;
+    RollArgPtr kp = (RollArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    for (int tile = blockIdx.x; tile < ntiles; tile += nwork) {
+        const int64_t base = (int64_t)tile * OBJ_PER_WAVE;
+        const int cnt = (int)((total - base) < OBJ_PER_WAVE ? (total - base) : OBJ_PER_WAVE);
+        {   // the tile's state from the input slot
+            const int si0 = (a.r.slot_out + H - 1) % H;
+            ssa_step_params p0 = k_arg.p;
+            p0.x_true_in = a.r.x_true_ring + si0 * sx;
+            p0.x_in = a.r.x_ring + si0 * sx;
+            p0.P_in = a.r.P_ring + si0 * sP;
+            wave_lds_sync();   // the previous tile's last stores have read the tiles
+            tile_issue(pf, p0, lane, base, cnt);
+            tile_commit(t, pf, lane);
+        }
+        for (int kk = 0; kk < K; ++kk) {
+            asm volatile("" : "+s"(kp));      // per step, as per tile in step_fast_kernel: nothing carried around the loop
+            asm volatile("" : "+v"(lane));
+            const StepK& k = ((const RollK*)kp)->k;
+            const ssa_rollout_params& r = ((const RollK*)kp)->r;
+            const int so = (r.slot_out + kk) % H, si = (so + H - 1) % H;
+            ssa_step_params pk = k.p;
+            pk.time_offset = k.p.time_offset + kk;
+            pk.x_true_in = r.x_true_ring + si * sx;  pk.x_true_out = r.x_true_ring + so * sx;
+            pk.x_in = r.x_ring + si * sx;            pk.x_out = r.x_ring + so * sx;
+            pk.P_in = r.P_ring + si * sP;            pk.P_out = r.P_ring + so * sP;
+            pk.obs = r.obs_ring + so * so_;
+            pk.metrics = r.metrics_ring + so * sm;
+            // per-ENV outputs are written by whichever wavefront owns the selected object, and wavefronts advance at
+            // their own pace: only the step that finally owns a ring slot may write it (per-object outputs have one
+            // writer, in order)
+            pk.upd = (r.upd_ring && kk >= K - H) ? r.upd_ring + so * su : nullptr;
+            pk.actions = r.actions + (int64_t)kk * E;
+            pk.stat_shards = r.stat_shards + (int64_t)kk * E * SSA_STAT_SHARDS * 4;
+            pk.aer_out = nullptr;
+            process_wave<PROP, true, 2>(t, k.c, pk, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, unused, pf, 0, 0, tile);
+            wave_lds_sync();
+        }
+    }
+}
+// grid (n_steps, n_env): folds step k's shard set into the statistics slot of step k -- when that slot still
+// belongs to step k at the end of the rollout (the last `history` steps) -- and clears it
+__global__ void __launch_bounds__(64) rollout_fold_kernel(unsigned long long* __restrict__ shards, double* __restrict__ stats_ring,
+                                                          int n_env, int n_steps, int slot_out, int history)
+{
+    const int kk = blockIdx.x, e = blockIdx.y;
+    const int so = (slot_out + kk) % history;
+    double* dst = (kk >= n_steps - history) ? stats_ring + (int64_t)so * n_env * SSA_STAT_STRIDE : nullptr;
+    fold_stat_shards(shards + (int64_t)kk * n_env * SSA_STAT_SHARDS * 4, dst, e, threadIdx.x);
 }
 
 // Post kernel, grid (nparts, n_env) x 256 threads: (1) the queued objects of this env with complete
@@ -1058,7 +1131,7 @@ __global__ void __launch_bounds__(POST_T) step_post_kernel(const StepK k, StatAc
         const int idx = it * OBJ_PER_WAVE + (lane >> 4);
         int64_t obj = (idx < n_listed) ? (int64_t)p.work[4 + idx] : -1;
         if (obj >= 0 && obj / m != e) obj = -1;   // another env's block takes it
-        process_wave<PROP, false, false>(tiles[w], C, p, lane, obj < 0 ? 0 : obj, obj >= 0, 0, 0, acc, pf_unused, 0, 0, 0);
+        process_wave<PROP, false, 0>(tiles[w], C, p, lane, obj < 0 ? 0 : obj, obj >= 0, 0, 0, acc, pf_unused, 0, 0, 0);
         wave_lds_sync();
     }
     if (p.aer_out) {   // O4 for every object of this block's slice that was not re-done above
@@ -1595,6 +1668,34 @@ int ssa_env_step_profile_ms(int32_t slot, float* kernel_ms)
     if (hipEventSynchronize(g_prof_ev[slot][1]) != hipSuccess ||
         hipEventElapsedTime(kernel_ms, g_prof_ev[slot][0], g_prof_ev[slot][1]) != hipSuccess) return SSA_E_LAUNCH;
     return SSA_OK;
+}
+int ssa_env_rollout_f64(const ssa_consts* c, const ssa_step_params* p, const ssa_rollout_params* r, void* stream)
+{
+    if (!c || !p || !r || p->n_obj <= 0 || p->n_env <= 0 || r->n_steps < 1 || r->history < 2) return SSA_E_INVALID;
+    if (r->slot_out < 0 || r->slot_out >= r->history) return SSA_E_INVALID;
+    if (!r->x_true_ring || !r->x_ring || !r->P_ring || !r->obs_ring || !r->metrics_ring || !r->stats_ring || !r->actions || !r->stat_shards)
+        return SSA_E_INVALID;
+    if (!p->status || !p->trans || !p->env_time || !p->z_noise || !p->work) return SSA_E_INVALID;
+    if (c->obs_type != SSA_OBS_AER && c->obs_type != SSA_OBS_XYZ) return SSA_E_INVALID;
+    if (c->propagator != SSA_PROP_FG && c->propagator != SSA_PROP_J2_RK4) return SSA_E_INVALID;   // ELEMENTS queues exceptions per step
+    if (c->propagator == SSA_PROP_J2_RK4 && (c->rk4_substeps < 1 || c->rk4_substeps > 4096)) return SSA_E_INVALID;
+    const int64_t total = (int64_t)p->n_env * p->n_obj;
+    if (total >= ((int64_t)1 << 31)) return SSA_E_INVALID;
+    RollK rk;
+    rk.k.c = *c;
+    rk.k.p = *p;
+    rk.k.p.aer_out = nullptr;
+    rk.r = *r;
+    const int64_t ntiles = (total + OBJ_PER_WAVE - 1) / OBJ_PER_WAVE;
+    const int64_t slots = (int64_t)device_cu_count() * 4 * SSA_STEP_WAVES;
+    const int64_t per_wave = (ntiles + slots - 1) / slots;
+    const int nwork = (int)((ntiles + per_wave - 1) / per_wave);
+    hipStream_t s = (hipStream_t)stream;
+    if (c->propagator == SSA_PROP_FG) hipLaunchKernelGGL(rollout_kernel<1>, dim3(nwork), dim3(64), 0, s, rk, (int)ntiles, nwork);
+    else hipLaunchKernelGGL(rollout_kernel<2>, dim3(nwork), dim3(64), 0, s, rk, (int)ntiles, nwork);
+    hipLaunchKernelGGL(rollout_fold_kernel, dim3(r->n_steps, p->n_env), dim3(64), 0, s, (unsigned long long*)r->stat_shards, r->stats_ring,
+                       p->n_env, r->n_steps, r->slot_out, r->history);
+    return launch_status();
 }
 int ssa_stats_fold_f64(uint64_t* stat_shards, double* stats, int32_t n_env, void* stream)
 {

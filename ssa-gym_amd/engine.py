@@ -170,6 +170,32 @@ class HotPathEngine:
             self._fold_pending = (self._shard_cur, int(p.stats))
             self._shard_cur ^= 1
 
+    def launch_rollout(self, slot_in, time_offset, actions, stream=None):
+        """K = actions.shape[0] consecutive steps in one launch (include/ssa_hip.h: ssa_env_rollout_f64): step k reads
+        history slot (slot_in + k) % H, writes (slot_in + k + 1) % H and has time index time_offset + k.  `actions`
+        is a device int32 tensor [K][E] (open-loop schedule).  Statistics: the last min(K, H) steps' slots."""
+        if self.consts.propagator == _lib.PROP_ELEMENTS:
+            raise _lib.SsaHipError("rollout: propagator 'elements' queues exceptions per step; use 'fg' or 'j2'")
+        if not (isinstance(actions, torch.Tensor) and actions.is_cuda and actions.dtype == torch.int32 and actions.is_contiguous()
+                and actions.dim() == 2 and actions.shape[1] == self.E and actions.shape[0] >= 1):
+            raise _lib.SsaHipError("rollout: actions must be a contiguous CUDA int32 tensor [K][n_env]")
+        s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        self.flush_stats(s)
+        K = int(actions.shape[0])
+        if getattr(self, "_roll_shards", None) is None or self._roll_shards.shape[0] < K:
+            self._roll_shards = torch.zeros((K, self.E, _lib.STAT_SHARDS, 4), dtype=torch.int64, device=self.dev)
+        r = _lib.ssa_rollout_params()
+        r.n_steps, r.history, r.slot_out = K, self.H, (int(slot_in) + 1) % self.H
+        r.x_true_ring, r.x_ring, r.P_ring = self._bx_t, self._bx, self._bP
+        r.obs_ring, r.metrics_ring, r.upd_ring, r.stats_ring = self._bo, self._bm, self._bu, self._bs
+        r.actions, r.stat_shards = actions.data_ptr(), self._roll_shards.data_ptr()
+        p = self._p
+        p.time_offset = int(time_offset)
+        p.launch_mask, p.stat_shards_prev, p.stats_prev, p.aer_out = 0, 0, 0, 0
+        rc = self._lib.ssa_env_rollout_f64(self._cref, self._pref, C.byref(r), s)
+        if rc:
+            raise _lib.SsaHipError("ssa_env_rollout_f64 failed with code %d" % rc)
+
     def profile_ms(self, slot):
         """duration [ms] of the dominant kernel of the step launched with profile_slot=slot (waits for it)."""
         ms = C.c_float(0.0)

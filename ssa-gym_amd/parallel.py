@@ -177,6 +177,18 @@ class HipLocalStepper:
         e.launch_step((self.tick - 1) % e.H, self.tick % e.H, self.tick, aer_out=aer, stats_out=st, fast_stats=self.fast_stats,
                       defer_fold=self.defer_fold, profile_slot=profile_slot)
 
+    def rollout(self, n_steps):
+        """advance n_steps of the pre-staged schedule in ONE launch (open-loop actions; HotPathEngine.launch_rollout)."""
+        e = self.engine
+        if self._sched is None:
+            raise RuntimeError("rollout needs load_schedule()")
+        while n_steps > 0:   # (the staged schedule is cyclic: split a launch that would run past its end)
+            k0 = (self.tick - self._sched_k0) % self._sched.numel()
+            n = min(n_steps, self._sched.numel() - k0)
+            e.launch_rollout(self.tick % e.H, self.tick + 1, self._sched[k0:k0 + n].view(n, 1))
+            self.tick += n
+            n_steps -= n
+
     def reset_episode(self, snap, episode_len):
         """start a new episode from a device-resident snapshot: the next step gets time index 1."""
         e = self.engine

@@ -520,3 +520,48 @@ def test_deferred_statistics_fold_equals_immediate_fold(hip, E, m):
             assert np.array_equal(a, b, equal_nan=True)
         assert not o[4].any()                                                # every shard set folded and cleared
     assert outs[0][0][1, 0, hip.lib.STAT_MAX_DPOS] > 1e19 and outs[0][0][K, 0, hip.lib.STAT_N_FAILED] >= 1   # the NaN state failed: sentinels
+
+
+@pytest.mark.parametrize("propagator", ["fg", "j2"])
+@pytest.mark.parametrize("E,m,K,H", [(1, 2003, 7, 8), (3, 50, 9, 4), (2, 30001, 3, 2)])
+def test_rollout_equals_single_steps(hip, E, m, K, H, propagator):
+    """ssa_env_rollout_f64: K steps in one launch (state resident in LDS across the steps) must reproduce K
+    ssa_env_step_f64 launches BITWISE: every surviving history slot (states, covariances, observations,
+    metrics, update records), status, and the statistics of the last min(K, H) steps.  Sizes cover several
+    envs per wavefront, ragged tiles, several tiles per wavefront (> 20 480 objects), ring wrap-around
+    (K > H), a failing filter and an update in every step."""
+    xt, x, P, g = make_batch(E * m, seed=123)
+    x[9, 1] = np.nan
+    consts = hip.host.make_consts(g["Q"], g["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, g["obs_lla"], propagator=propagator)
+    n_time = c2t().shape[0]
+    acts = np.array([[(7 * e + 3 * k) % m for e in range(E)] for k in range(K)], dtype=np.int32)
+    zn_host = np.random.RandomState(8).normal(size=(n_time, m, 3)) * np.array([4.8e-6, 4.8e-6, 1e3]) if m < 5000 else None
+    outs = []
+    for mode in ("steps", "rollout"):
+        zn = hip.torch.as_tensor(zn_host).cuda() if zn_host is not None else \
+            hip.torch.zeros((n_time, m, 3), dtype=hip.torch.float64, device="cuda")
+        eng = hip.engine.HotPathEngine(consts, m, E, c2t(), zn, history=H, zn_stride_env=0)
+        eng.load_state(0, xt, x, P)
+        if mode == "steps":
+            for k in range(K):
+                eng.set_actions(acts[k])
+                eng.launch_step(k % H, (k + 1) % H, 1 + k, fast_stats=True)
+        else:
+            eng.launch_rollout(0, 1, hip.torch.as_tensor(acts).cuda())
+        hip.torch.cuda.synchronize()
+        outs.append([t.cpu().numpy() for t in (eng.x_true, eng.x_filter, eng.P_filter, eng.obs, eng.metrics, eng.upd, eng.status,
+                                               eng.stats)] + [eng._shard_sets.cpu().numpy()])
+    a, b = outs
+    names = ("x_true", "x_filter", "P_filter", "obs", "metrics", "upd", "status")
+    for nme, u, v in zip(names, a, b):
+        if nme == "metrics" or u.ndim == 1 or K >= H:
+            assert np.array_equal(u, v, equal_nan=True), nme
+        else:   # slots never written keep their initial fill
+            sl = [s_ % H for s_ in range(0, K + 1)]
+            assert np.array_equal(u[sl], v[sl], equal_nan=True), nme
+    L = hip.lib
+    for k in range(max(0, K - H), K):                     # statistics of the steps whose slot survives
+        so = (k + 1) % H
+        for sidx in (L.STAT_MAX_DPOS, L.STAT_CNT_LT_1E4, L.STAT_CNT_LT_1E7, L.STAT_N_FAILED):
+            assert np.array_equal(a[7][so, :, sidx], b[7][so, :, sidx], equal_nan=True), (k, sidx)
+    assert a[7][K % H, 0, L.STAT_N_FAILED] >= 1 and np.any(a[5][..., L.UPD_OBS_TAKEN] == 1.0)
