@@ -128,12 +128,12 @@ typedef struct ssa_step_params {
     double *stats;             /* [E][SSA_STAT_STRIDE] reward statistics of this step (O3), may be NULL */
     int32_t *work;             /* ssa_env_step_work_bytes(): exception queue; zero it once before the first call */
     void *stat_ws;             /* ssa_reward_stats_workspace_bytes(): per-block statistics partials */
-    uint64_t *stat_shards;     /* [E][SSA_STAT_SHARDS][4] zero-initialised device words, or NULL.  When given (and
-                                  aer_out is NULL, propagator != ELEMENTS) the common-path kernel accumulates max
-                                  delta_pos / trinary counts / failures itself with sharded atomics and a one-wave
-                                  fold kernel writes `stats`: two launches per step instead of three.  arg-max
-                                  sigma_pos (only the 'shaped' reward needs it) is then NOT computed:
-                                  stats[SSA_STAT_ARGMAX_SPOS] = -1, stats[SSA_STAT_MAX_SPOS] = NaN. */
+    uint64_t *stat_shards;     /* [E][SSA_STAT_SHARDS][4] zero-initialised device words, or NULL.  When given (and the
+                                  propagator is not ELEMENTS) the common-path kernel accumulates max delta_pos / trinary
+                                  counts / failures itself with sharded atomics; a one-wave fold kernel -- or, with
+                                  aer_out, the post kernel's first wavefront -- writes `stats` and clears the words: two
+                                  launches per step instead of three.  arg-max sigma_pos (only the 'shaped' reward needs
+                                  it) is then NOT computed: stats[SSA_STAT_ARGMAX_SPOS] = -1, stats[SSA_STAT_MAX_SPOS] = NaN. */
     uint64_t *stat_shards_prev;/* deferred fold (with SSA_LAUNCH_DEFER_FOLD in launch_mask): the shard set the PREVIOUS step
                                   accumulated into, or NULL.  The step kernel then carries n_env extra wavefronts that fold
                                   it into stats_prev and clear it while the objects of THIS step are being advanced, and
@@ -146,10 +146,14 @@ typedef struct ssa_step_params {
 } ssa_step_params;
 
 /* ---------------------------------------------------------------- fused hot path
- * Three launches: (1) the common path for every object, 4 objects per wavefront; objects that need
- * robust_cholesky's jitter ladder or a non-strong-elliptic conic branch are queued; (2) a post kernel
- * that re-does the queued objects with complete semantics and reduces the reward statistics per
- * block; (3) a one-wave kernel that folds the statistics and resets the queue. */
+ * One env step for every object of every env.  Launches:
+ *   stat_shards given, FG / J2 propagator : the step kernel (4 objects per wavefront, the update and the reward
+ *       statistics included) + a one-wave fold -- or + the post kernel when aer_out asks for the O4 payload -- or
+ *       nothing more with SSA_LAUNCH_DEFER_FOLD (the next step's launch folds): 2 / 2 / 1 launches;
+ *   otherwise (ELEMENTS propagator, or exact arg-max sigma_pos wanted): the common-path kernel, which queues
+ *       objects that need robust_cholesky's jitter ladder or a non-strong-elliptic conic branch; a post kernel
+ *       that re-does the queued objects with complete semantics and reduces the statistics per block; a one-wave
+ *       kernel that folds them and resets the queue: 3 launches. */
 int ssa_env_step_f64(const ssa_consts *c_host, const ssa_step_params *p_host, void *stream);
 /* Same step, with the dominant launch (the common-path kernel) bracketed by the event pair `slot`
  * (0 <= slot < SSA_PROFILE_SLOTS) bound to that dispatch: ssa_env_step_profile_ms() then returns the kernel's

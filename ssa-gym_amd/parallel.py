@@ -160,7 +160,7 @@ class HipLocalStepper:
         self.engine.flush_stats()
 
     def step(self, local_action, obs_out=None, stats_out=None, profile_slot=None):
-        """enqueue one env step; when given, the post/final kernels write the shard's aer observation
+        """enqueue one env step; when given, the post kernel writes the shard's aer observation
         block and its reward statistics directly into `obs_out` / `stats_out` (the all-gather payload)."""
         e = self.engine
         self.tick += 1
