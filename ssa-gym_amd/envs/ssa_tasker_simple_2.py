@@ -318,7 +318,30 @@ class SSA_Tasker_Env(Env):
         self._argmax_sigma = int(self._stats[_lib.STAT_ARGMAX_SPOS])
         t_dev = time.time()
         self.runtime['perform predictions'] += t_dev - s
-        # update bookkeeping (:292-315)
+        self._book_update(i, a, rec)
+        n_failed = int(self._stats[_lib.STAT_N_FAILED])
+        if n_failed != self._n_failed:
+            self._record_failures()
+        done = self._reward_done(i, a, self._stats, self._argmax_sigma_prev)
+        if i + 1 >= self.n:
+            done = True
+        obs = obs_np
+        if self.obs_returned == 'aer':
+            self.observation[:] = obs
+            obs = self.observation
+        elif self.obs_returned != 'flatten':
+            obs = obs.reshape(self.m, 12)
+        e_t = time.time()
+        self.runtime['Observations and Reward'] += e_t - t_dev
+        self.runtime['step'] += e_t - step_s
+        if self.obs_returned == 'flatten':
+            return obs, self.rewards[i], done, {}
+        r = self.rewards[i]   # np.nan_to_num(..., nan=0.5, posinf=0.5, neginf=0.5) of a scalar (:365-367)
+        return obs, (r if np.isfinite(r) else np.float64(0.5)), done, {}
+
+    # ------------------------------------------------------------------ per-step host bookkeeping
+    def _book_update(self, i, a, rec):
+        """update record of step i (:292-315) into the env's sparse histories"""
         if rec[_lib.UPD_ACTION] >= 0:
             self._upd_action[i] = int(a)
             self._z_true[i] = rec[_lib.UPD_Z_TRUE:_lib.UPD_Z_TRUE + 3]
@@ -329,11 +352,9 @@ class SSA_Tasker_Env(Env):
                     self.S[i, int(a)] = self._S_sel[i]
                 self.sigmas_h[i] = rec[_lib.UPD_SIGMAS_H:_lib.UPD_SIGMAS_H + 39].reshape(13, 3)
                 self.obs_taken[i] = True
-        n_failed = int(self._stats[_lib.STAT_N_FAILED])
-        if n_failed != self._n_failed:
-            self._record_failures()
-        # reward / done (:324-354)
-        st = self._stats
+
+    def _reward_done(self, i, a, st, argmax_sigma_prev):
+        """reward / done of step i from its statistics (:324-354); fills self.rewards[i]"""
         max_dpos = st[_lib.STAT_MAX_DPOS]
         done = False
         if self.reward_type == 'jones':
@@ -352,25 +373,65 @@ class SSA_Tasker_Env(Env):
                 done, self.rewards[i] = True, 0
             elif max_dpos < 3e4:
                 done, self.rewards[i] = True, 1 - np.sum(self.rewards[:i])
-            elif a == self._argmax_sigma_prev:
+            elif a == argmax_sigma_prev:
                 self.rewards[i] = 1 / self.n
             else:
                 self.rewards[i] = -1 / self.n
-        if i + 1 >= self.n:
-            done = True
-        obs = obs_np
+        return done
+
+    def rollout(self, actions):
+        """Open-loop extension (no reference counterpart as ONE call): apply `actions` as consecutive step()
+        calls would -- the loop of the reference's agent_naive_random / round-robin drivers (agents.py,
+        tests.py:584-603) -- with up to H-1 steps per kernel launch (ssa_env_rollout_f64: state resident on
+        chip across the steps, results bit-identical to step()).  Stops at the first `done`.  Returns
+        (observation after the last executed step, rewards[k], dones[k], info).  Rewards 'jones' and
+        'trinary' (the 'shaped' reward needs the arg-max of sigma_pos of every step: use step())."""
+        import torch
+        if self.reward_type == 'shaped':
+            raise NotImplementedError("rollout: reward_type 'shaped' needs argmax(sigma_pos) per step; use step()")
+        actions = np.asarray(actions, dtype=np.int64).ravel()
+        for a in actions:
+            assert self.action_space.contains(int(a)), "%r invalid" % (a,)
+        e = self._engine
+        K = min(len(actions), self.n - 1 - self.i)
+        rewards, dones = [], []
+        pos, done = 0, False
+        while pos < K and not done:
+            kk = min(K - pos, e.H - 1)
+            i0 = self.i
+            act = torch.as_tensor(actions[pos:pos + kk].astype(np.int32)).view(kk, 1).to(e.dev)
+            e.launch_rollout(i0 % e.H, i0 + 1, act)
+            slots = [(i0 + 1 + k) % e.H for k in range(kk)]
+            stats = e.stats[slots, 0].cpu().numpy()          # synchronises the stream
+            upd = e.upd[slots, 0].cpu().numpy()
+            for k in range(kk):
+                self.i += 1
+                i, a = self.i, int(actions[pos + k])
+                self.actions[i] = a
+                self._book_update(i, a, upd[k])
+                self._stats = stats[k]
+                done = self._reward_done(i, a, stats[k], -1) or (i + 1 >= self.n)
+                r = self.rewards[i]
+                rewards.append(r if (self.obs_returned == 'flatten' or np.isfinite(r)) else np.float64(0.5))
+                dones.append(done)
+                if done:
+                    break
+            pos += kk
+        self._argmax_sigma = -1
+        if int(self._stats[_lib.STAT_N_FAILED]) != self._n_failed:
+            self._record_failures()
+        slot = self.i % e.H
         if self.obs_returned == 'aer':
-            self.observation[:] = obs
+            from .. import device
+            M = e.trans[self.i % e.n_time].reshape(3, 3)
+            device.aer_obs(e.x_filter[slot], e.P_filter[slot], M, self._consts, out=self._aer_dev.view(self.m, 4))
+            self.observation[:] = self._aer_dev.cpu().numpy()
             obs = self.observation
-        elif self.obs_returned != 'flatten':
-            obs = obs.reshape(self.m, 12)
-        e_t = time.time()
-        self.runtime['Observations and Reward'] += e_t - t_dev
-        self.runtime['step'] += e_t - step_s
-        if self.obs_returned == 'flatten':
-            return obs, self.rewards[i], done, {}
-        r = self.rewards[i]   # np.nan_to_num(..., nan=0.5, posinf=0.5, neginf=0.5) of a scalar (:365-367)
-        return obs, (r if np.isfinite(r) else np.float64(0.5)), done, {}
+        elif self.obs_returned == 'flatten':
+            obs = e.obs[slot].cpu().numpy().reshape(-1)
+        else:
+            obs = e.obs[slot].cpu().numpy()
+        return obs, np.asarray(rewards), np.asarray(dones, dtype=bool), {}
 
     # ------------------------------------------------------------------ failures (:369-382)
     def _record_failures(self):

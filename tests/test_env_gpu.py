@@ -264,3 +264,44 @@ def test_second_reset_starts_a_fresh_episode(envs):
     assert np.array_equal(obs.reshape(5, 12)[:, :6], env.x_filter[0])
     obs, r, done, _ = env.step(2)
     assert env.i == 1 and env.obs_taken[1] and not done
+
+
+@pytest.mark.parametrize("mode,reward,hist", [('flatten', 'trinary', 'full'), ('aer', 'trinary', 7), ('2darray', 'jones', 'full')])
+def test_env_rollout_equals_step_loop(envs, mode, reward, hist):
+    """SSA_Tasker_Env.rollout(actions) (open-loop extension: K steps per launch) against the same env driven by
+    step(): rewards, dones, the returned observation, the episode index, the filter histories and the update
+    bookkeeping are identical -- also with a short history ring (several launches) and with a 'jones' episode
+    that terminates inside the rollout."""
+    cfg = dict(envs.env_config)
+    cfg.update(rso_count=24, steps=40, seed=11, obs_returned=mode, reward_type=reward, history=hist)
+    acts = [(5 * k + 1) % 24 for k in range(25)]
+    a, b = envs.make('ssa_tasker_simple-v2', config=cfg), envs.make('ssa_tasker_simple-v2', config=cfg)
+    oa, ob = a.reset(), b.reset()
+    assert np.array_equal(oa, ob)
+    ra, da = [], []
+    for k in acts:
+        o1, r, d, _ = a.step(k)
+        ra.append(r)
+        da.append(d)
+        if d:
+            break
+    o2, rb, db, info = b.rollout(acts)
+    assert info == {} and len(rb) == len(ra) and list(db) == da
+    assert np.array_equal(np.asarray(ra, dtype=float), rb.astype(float))
+    assert a.i == b.i and np.array_equal(o1, o2, equal_nan=True) and o1.shape == o2.shape
+    i = a.i
+    for name in ("x_true", "x_filter", "P_filter", "delta_pos"):
+        assert np.array_equal(np.asarray(getattr(a, name)[i]), np.asarray(getattr(b, name)[i]), equal_nan=True), name
+    assert np.array_equal(a.rewards[:i + 1], b.rewards[:i + 1]) and np.array_equal(a.actions[:i + 1], b.actions[:i + 1])
+    assert np.array_equal(a.obs_taken[:i + 1], b.obs_taken[:i + 1]) and a.obs_taken[:i + 1].any()
+    assert np.array_equal(np.asarray(a.y[i]), np.asarray(b.y[i]), equal_nan=True)
+    # the env keeps stepping normally after a rollout
+    if not da[-1]:
+        o1, r1, d1, _ = a.step(3)
+        o2, r2, d2, _ = b.step(3)
+        assert np.array_equal(o1, o2, equal_nan=True) and r1 == r2 and d1 == d2
+    with pytest.raises(NotImplementedError):
+        cfg['reward_type'] = 'shaped'
+        c = envs.make('ssa_tasker_simple-v2', config=cfg)
+        c.reset()
+        c.rollout([0, 1])
