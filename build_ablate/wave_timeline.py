@@ -24,6 +24,9 @@ local = parallel.HipLocalStepper(eng, consts, fast_stats=True)
 local.load_schedule(np.arange(400) % m)
 for k in range(int(os.environ.get("STEPS", 100))):
     local.step(-1)
+local.flush()
+if os.environ.get("ROLL"):      # the stamps then belong to the LAST step of a rollout launch (steady state)
+    local.rollout(int(os.environ["ROLL"]))
 torch.cuda.synchronize()
 lib = _lib.load()
 nb = (m + 3) // 4

@@ -1020,7 +1020,15 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(const Ste
         tile_issue(pf, k_arg.p, lane, b0, tile < ntiles ? (int)((total - b0) < OBJ_PER_WAVE ? (total - b0) : OBJ_PER_WAVE) : 0);
     }
     KernargPtr kp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned wave_slot, turn = 0;   // issue priority rotated per tile: see rollout_kernel
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(wave_slot));
     for (; tile < ntiles; tile += nwork) {
+        switch ((wave_slot + turn++) & 3u) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
         // the body must compile like a one-tile kernel: re-derive the argument block and the lane id per
         // tile, so that the ~100 argument scalars and the lane-derived LDS addresses are produced on demand
         // instead of being carried around the loop in registers
@@ -1072,8 +1080,24 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) rollout_kernel(const RollK
             tile_issue(pf, p0, lane, base, cnt);
             tile_commit(t, pf, lane);
         }
+        unsigned wave_slot;   // the wavefront's slot on its SIMD (HW_ID bits 3:0)
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(wave_slot));
         for (int kk = 0; kk < K; ++kk) {
+#ifndef SSA_ROLL_NOPRIO
+            // The SIMD arbiter serves the oldest wavefront first: left alone, the 5 co-resident wavefronts finish
+            // their K steps one after the other and the SIMD runs the tail of the launch with 4, 3, 2, 1 of them
+            // (latency-bound).  Rotating the issue priority per step keeps them level, so all stay resident and
+            // the stages of different wavefronts interleave until the end.
+            switch ((wave_slot + (unsigned)kk) & 3u) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+            }
+#endif
+#ifndef SSA_ROLL_HOIST
             asm volatile("" : "+s"(kp));      // per step, as per tile in step_fast_kernel: nothing carried around the loop
+#endif
             asm volatile("" : "+v"(lane));
             const StepK& k = ((const RollK*)kp)->k;
             const ssa_rollout_params& r = ((const RollK*)kp)->r;
