@@ -53,12 +53,14 @@ def build_problem(m, seed, n_time=480):
     return dict(x_true=x_true, x=x, P0=P0, Q=Q, R=R, obs_lla=obs_lla, trans=trans, z_sigma=z_sigma)
 
 
-def cpu_baseline(m, budget_s=15.0):
-    """single-core C oracle (oracle/ssa_oracle.c), same step definition, bounded sample."""
+def cpu_baseline(m, budget_s=15.0, all_cores=False):
+    """C oracle (oracle/ssa_oracle.c), same step definition, bounded sample: one host core, or (all_cores) its
+    OpenMP build over the cores this process may run on."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
     orc.build()
-    o = orc.Oracle()
+    o = orc.Oracle(omp=all_cores)
+    cores = o.lib.orc_omp_threads(len(os.sched_getaffinity(0))) if all_cores else 1
     pb = build_problem(m, seed=0)
     Wm, Wc, scale = orc.merwe_weights(1e-4, 2.0, -3)
     xt, x, P = pb["x_true"], pb["x"], np.tile(pb["P0"], (m, 1, 1))
@@ -75,8 +77,9 @@ def cpu_baseline(m, budget_s=15.0):
         el = time.perf_counter() - t0
         if el > budget_s or steps >= 200:
             break
-    return {"value": steps / el, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": "%d steps of the %d-object env on one host core (oracle/ssa_oracle.c, gcc -O2), %.1f s" % (steps, m, el)}
+    return {"value": steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d steps of the %d-object env on %d host core(s) (oracle/ssa_oracle.c, gcc -O2%s), %.1f s"
+                      % (steps, m, cores, " -fopenmp" if all_cores else "", el)}
 
 
 def main():
@@ -258,9 +261,10 @@ def main():
                 "failed_filters": int((eng.status != 0).sum().item()),
                 "note": "open-loop schedule only (actions of a launch known up front); bit-identical to per-step launches"}
 
-    cpu = None
+    cpu, cpu_all = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N=1 only
         cpu = cpu_baseline(m)
+        cpu_all = cpu_baseline(m, budget_s=8.0, all_cores=True)
 
     if rank == 0:
         steps_per_s = K / elapsed
@@ -282,10 +286,11 @@ def main():
                        "allgather_warmup_probe": allgather_probe},
             "object_steps_per_sec": round(steps_per_s * m * world, 1),
             "failed_filters": n_failed,
-            "roofline": roof, "cpu_baseline": cpu, "rollout": roll,
+            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "rollout": roll,
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(steps_per_s * world / cpu["value"], 1)
+            out["speedup_vs_cpu_baseline_all_cores"] = round(steps_per_s * world / cpu_all["value"], 1)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

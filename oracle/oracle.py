@@ -49,8 +49,8 @@ def _p(a):
 
 
 class Oracle:
-    def __init__(self, long_double=False):
-        name = "libssa_oracle_ld.so" if long_double else "libssa_oracle.so"
+    def __init__(self, long_double=False, omp=False):
+        name = "libssa_oracle_ld.so" if long_double else ("libssa_oracle_omp.so" if omp else "libssa_oracle.so")
         path = os.path.join(_HERE, name)
         if not os.path.exists(path):
             build()
@@ -74,6 +74,8 @@ class Oracle:
                                    C.c_double, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int,
                                    _dp, _dp, _dp, C.c_double, _dp, _dp, _dp, _dp, _dp]
         L.orc_aer_obs.argtypes = [_dp, _dp, _dp, _dp, _dp, _dp, C.c_long]
+        L.orc_omp_threads.argtypes = [C.c_int]
+        L.orc_omp_threads.restype = C.c_int
 
     # ---- P1-P5
     def propagate(self, x, dt):

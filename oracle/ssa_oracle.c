@@ -644,6 +644,13 @@ static int ukf_update(real *x, real *P, real *sigmas_f, const real *z, const rea
 static void ld(const double *s, real *d, int n) { for (int i = 0; i < n; ++i) d[i] = (real)s[i]; }
 static void st(const real *s, double *d, int n) { for (int i = 0; i < n; ++i) d[i] = (double)s[i]; }
 
+#ifdef _OPENMP
+#include <omp.h>
+int orc_omp_threads(int set) { if (set > 0) omp_set_num_threads(set); return omp_get_max_threads(); }
+#else
+int orc_omp_threads(int set) { (void)set; return 1; }
+#endif
+
 void orc_propagate(const double *x_in, double *x_out, long n, double dt)
 {
     for (long j = 0; j < n; ++j) {
@@ -794,12 +801,20 @@ void orc_env_step(const double *x_true_in, double *x_true_out, const double *x_i
     real qq[36], rr[9], wm[NS], wc[NS], mm[9], ll[3], oo[3];
     ld(Q, qq, 36); ld(R, rr, 9); ld(Wm, wm, NS); ld(Wc, wc, NS); ld(M, mm, 9); ld(obs_lla, ll, 3); ld(obs_itrs, oo, 3);
     for (int c = 0; c < 16; ++c) upd_out[c] = (c == 0) ? 0.0 : NAN;
+    /* the per-object loops are independent; the OpenMP build (libssa_oracle_omp.so) is bench.py's "all host cores"
+     * CPU baseline (CPU-N) -- same arithmetic, same results */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (long j = 0; j < m; ++j) { /* propagate next true state (:265-266) */
         real x[6], o[6];
         ld(x_true_in + 6 * j, x, 6);
         fx_farnocchia(x, (real)dt, o);
         st(o, x_true_out + 6 * j, 6);
     }
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 64)
+#endif
     for (long j = 0; j < m; ++j) { /* perform predictions (:271-287) */
         real x[6], P[36], sf[NS * NX];
         ld(x_in + 6 * j, x, 6); ld(P_in + 36 * j, P, 36);
