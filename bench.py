@@ -53,6 +53,26 @@ def build_problem(m, seed, n_time=480):
     return dict(x_true=x_true, x=x, P0=P0, Q=Q, R=R, obs_lla=obs_lla, trans=trans, z_sigma=z_sigma)
 
 
+def host_cpu_share():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a container that sees
+    256 CPUs with a 16-CPU quota collapses when 256 threads share it: 3.9 env-steps/s against 144 with 16,
+    build_ablate/cpu_threads_sweep.py)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())             # cgroup v1
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(m, budget_s=15.0, all_cores=False):
     """C oracle (oracle/ssa_oracle.c), same step definition, bounded sample: one host core, or (all_cores) its
     OpenMP build over the cores this process may run on."""
@@ -60,7 +80,7 @@ def cpu_baseline(m, budget_s=15.0, all_cores=False):
     import oracle as orc
     orc.build()
     o = orc.Oracle(omp=all_cores)
-    cores = o.lib.orc_omp_threads(len(os.sched_getaffinity(0))) if all_cores else 1
+    cores = o.lib.orc_omp_threads(host_cpu_share()) if all_cores else 1
     pb = build_problem(m, seed=0)
     Wm, Wc, scale = orc.merwe_weights(1e-4, 2.0, -3)
     xt, x, P = pb["x_true"], pb["x"], np.tile(pb["P0"], (m, 1, 1))
@@ -75,7 +95,7 @@ def cpu_baseline(m, budget_s=15.0, all_cores=False):
         xt, x, P = r["x_true"], r["x"], r["P"]
         steps += 1
         el = time.perf_counter() - t0
-        if el > budget_s or steps >= 200:
+        if el > budget_s or steps >= 2000:
             break
     return {"value": steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": "%d steps of the %d-object env on %d host core(s) (oracle/ssa_oracle.c, gcc -O2%s), %.1f s"
