@@ -522,9 +522,10 @@ def test_deferred_statistics_fold_equals_immediate_fold(hip, E, m):
     assert outs[0][0][1, 0, hip.lib.STAT_MAX_DPOS] > 1e19 and outs[0][0][K, 0, hip.lib.STAT_N_FAILED] >= 1   # the NaN state failed: sentinels
 
 
-@pytest.mark.parametrize("propagator", ["fg", "j2"])
+@pytest.mark.parametrize("propagator,obs_type,resample,interval", [("fg", "aer", False, 1), ("j2", "aer", False, 1),
+                                                                    ("fg", "xyz", True, 1), ("fg", "aer", True, 3)])
 @pytest.mark.parametrize("E,m,K,H", [(1, 2003, 7, 8), (3, 50, 9, 4), (2, 30001, 3, 2)])
-def test_rollout_equals_single_steps(hip, E, m, K, H, propagator):
+def test_rollout_equals_single_steps(hip, E, m, K, H, propagator, obs_type, resample, interval):
     """ssa_env_rollout_f64: K steps in one launch (state resident in LDS across the steps) must reproduce K
     ssa_env_step_f64 launches BITWISE: every surviving history slot (states, covariances, observations,
     metrics, update records), status, and the statistics of the last min(K, H) steps.  Sizes cover several
@@ -532,7 +533,9 @@ def test_rollout_equals_single_steps(hip, E, m, K, H, propagator):
     (K > H), a failing filter and an update in every step."""
     xt, x, P, g = make_batch(E * m, seed=123)
     x[9, 1] = np.nan
-    consts = hip.host.make_consts(g["Q"], g["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, g["obs_lla"], propagator=propagator)
+    R = g["R"] if obs_type == "aer" else np.diag([5e2 ** 2] * 3)
+    consts = hip.host.make_consts(g["Q"], R, 1e-4, 2.0, -3, 20.0, -np.pi / 2, g["obs_lla"], propagator=propagator,
+                                  obs_type=obs_type, resample=resample, update_interval=interval)
     n_time = c2t().shape[0]
     acts = np.array([[(7 * e + 3 * k) % m for e in range(E)] for k in range(K)], dtype=np.int32)
     zn_host = np.random.RandomState(8).normal(size=(n_time, m, 3)) * np.array([4.8e-6, 4.8e-6, 1e3]) if m < 5000 else None
@@ -552,6 +555,20 @@ def test_rollout_equals_single_steps(hip, E, m, K, H, propagator):
         outs.append([t.cpu().numpy() for t in (eng.x_true, eng.x_filter, eng.P_filter, eng.obs, eng.metrics, eng.upd, eng.status,
                                                eng.stats)] + [eng._shard_sets.cpu().numpy()])
     a, b = outs
+    L = hip.lib
+
+    def defined_fields(u):
+        """an update record defines its flags always, z_true when the object was visible, y / S / sigmas_h when the
+        observation was taken; the other words of a ring slot are leftovers of the step that used it before"""
+        u = u.copy()
+        vis, taken = u[..., L.UPD_VISIBLE] == 1.0, u[..., L.UPD_OBS_TAKEN] == 1.0
+        keep = np.zeros(u.shape, dtype=bool)
+        keep[..., [L.UPD_OBS_TAKEN, L.UPD_VISIBLE, L.UPD_ACTION]] = True
+        keep[..., L.UPD_Z_TRUE:L.UPD_Z_TRUE + 3] = vis[..., None]
+        keep[..., L.UPD_Y:L.UPD_SIGMAS_H + 39] = taken[..., None]
+        u[~keep] = 0.0
+        return u
+    a[5], b[5] = defined_fields(a[5]), defined_fields(b[5])
     names = ("x_true", "x_filter", "P_filter", "obs", "metrics", "upd", "status")
     for nme, u, v in zip(names, a, b):
         if nme == "metrics" or u.ndim == 1 or K >= H:
@@ -559,7 +576,6 @@ def test_rollout_equals_single_steps(hip, E, m, K, H, propagator):
         else:   # slots never written keep their initial fill
             sl = [s_ % H for s_ in range(0, K + 1)]
             assert np.array_equal(u[sl], v[sl], equal_nan=True), nme
-    L = hip.lib
     for k in range(max(0, K - H), K):                     # statistics of the steps whose slot survives
         so = (k + 1) % H
         for sidx in (L.STAT_MAX_DPOS, L.STAT_CNT_LT_1E4, L.STAT_CNT_LT_1E7, L.STAT_N_FAILED):
