@@ -916,9 +916,38 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     if (FAST) {
         store_tile(t, p, lane, base, cnt);
         SSA_TR(8);
-        if (p.stat_shards && PROP != 0 && lane == 0) {
-            // O3 by sharded atomics: max delta_pos (as ordered bits: non-negative doubles and NaN order like
-            // unsigned integers, so NaN wins exactly as in np.max), trinary counts, failures
+        // O3 by sharded atomics: max delta_pos (as ordered bits: non-negative doubles and NaN order like unsigned
+        // integers, so NaN wins exactly as in np.max), trinary counts (packed in one word), failures
+        const bool one_env = p.n_env == 1 || ((uint32_t)base / (uint32_t)p.n_obj == (uint32_t)(base + cnt - 1) / (uint32_t)p.n_obj);
+        if (p.stat_shards && PROP != 0 && one_env) {
+            // common case, the tile lies in one env: every lane takes its row's values, two cross-row DPP steps
+            // (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) leave the tile's totals in row 3
+            const double dp = t.Met[g * 4 + 0];
+            const bool rv = g < cnt;
+            unsigned long long mx = rv ? ((unsigned long long)__double_as_longlong(dp) & 0x7fffffffffffffffull) : 0ull;
+            unsigned long long cn = rv ? ((unsigned long long)(dp < 1e4) + ((unsigned long long)(dp < 1e7) << 32)) : 0ull;
+            int nfl = (rv && t.St[g] != 0) ? 1 : 0;
+#define SSA_XROW(CTRL, ROWMASK)                                                                                          \
+            {                                                                                                            \
+                const unsigned long long m2 = ((unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(0, (int)(mx >> 32), CTRL, ROWMASK, 0xF, false) << 32) | \
+                                              (unsigned)__builtin_amdgcn_update_dpp(0, (int)(mx & 0xffffffffull), CTRL, ROWMASK, 0xF, false);                 \
+                const unsigned long long c2 = ((unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(0, (int)(cn >> 32), CTRL, ROWMASK, 0xF, false) << 32) | \
+                                              (unsigned)__builtin_amdgcn_update_dpp(0, (int)(cn & 0xffffffffull), CTRL, ROWMASK, 0xF, false);                 \
+                nfl += __builtin_amdgcn_update_dpp(0, nfl, CTRL, ROWMASK, 0xF, false);                                   \
+                mx = m2 > mx ? m2 : mx;                                                                                  \
+                cn += c2;                                                                                                \
+            }
+            SSA_XROW(0x142, 0xA)   // row_bcast:15
+            SSA_XROW(0x143, 0xC)   // row_bcast:31
+#undef SSA_XROW
+            if (lane == 63) {
+                const int64_t e_tile = (p.n_env > 1) ? (int64_t)((uint32_t)base / (uint32_t)p.n_obj) : 0;
+                unsigned long long* sh = (unsigned long long*)p.stat_shards + ((e_tile * SSA_STAT_SHARDS) + (tile & (SSA_STAT_SHARDS - 1))) * 4;
+                atomicMax(sh, mx);
+                atomicAdd(sh + 1, cn);
+                if (nfl) atomicAdd(sh + 2, (unsigned long long)nfl);
+            }
+        } else if (p.stat_shards && PROP != 0 && lane == 0) {   // a tile that straddles envs: one group of atomics per env
             int64_t e_cur = -1;
             unsigned long long mx = 0ull, cnts = 0ull, nf = 0ull;
             const int64_t e_first = (p.n_env > 1) ? (int64_t)((uint32_t)base / (uint32_t)p.n_obj) : 0;
