@@ -258,7 +258,7 @@ def main():
     # launch -- what an open-loop schedule such as this protocol's round-robin allows (state resident in LDS across
     # the steps of a launch; every step's outputs still written)
     roll = None
-    if rank == 0 and world == 1 and not use_dist and args.rollout > 0 and args.propagator != "elements":
+    if rank == 0 and world == 1 and not use_dist and args.rollout > 0:
         R = args.rollout
 
         def roll_steps(n):

@@ -255,6 +255,14 @@ __device__ __noinline__ Vec6 kepler_general_v(Vec6 x, double tof)
     kepler_general_impl(x.v, tof, o.v, nullptr);
     return o;
 }
+// the step kernels' own instance (inherits their register budget; spills inside it are confined to the rare call)
+template <int TAG>
+__device__ __noinline__ Vec6 kepler_general_tagged(Vec6 x, double tof)
+{
+    Vec6 o;
+    kepler_general_impl(x.v, tof, o.v, nullptr);
+    return o;
+}
 __device__ __noinline__ Vec8 kepler_general_diag_v(Vec6 x, double tof, Vec6* out)
 {
     Vec8 d;
@@ -656,15 +664,17 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
 #pragma unroll
                 for (int c = 0; c < 6; ++c) o[c] = __builtin_nan("");
             }
-        } else if (FAST) {
-            need_full = need_full || (((__ballot(!kep_ok && l < 14) >> (g * 16)) & 0xFFFFull) != 0);
-        } else if (!kep_ok) {
-            Vec6 si;
+        } else if (__any(!kep_ok)) {
+            // SSA_PROP_ELEMENTS outside the strong-elliptic regime (or NaN input): the complete restatement of
+            // farnocchia(), out of line, for the lanes that need it (whole-wave branch: skipped otherwise)
+            if (!kep_ok) {
+                Vec6 si;
 #pragma unroll
-            for (int c = 0; c < 6; ++c) si.v[c] = s[c];
-            Vec6 oo = kepler_general_v(si, C.dt);
+                for (int c = 0; c < 6; ++c) si.v[c] = s[c];
+                Vec6 oo = FAST ? kepler_general_tagged<1>(si, C.dt) : kepler_general_v(si, C.dt);
 #pragma unroll
-            for (int c = 0; c < 6; ++c) o[c] = oo.v[c];
+                for (int c = 0; c < 6; ++c) o[c] = oo.v[c];
+            }
         }
     }
     wave_lds_sync();   // every lane has consumed t.X / t.T / t.U
@@ -919,7 +929,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         // O3 by sharded atomics: max delta_pos (as ordered bits: non-negative doubles and NaN order like unsigned
         // integers, so NaN wins exactly as in np.max), trinary counts (packed in one word), failures
         const bool one_env = p.n_env == 1 || ((uint32_t)base / (uint32_t)p.n_obj == (uint32_t)(base + cnt - 1) / (uint32_t)p.n_obj);
-        if (p.stat_shards && PROP != 0 && one_env) {
+        if (p.stat_shards && one_env) {
             // common case, the tile lies in one env: every lane takes its row's values, two cross-row DPP steps
             // (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) leave the tile's totals in row 3
             const double dp = t.Met[g * 4 + 0];
@@ -947,7 +957,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                 atomicAdd(sh + 1, cn);
                 if (nfl) atomicAdd(sh + 2, (unsigned long long)nfl);
             }
-        } else if (p.stat_shards && PROP != 0 && lane == 0) {   // a tile that straddles envs: one group of atomics per env
+        } else if (p.stat_shards && lane == 0) {   // a tile that straddles envs: one group of atomics per env
             int64_t e_cur = -1;
             unsigned long long mx = 0ull, cnts = 0ull, nf = 0ull;
             const int64_t e_first = (p.n_env > 1) ? (int64_t)((uint32_t)base / (uint32_t)p.n_obj) : 0;
@@ -1196,7 +1206,7 @@ __global__ void __launch_bounds__(POST_T) step_post_kernel(const StepK k, StatAc
             }
         }
     }
-    if (p.stat_shards && PROP != 0) {
+    if (p.stat_shards) {
         // statistics were accumulated by the common-path kernel (complete before this launch): fold them here
         if (blockIdx.x == 0 && w == 0) fold_stat_shards((unsigned long long*)p.stat_shards, p.stats, e, lane);
     } else if (p.stats) {
@@ -1657,7 +1667,7 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
     const int64_t slots = (int64_t)device_cu_count() * 4 * SSA_STEP_WAVES;
     const int64_t per_wave = (ntiles + slots - 1) / slots;
     const int nwork = (int)((ntiles + per_wave - 1) / per_wave);
-    const bool fast_stats = p->stat_shards && c->propagator != SSA_PROP_ELEMENTS;   // statistics by the common-path kernel's atomics
+    const bool fast_stats = p->stat_shards != nullptr;   // statistics by the common-path kernel's atomics
     const bool defer = fast_stats && !p->aer_out && (p->launch_mask & SSA_LAUNCH_DEFER_FOLD);
     if (defer && p->stat_shards_prev && (!p->stats_prev || p->stat_shards_prev == p->stat_shards)) return SSA_E_INVALID;
     const int nfold = (defer && p->stat_shards_prev) ? p->n_env : 0;
@@ -1730,7 +1740,7 @@ int ssa_env_rollout_f64(const ssa_consts* c, const ssa_step_params* p, const ssa
         return SSA_E_INVALID;
     if (!p->status || !p->trans || !p->env_time || !p->z_noise || !p->work) return SSA_E_INVALID;
     if (c->obs_type != SSA_OBS_AER && c->obs_type != SSA_OBS_XYZ) return SSA_E_INVALID;
-    if (c->propagator != SSA_PROP_FG && c->propagator != SSA_PROP_J2_RK4) return SSA_E_INVALID;   // ELEMENTS queues exceptions per step
+    if (c->propagator != SSA_PROP_FG && c->propagator != SSA_PROP_ELEMENTS && c->propagator != SSA_PROP_J2_RK4) return SSA_E_INVALID;
     if (c->propagator == SSA_PROP_J2_RK4 && (c->rk4_substeps < 1 || c->rk4_substeps > 4096)) return SSA_E_INVALID;
     const int64_t total = (int64_t)p->n_env * p->n_obj;
     if (total >= ((int64_t)1 << 31)) return SSA_E_INVALID;
@@ -1745,6 +1755,7 @@ int ssa_env_rollout_f64(const ssa_consts* c, const ssa_step_params* p, const ssa
     const int nwork = (int)((ntiles + per_wave - 1) / per_wave);
     hipStream_t s = (hipStream_t)stream;
     if (c->propagator == SSA_PROP_FG) hipLaunchKernelGGL(rollout_kernel<1>, dim3(nwork), dim3(64), 0, s, rk, (int)ntiles, nwork);
+    else if (c->propagator == SSA_PROP_ELEMENTS) hipLaunchKernelGGL(rollout_kernel<0>, dim3(nwork), dim3(64), 0, s, rk, (int)ntiles, nwork);
     else hipLaunchKernelGGL(rollout_kernel<2>, dim3(nwork), dim3(64), 0, s, rk, (int)ntiles, nwork);
     hipLaunchKernelGGL(rollout_fold_kernel, dim3(r->n_steps, p->n_env), dim3(64), 0, s, (unsigned long long*)r->stat_shards, r->stats_ring,
                        p->n_env, r->n_steps, r->slot_out, r->history);

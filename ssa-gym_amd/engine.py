@@ -149,7 +149,7 @@ class HotPathEngine:
         p.aer_out = aer_out
         # two-launch path (no arg-max of sigma_pos): see include/ssa_hip.h ssa_step_params.stat_shards
         s = torch.cuda.current_stream().cuda_stream if stream is None else stream
-        defer = bool(defer_fold and fast_stats and not aer_out and self.consts.propagator != _lib.PROP_ELEMENTS)
+        defer = bool(defer_fold and fast_stats and not aer_out)
         if not defer and self._fold_pending is not None:
             self.flush_stats(s)       # a deferred step is followed by an immediate one: fold it first (same stream, in order)
         p.stat_shards = self._shard_sets[self._shard_cur].data_ptr() if fast_stats else 0
@@ -174,8 +174,6 @@ class HotPathEngine:
         """K = actions.shape[0] consecutive steps in one launch (include/ssa_hip.h: ssa_env_rollout_f64): step k reads
         history slot (slot_in + k) % H, writes (slot_in + k + 1) % H and has time index time_offset + k.  `actions`
         is a device int32 tensor [K][E] (open-loop schedule).  Statistics: the last min(K, H) steps' slots."""
-        if self.consts.propagator == _lib.PROP_ELEMENTS:
-            raise _lib.SsaHipError("rollout: propagator 'elements' queues exceptions per step; use 'fg' or 'j2'")
         if not (isinstance(actions, torch.Tensor) and actions.is_cuda and actions.dtype == torch.int32 and actions.is_contiguous()
                 and actions.dim() == 2 and actions.shape[1] == self.E and actions.shape[0] >= 1):
             raise _lib.SsaHipError("rollout: actions must be a contiguous CUDA int32 tensor [K][n_env]")

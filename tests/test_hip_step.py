@@ -523,6 +523,7 @@ def test_deferred_statistics_fold_equals_immediate_fold(hip, E, m):
 
 
 @pytest.mark.parametrize("propagator,obs_type,resample,interval", [("fg", "aer", False, 1), ("j2", "aer", False, 1),
+                                                                    ("elements", "aer", False, 1),
                                                                     ("fg", "xyz", True, 1), ("fg", "aer", True, 3)])
 @pytest.mark.parametrize("E,m,K,H", [(1, 2003, 7, 8), (3, 50, 9, 4), (2, 30001, 3, 2)])
 def test_rollout_equals_single_steps(hip, E, m, K, H, propagator, obs_type, resample, interval):
