@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SSA_ABI_VERSION 11
+#define SSA_ABI_VERSION 12
 
 /* error codes */
 #define SSA_OK 0
@@ -126,10 +126,10 @@ typedef struct ssa_step_params {
     uint32_t launch_mask;      /* 0 = everything; diagnostic: 1 common-path kernel, 2 post kernel, 4 final;
                                   SSA_LAUNCH_DEFER_FOLD (8): see stat_shards_prev */
     double *stats;             /* [E][SSA_STAT_STRIDE] reward statistics of this step (O3), may be NULL */
-    int32_t *work;             /* ssa_env_step_work_bytes(): exception queue; zero it once before the first call */
+    int32_t *work;             /* unused since ABI 12 (the exception queue is gone); may be NULL */
     void *stat_ws;             /* ssa_reward_stats_workspace_bytes(): per-block statistics partials */
-    uint64_t *stat_shards;     /* [E][SSA_STAT_SHARDS][4] zero-initialised device words, or NULL.  When given (and the
-                                  propagator is not ELEMENTS) the common-path kernel accumulates max delta_pos / trinary
+    uint64_t *stat_shards;     /* [E][SSA_STAT_SHARDS][4] zero-initialised device words, or NULL.  When given the
+                                  step kernel accumulates max delta_pos / trinary
                                   counts / failures itself with sharded atomics; a one-wave fold kernel -- or, with
                                   aer_out, the post kernel's first wavefront -- writes `stats` and clears the words: two
                                   launches per step instead of three.  arg-max sigma_pos (only the 'shaped' reward needs
@@ -146,14 +146,14 @@ typedef struct ssa_step_params {
 } ssa_step_params;
 
 /* ---------------------------------------------------------------- fused hot path
- * One env step for every object of every env.  Launches:
- *   stat_shards given, FG / J2 propagator : the step kernel (4 objects per wavefront, the update and the reward
- *       statistics included) + a one-wave fold -- or + the post kernel when aer_out asks for the O4 payload -- or
- *       nothing more with SSA_LAUNCH_DEFER_FOLD (the next step's launch folds): 2 / 2 / 1 launches;
- *   otherwise (ELEMENTS propagator, or exact arg-max sigma_pos wanted): the common-path kernel, which queues
- *       objects that need robust_cholesky's jitter ladder or a non-strong-elliptic conic branch; a post kernel
- *       that re-does the queued objects with complete semantics and reduces the statistics per block; a one-wave
- *       kernel that folds them and resets the queue: 3 launches. */
+ * One env step for every object of every env, every propagator:
+ * the step kernel advances 4 objects per wavefront with complete semantics (robust_cholesky's jitter ladder inline,
+ * conic branches beyond the strong-elliptic one as out-of-line calls), the update and -- with stat_shards -- the
+ * reward statistics included.  Launches per step:
+ *   stat_shards given : step kernel + a one-wave fold; or + the post kernel when aer_out asks for the O4 payload
+ *       (it folds as well); or nothing more with SSA_LAUNCH_DEFER_FOLD (the next step's launch folds): 2 / 2 / 1;
+ *   stat_shards NULL  : step kernel + post kernel (exact statistics per block, arg-max sigma_pos included, and the
+ *       payload) + a one-wave fold of those: 3 launches. */
 int ssa_env_step_f64(const ssa_consts *c_host, const ssa_step_params *p_host, void *stream);
 /* Same step, with the dominant launch (the common-path kernel) bracketed by the event pair `slot`
  * (0 <= slot < SSA_PROFILE_SLOTS) bound to that dispatch: ssa_env_step_profile_ms() then returns the kernel's
@@ -170,8 +170,7 @@ int ssa_env_step_profile_ms(int32_t slot, float *kernel_ms);
  * K calls ssa_env_step_f64 would make, with every step's outputs written to that step's slot of the history rings and
  * results bit-identical to them, but each wavefront keeps its objects' state in LDS across the steps (an object's
  * trajectory depends on no other object).  `first` is the parameter block of the FIRST step (n_obj, n_env, time_offset,
- * status, trans, env_time, z_noise and strides, n_time, work; its in/out/stats pointers are ignored).  Propagators FG
- * and J2 only.  Two launches: the rollout kernel and a fold of the per-step statistics. */
+ * status, trans, env_time, z_noise and strides, n_time; its in/out/stats pointers are ignored).  Two launches: the rollout kernel and a fold of the per-step statistics. */
 typedef struct ssa_rollout_params {
     int32_t n_steps;           /* K >= 1 */
     int32_t history;           /* H >= 2: depth of the rings below */
@@ -192,7 +191,7 @@ int ssa_env_rollout_f64(const ssa_consts *c_host, const ssa_step_params *first, 
 /* folds a shard set into stats[n_env][SSA_STAT_STRIDE] and clears it: the last step of a deferred-fold sequence,
  * or whenever the host wants the statistics of the step just launched */
 int ssa_stats_fold_f64(uint64_t *stat_shards, double *stats, int32_t n_env, void *stream);
-/* bytes of the int32 `work` buffer for n_env environments of n_obj objects */
+/* historical: size of the `work` buffer (now unused); returns a token size */
 int64_t ssa_env_step_work_bytes(int64_t n_obj, int32_t n_env);
 
 /* O3: per-env reductions over metrics[E][4][m] and status -> stats[E][SSA_STAT_STRIDE]

@@ -45,7 +45,7 @@ class ssa_rollout_params(C.Structure):
 
 
 # constants of include/ssa_hip.h
-ABI_VERSION = 11
+ABI_VERSION = 12
 ST_OK, ST_PREDICT_NAN, ST_PREDICT_LINALG, ST_UPDATE_NAN, ST_UPDATE_LINALG = range(5)
 OBS_AER, OBS_XYZ = 0, 1
 PROP_ELEMENTS, PROP_FG, PROP_J2_RK4 = 0, 1, 2

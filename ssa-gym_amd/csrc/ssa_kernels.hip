@@ -274,7 +274,7 @@ __device__ __noinline__ Vec8 kepler_general_diag_v(Vec6 x, double tof, Vec6* out
 
 // ------------------------------------------------------------------------------------------
 // fused env step: ONE launch per step over every object.  The common path (plain Cholesky,
-// strong-elliptic Kepler) is inline; the robust_cholesky jitter ladder and the other conic branches
+// strong-elliptic Kepler) and robust_cholesky's jitter ladder are inline; the other conic branches
 // are out-of-line calls taken only by the lanes that need them.  The per-env UKF update runs in the
 // row that owns the selected object, hidden among the other waves of the launch.
 struct StepK {
@@ -296,36 +296,6 @@ struct alignas(16) Tiles {   // LDS working set of one wavefront (4 objects)
     double Met[OBJ_PER_WAVE * 4];
     int St[OBJ_PER_WAVE];
 };
-
-// per-row (16-lane) gather of one object's state into the tiles; objects of a fast-kernel wave are
-// consecutive, so the four rows together read one contiguous 1152-byte span of P (coalesced).
-SSA_DEV void load_object(Tiles& t, const ssa_step_params& p, int g, int l, int64_t obj, bool valid)
-{
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        int idx = l + 16 * r;
-        if (idx < 36) t.P[g * 36 + idx] = valid ? p.P_in[obj * 36 + idx] : 0.0;
-    }
-    if (l < 6) t.X[g * 6 + l] = valid ? p.x_in[obj * 6 + l] : 0.0;
-    else if (l >= 8 && l < 14) t.T[g * 6 + l - 8] = valid ? p.x_true_in[obj * 6 + l - 8] : 0.0;
-    else if (l == 15) t.St[g] = valid ? p.status[obj] : SSA_ST_PREDICT_NAN;
-}
-
-SSA_DEV void store_object(const Tiles& t, const ssa_step_params& p, int g, int l, int64_t obj, bool valid, int e, int64_t j,
-                          bool write_status)
-{
-    if (!valid) return;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        int idx = l + 16 * r;
-        if (idx < 36) p.P_out[obj * 36 + idx] = t.P[g * 36 + idx];
-    }
-    if (l < 6) p.x_out[obj * 6 + l] = t.X[g * 6 + l];
-    else if (l >= 8 && l < 14) p.x_true_out[obj * 6 + l - 8] = t.T[g * 6 + l - 8];
-    else if (l == 15 && write_status) p.status[obj] = t.St[g];
-    if (l < 12) p.obs[obj * 12 + l] = t.Obs[g * 12 + l];
-    if (l < 4) p.metrics[((int64_t)e * 4 + l) * p.n_obj + j] = t.Met[g * 4 + l];
-}
 
 // Wave-contiguous tile I/O: the 4 objects of a wavefront are consecutive, so P / x / x_true / obs are
 // single contiguous spans (1152 / 192 / 192 / 384 B) moved as 16-byte lanes -- whole cache lines per
@@ -572,23 +542,19 @@ SSA_DEV void aer_obs_row(const double* x, const double* P, const ssa_step_params
 
 #ifdef SSA_TRACE   // diagnostic build only (build_ablate/wave_timeline.py): per-wave phase timestamps, 100 MHz wall clock
 __device__ unsigned long long g_trace[16384 * 16];
-#define SSA_TR(k) do { if (FAST && lane == 0 && tile < 16384) g_trace[tile * 16 + (k)] = wall_clock64(); } while (0)
+#define SSA_TR(k) do { if (lane == 0 && tile < 16384) g_trace[tile * 16 + (k)] = wall_clock64(); } while (0)
 #else
 #define SSA_TR(k) do { } while (0)
 #endif
 
-// One wavefront advances up to 4 objects (one per 16-lane row).
-//   FAST = true : the objects are consecutive (tile I/O); anything beyond the common path -- a
-//                 Cholesky that needs the jitter ladder, a sigma point outside the strong-elliptic
-//                 regime -- is NOT handled here: the object is queued (work list + mark) and its
-//                 status left untouched.  No out-of-line calls -> small register budget.
-//   FAST = false: complete semantics for arbitrary objects (the queue), per-row I/O; the row's
-//                 metrics are folded into `acc` (reward statistics of queued objects).
-// TILE (FAST only): 0 = the tile is loaded here; 1 = it was prefetched (commit now, request the next one after the
+// One wavefront advances up to 4 consecutive objects (one per 16-lane row) by one env step, complete semantics:
+// the robust_cholesky ladder is inline, conic branches beyond the strong-elliptic one are out-of-line calls taken
+// only by the lanes that need them.
+// TILE: 0 = the tile is loaded here; 1 = it was prefetched (commit now, request the next one after the
 // Kepler stage); 2 = the tiles already hold the state (a rollout's later steps)
-template <int PROP, bool FAST, int TILE>
+template <int PROP, int TILE>
 SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& p, int lane, int64_t obj, bool valid,
-                          int64_t base, int cnt, StatAcc& acc, TileRegs& pf, int64_t next_base, int next_cnt, int tile)
+                          int64_t base, int cnt, TileRegs& pf, int64_t next_base, int next_cnt, int tile)
 {
     const int g = lane >> 4, l = lane & 15;
     // env of the object: no division for the single-env case, a 32-bit one otherwise (n_env * n_obj < 2^31)
@@ -599,24 +565,20 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     const int tix = valid ? p.env_time[e] + p.time_offset : 0;
     SSA_TR(0);
 #ifdef SSA_TRACE
-    if (FAST && lane == 0 && tile < 16384) {
+    if (lane == 0 && tile < 16384) {
         unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         g_trace[tile * 16 + 15] = ((unsigned long long)xcc << 32) | hw;
     }
 #endif
 
-    if (FAST) {
-        if (TILE == 0) tile_issue(pf, p, lane, base, cnt);   // one tile per wavefront: plain load, no staging registers kept
-        if (TILE != 2) tile_commit(t, pf, lane);            // TILE 1: requested one tile ago (or by the kernel prologue)
-    }
-    else load_object(t, p, g, l, valid ? obj : 0, valid);
+    if (TILE == 0) tile_issue(pf, p, lane, base, cnt);   // one tile per wavefront: plain load, no staging registers kept
+    if (TILE != 2) tile_commit(t, pf, lane);            // TILE 1: requested one tile ago (or by the kernel prologue)
     wave_lds_sync();
     SSA_TR(1);
 
     const int st_in = t.St[g];
     const bool active = valid && st_in == SSA_ST_OK;
-    bool need_full = false;   // FAST only: row-uniform "this object needs the complete kernel"
 
     // ---- U1/U2: sigma points
 #if defined(SSA_ABLATE) && (SSA_ABLATE & 2)
@@ -654,7 +616,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
             const J2Params jq = {C.j2, C.r_eq, C.rk4_substeps};
             kep_ok = propagate_j2_rk4(s, C.dt, jq, o);
         } else {
-            kep_ok = kepler_step_fast<PROP == 2 ? 1 : PROP, FAST ? 1 : 0>(s, C.dt, o);
+            kep_ok = kepler_step_fast<PROP == 2 ? 1 : PROP, 1>(s, C.dt, o);
         }
 #endif
         if (PROP != 0) {
@@ -671,7 +633,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                 Vec6 si;
 #pragma unroll
                 for (int c = 0; c < 6; ++c) si.v[c] = s[c];
-                Vec6 oo = FAST ? kepler_general_tagged<1>(si, C.dt) : kepler_general_v(si, C.dt);
+                Vec6 oo = kepler_general_tagged<1>(si, C.dt);
 #pragma unroll
                 for (int c = 0; c < 6; ++c) o[c] = oo.v[c];
             }
@@ -680,7 +642,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     wave_lds_sync();   // every lane has consumed t.X / t.T / t.U
     SSA_TR(3);
     // the next tile's inputs: in flight during the transform / covariance / observation / store of this one
-    if (FAST && TILE == 1) tile_issue(pf, p, lane, next_base, next_cnt);
+    if (TILE == 1) tile_issue(pf, p, lane, next_base, next_cnt);
 
     // ---- U3: unscented transform, centred form of x = dot(Wm, sigmas_f):
     //   x = sigma_0' + m',   m' = (sum(Wm) - 1) sigma_0' + Wi sum_{i>=1} (sigma_i' - sigma_0')
@@ -722,7 +684,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     // in the row's (now free) t.D area:  W[0..9) S | W[9..27) Pxz | W[27..36) inv(S) | W[36..54) K
     const bool interval_ok = (C.update_interval <= 1) || (tix % C.update_interval == 0);
     const bool my_update = valid && act >= 0 && (int64_t)act == j && interval_ok;
-    if (my_update && !need_full) {
+    if (my_update) {
         const int tmod = (p.n_time > 0) ? tix % p.n_time : 0;   // row of `trans` / `z_noise` (episodes wrap)
         double* rec = p.upd ? p.upd + (int64_t)e * SSA_UPD_STRIDE : nullptr;
         double* W = &t.D[g * 78];
@@ -884,7 +846,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         }
     }
     // envs whose action selects nobody still get a cleared record (written by object 0's row)
-    if (FAST && valid && p.upd && j == 0 && l == 0 && !(act >= 0 && interval_ok && (int64_t)act < p.n_obj)) {
+    if (valid && p.upd && j == 0 && l == 0 && !(act >= 0 && interval_ok && (int64_t)act < p.n_obj)) {
         double* rec = p.upd + (int64_t)e * SSA_UPD_STRIDE;
         rec[SSA_UPD_OBS_TAKEN] = 0.0;
         rec[SSA_UPD_VISIBLE] = 0.0;
@@ -905,25 +867,12 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         for (int idx = l; idx < 36; idx += 16) t.P[g * 36 + idx] = p.P_in[obj * 36 + idx];
         if (l < 6) t.X[g * 6 + l] = p.x_in[obj * 6 + l];
     }
-    if (FAST) {
-        // queue what the common path could not finish; its status stays as it was and whatever was
-        // computed for it is overwritten by the complete kernel
-        need_full = need_full && active;
-        if (need_full) st_new = st_in;
-        if (l == 0) {
-            if (need_full) {
-                const int pos = atomicAdd(p.work, 1);
-                if ((int64_t)pos < (int64_t)p.n_env * p.n_obj) p.work[4 + pos] = (int32_t)obj;   // capacity = every object once
-            }
-            if (valid && PROP == 0) p.work[4 + p.n_env * p.n_obj + obj] = need_full ? 1 : 0;   // mark: excluded from the slice statistics
-        }
-    }
     if (l == 0) t.St[g] = st_new;
     wave_lds_sync();
     observe_rows(t, g, l);
     wave_lds_sync();
     SSA_TR(7);
-    if (FAST) {
+    {
         store_tile(t, p, lane, base, cnt);
         SSA_TR(8);
         // O3 by sharded atomics: max delta_pos (as ordered bits: non-negative doubles and NaN order like unsigned
@@ -985,17 +934,6 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
             }
         }
         SSA_TR(9);
-    } else {
-        store_object(t, p, g, l, obj, valid, e, j, true);
-        if (valid && l == 0 && p.aer_out) aer_obs_row(&t.X[g * 6], &t.P[g * 36], p, C, e, obj);
-        if (valid && l == 0) {
-            StatAcc a = stat_identity();
-            const double dp = t.Met[g * 4 + 0], sp = t.Met[g * 4 + 2];
-            if (dp != dp) a.mx_nan = 1; else a.mx = dp;
-            a.c4 = dp < 1e4; a.c7 = dp < 1e7; a.nf = st_new != 0;
-            a.sm = sp; a.arg = j; a.sm_nan = (sp != sp);
-            stat_merge(acc, a);
-        }
     }
 }
 
@@ -1045,13 +983,12 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(const Ste
         return;
     }
     const int64_t total = (int64_t)k_arg.p.n_env * k_arg.p.n_obj;
-    StatAcc unused = stat_identity();
     TileRegs pf;
     int tile = blockIdx.x;
     if (!MULTI) {
         const int64_t base = (int64_t)tile * OBJ_PER_WAVE;
         const int cnt = (int)((total - base) < OBJ_PER_WAVE ? (total - base) : OBJ_PER_WAVE);
-        process_wave<PROP, true, 0>(t, k_arg.c, k_arg.p, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, unused, pf, 0, 0, tile);
+        process_wave<PROP, 0>(t, k_arg.c, k_arg.p, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, pf, 0, 0, tile);
         return;
     }
     {
@@ -1079,7 +1016,7 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(const Ste
         const int nt = tile + nwork;
         const int64_t nbase = (int64_t)nt * OBJ_PER_WAVE;
         const int ncnt = nt < ntiles ? (int)((total - nbase) < OBJ_PER_WAVE ? (total - nbase) : OBJ_PER_WAVE) : 0;
-        process_wave<PROP, true, 1>(t, k.c, k.p, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, unused, pf, nbase, ncnt, tile);
+        process_wave<PROP, 1>(t, k.c, k.p, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, pf, nbase, ncnt, tile);
         wave_lds_sync();   // the tile's LDS reads (store) precede the next tile's commit
     }
 }
@@ -1102,7 +1039,6 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) rollout_kernel(const RollK
     const int64_t total = (int64_t)k_arg.p.n_env * k_arg.p.n_obj;
     const int E = k_arg.p.n_env, H = a.r.history, K = a.r.n_steps;
     const int64_t sx = total * 6, sP = total * 36, so_ = total * 12, sm = (int64_t)E * 4 * k_arg.p.n_obj, su = (int64_t)E * SSA_UPD_STRIDE;
-    StatAcc unused = stat_identity();
     TileRegs pf;
     typedef const __attribute__((address_space(4))) RollK* RollArgPtr;
     RollArgPtr kp = (RollArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1155,7 +1091,7 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) rollout_kernel(const RollK
             pk.actions = r.actions + (int64_t)kk * E;
             pk.stat_shards = r.stat_shards + (int64_t)kk * E * SSA_STAT_SHARDS * 4;
             pk.aer_out = nullptr;
-            process_wave<PROP, true, 2>(t, k.c, pk, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, unused, pf, 0, 0, tile);
+            process_wave<PROP, 2>(t, k.c, pk, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, pf, 0, 0, tile);
             wave_lds_sync();
         }
     }
@@ -1171,39 +1107,25 @@ __global__ void __launch_bounds__(64) rollout_fold_kernel(unsigned long long* __
     fold_stat_shards(shards + (int64_t)kk * n_env * SSA_STAT_SHARDS * 4, dst, e, threadIdx.x);
 }
 
-// Post kernel, grid (nparts, n_env) x 256 threads: (1) the queued objects of this env with complete
-// semantics, 4 per wavefront per iteration; (2) this block's slice of the env's reward statistics
-// (queued objects are skipped there -- `mark` -- and folded in by the wavefront that re-did them);
-// (3) one StatAcc per block for reward_final_kernel.
+// Post kernel, grid (nparts, n_env) x 256 threads, launched when a payload or the exact statistics are wanted:
+// (1) the (az, el, range, trace P) observation block O4 of this block's slice (aer_out); (2) the statistics: the
+// fold of the step kernel's shards in the first wavefront, or -- without stat_shards -- this block's slice of the
+// exact reduction (arg-max sigma_pos included), one StatAcc per block for reward_final_kernel.
 constexpr int POST_T = 256, POST_ILP = 4;
 template <int PROP>
 __global__ void __launch_bounds__(POST_T) step_post_kernel(const StepK k, StatAcc* __restrict__ parts, int nparts)
 {
-    __shared__ Tiles tiles[POST_T / 64];
     __shared__ StatAcc part[POST_T / 64];
     const ssa_consts& C = k.c;
     const ssa_step_params& p = k.p;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int e = blockIdx.y;
-    const int64_t m = p.n_obj, N = (int64_t)p.n_env * p.n_obj;
+    const int64_t m = p.n_obj;
     StatAcc acc = stat_identity();
-    TileRegs pf_unused;
-    const int n_listed = (int)((int64_t)p.work[0] < N ? (int64_t)p.work[0] : N);
-    const int waves_total = nparts * (POST_T / 64);
-    for (int it = blockIdx.x * (POST_T / 64) + w; it * OBJ_PER_WAVE < n_listed; it += waves_total) {
-        const int idx = it * OBJ_PER_WAVE + (lane >> 4);
-        int64_t obj = (idx < n_listed) ? (int64_t)p.work[4 + idx] : -1;
-        if (obj >= 0 && obj / m != e) obj = -1;   // another env's block takes it
-        process_wave<PROP, false, 0>(tiles[w], C, p, lane, obj < 0 ? 0 : obj, obj >= 0, 0, 0, acc, pf_unused, 0, 0, 0);
-        wave_lds_sync();
-    }
-    if (p.aer_out) {   // O4 for every object of this block's slice that was not re-done above
-        const int32_t* mark = p.work + 4 + N + (int64_t)e * m;
+    if (p.aer_out) {
         for (int64_t i = (int64_t)blockIdx.x * POST_T + tid; i < m; i += (int64_t)nparts * POST_T) {
-            if (PROP != 0 || mark[i] == 0) {
-                const int64_t obj = (int64_t)e * m + i;
-                aer_obs_row(p.x_out + obj * 6, p.P_out + obj * 36, p, C, e, obj);
-            }
+            const int64_t obj = (int64_t)e * m + i;
+            aer_obs_row(p.x_out + obj * 6, p.P_out + obj * 36, p, C, e, obj);
         }
     }
     if (p.stat_shards) {
@@ -1213,10 +1135,9 @@ __global__ void __launch_bounds__(POST_T) step_post_kernel(const StepK k, StatAc
         const double* dpos = p.metrics + ((int64_t)e * 4 + 0) * m;
         const double* spos = p.metrics + ((int64_t)e * 4 + 2) * m;
         const int32_t* st = p.status + (int64_t)e * m;
-        const int32_t* mark = p.work + 4 + N + (int64_t)e * m;
         for (int64_t b0 = (int64_t)blockIdx.x * POST_T * POST_ILP; b0 < m; b0 += (int64_t)nparts * POST_T * POST_ILP) {
             double dp[POST_ILP], sp[POST_ILP];
-            int sv[POST_ILP], mk[POST_ILP];
+            int sv[POST_ILP];
 #pragma unroll
             for (int q = 0; q < POST_ILP; ++q) {
                 int64_t i = b0 + (int64_t)q * POST_T + tid;
@@ -1224,12 +1145,11 @@ __global__ void __launch_bounds__(POST_T) step_post_kernel(const StepK k, StatAc
                 dp[q] = in ? dpos[i] : 0.0;
                 sp[q] = in ? spos[i] : -2.0;
                 sv[q] = in ? st[i] : 0;
-                mk[q] = in ? (PROP == 0 ? mark[i] : 0) : 1;
             }
 #pragma unroll
             for (int q = 0; q < POST_ILP; ++q) {
                 int64_t i = b0 + (int64_t)q * POST_T + tid;
-                if (i < m && mk[q] == 0) {
+                if (i < m) {
                     if (dp[q] != dp[q]) acc.mx_nan = 1; else acc.mx = fmax(acc.mx, dp[q]);
                     acc.c4 += dp[q] < 1e4;
                     acc.c7 += dp[q] < 1e7;
@@ -1301,11 +1221,9 @@ __global__ void __launch_bounds__(STAT_T) reward_partial_kernel(const double* __
         parts[(int64_t)e * nparts + blockIdx.x] = r;
     }
 }
-__global__ void __launch_bounds__(64) reward_final_kernel(const StatAcc* __restrict__ parts, double* __restrict__ stats, int nparts,
-                                                          int32_t* __restrict__ work_count)
+__global__ void __launch_bounds__(64) reward_final_kernel(const StatAcc* __restrict__ parts, double* __restrict__ stats, int nparts)
 {
     const int e = blockIdx.x, t = threadIdx.x;
-    if (work_count && e == 0 && t == 0) *work_count = 0;   // the step's queue has been consumed
     StatAcc a = stat_identity();
     for (int i = t; i < nparts; i += 64) stat_merge(a, parts[(int64_t)e * nparts + i]);
     a = stat_wave_reduce(a);
@@ -1642,9 +1560,8 @@ static int device_cu_count()
 }
 static int post_parts(int64_t n_obj, int32_t n_env)
 {
-    int64_t want = (n_obj + (int64_t)POST_T * POST_ILP - 1) / ((int64_t)POST_T * POST_ILP);
-    int64_t spread = 256 / (n_env < 1 ? 1 : n_env);   // enough wavefronts to re-do a long queue quickly
-    if (want < spread) want = spread;
+    (void)n_env;
+    int64_t want = (n_obj + POST_T - 1) / POST_T;   // one payload row per thread (the statistics slice strides)
     if (want < 1) want = 1;
     if (want > 256) want = 256;
     return (int)want;
@@ -1654,7 +1571,7 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
 {
     if (!c || !p || p->n_obj <= 0 || p->n_env <= 0) return SSA_E_INVALID;
     if (!p->x_true_in || !p->x_true_out || !p->x_in || !p->x_out || !p->P_in || !p->P_out || !p->status ||
-        !p->obs || !p->metrics || !p->trans || !p->env_time || !p->actions || !p->z_noise || !p->work || !p->stat_ws)
+        !p->obs || !p->metrics || !p->trans || !p->env_time || !p->actions || !p->z_noise || !p->stat_ws)
         return SSA_E_INVALID;
     if (c->obs_type != SSA_OBS_AER && c->obs_type != SSA_OBS_XYZ) return SSA_E_INVALID;
     StepK k;
@@ -1702,10 +1619,9 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
         else hipLaunchKernelGGL(step_post_kernel<2>, dim3(nparts, p->n_env), dim3(POST_T), 0, s, k, parts, nparts);
     }
     if (fast_stats) return launch_status();   // payload + fold were the post kernel's job (2 launches)
-    // folds the per-block statistics (when requested) and resets the queue for the next step
-    if (mask & 4u)
-        hipLaunchKernelGGL(reward_final_kernel, dim3(p->n_env), dim3(64), 0, s, (const StatAcc*)parts, p->stats,
-                           p->stats ? nparts : 0, p->work);
+    // folds the per-block statistics
+    if ((mask & 4u) && p->stats)
+        hipLaunchKernelGGL(reward_final_kernel, dim3(p->n_env), dim3(64), 0, s, (const StatAcc*)parts, p->stats, nparts);
     return launch_status();
 }
 int ssa_env_step_f64(const ssa_consts* c, const ssa_step_params* p, void* stream)
@@ -1738,7 +1654,7 @@ int ssa_env_rollout_f64(const ssa_consts* c, const ssa_step_params* p, const ssa
     if (r->slot_out < 0 || r->slot_out >= r->history) return SSA_E_INVALID;
     if (!r->x_true_ring || !r->x_ring || !r->P_ring || !r->obs_ring || !r->metrics_ring || !r->stats_ring || !r->actions || !r->stat_shards)
         return SSA_E_INVALID;
-    if (!p->status || !p->trans || !p->env_time || !p->z_noise || !p->work) return SSA_E_INVALID;
+    if (!p->status || !p->trans || !p->env_time || !p->z_noise) return SSA_E_INVALID;
     if (c->obs_type != SSA_OBS_AER && c->obs_type != SSA_OBS_XYZ) return SSA_E_INVALID;
     if (c->propagator != SSA_PROP_FG && c->propagator != SSA_PROP_ELEMENTS && c->propagator != SSA_PROP_J2_RK4) return SSA_E_INVALID;
     if (c->propagator == SSA_PROP_J2_RK4 && (c->rk4_substeps < 1 || c->rk4_substeps > 4096)) return SSA_E_INVALID;
@@ -1769,7 +1685,8 @@ int ssa_stats_fold_f64(uint64_t* stat_shards, double* stats, int32_t n_env, void
 }
 int64_t ssa_env_step_work_bytes(int64_t n_obj, int32_t n_env)
 {
-    return (int64_t)(4 + 2 * n_obj * (int64_t)n_env) * (int64_t)sizeof(int32_t);
+    (void)n_obj; (void)n_env;
+    return 16;   // `work` is not used any more (the exception queue is gone); a token size keeps old callers valid
 }
 
 int ssa_reward_stats_f64(const double* metrics, const int32_t* status, double* stats, void* workspace, int64_t n_obj,
@@ -1781,7 +1698,7 @@ int ssa_reward_stats_f64(const double* metrics, const int32_t* status, double* s
     StatAcc* parts = (StatAcc*)workspace;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(reward_partial_kernel, dim3(nparts, n_env), dim3(STAT_T), 0, s, metrics, status, parts, n_obj, nparts);
-    hipLaunchKernelGGL(reward_final_kernel, dim3(n_env), dim3(64), 0, s, (const StatAcc*)parts, stats, nparts, (int32_t*)nullptr);
+    hipLaunchKernelGGL(reward_final_kernel, dim3(n_env), dim3(64), 0, s, (const StatAcc*)parts, stats, nparts);
     return launch_status();
 }
 int64_t ssa_reward_stats_workspace_bytes(int32_t n_env)
