@@ -1070,9 +1070,7 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) rollout_kernel(const RollK
                 default: __builtin_amdgcn_s_setprio(3); break;
             }
 #endif
-#ifndef SSA_ROLL_HOIST
             asm volatile("" : "+s"(kp));      // per step, as per tile in step_fast_kernel: nothing carried around the loop
-#endif
             asm volatile("" : "+v"(lane));
             const StepK& k = ((const RollK*)kp)->k;
             const ssa_rollout_params& r = ((const RollK*)kp)->r;
