@@ -303,6 +303,9 @@ def main():
                        "propagator": args.propagator, "parallelism": "object-shard x%d" % world,
                        "allgather": (("comm-stream (overlapped with the next step)" if state["overlap"] else "in-stream")
                                      if use_dist else None),
+                       "allgather_api": (("RCCL ncclAllGather enqueued directly in the compute/communication stream"
+                                          if sharded._rccl is not None else "torch.distributed.all_gather_into_tensor")
+                                         if sharded is not None else None),
                        "allgather_warmup_probe": allgather_probe},
             "object_steps_per_sec": round(steps_per_s * m * world, 1),
             "failed_filters": n_failed,

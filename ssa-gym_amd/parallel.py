@@ -59,8 +59,9 @@ class ShardedStepper:
     xGMI while the compute stream already runs the kernels of step k+1; the compute stream only waits
     (on an event, not on the host) before it overwrites a payload buffer two steps later."""
 
-    def __init__(self, plan, local, group=None):
+    def __init__(self, plan, local, group=None, direct_rccl=True):
         self.plan, self.local, self.group = plan, local, group
+        self._rccl = None
         dev = local.device
         self.width = 4 * plan.m_pad + STAT_STRIDE
         self.send = [torch.zeros(self.width, dtype=torch.float64, device=dev) for _ in range(2)]
@@ -72,6 +73,22 @@ class ShardedStepper:
             self._ready = [torch.cuda.Event(), torch.cuda.Event()]
             self._done = [torch.cuda.Event(), torch.cuda.Event()]
             self._pending = [False, False]
+            # the all-gather enqueued by RCCL itself in our stream (no ProcessGroup stream hops, rccl.py); the
+            # torch.distributed collective remains the fallback
+            if direct_rccl and dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl":
+                try:
+                    from . import rccl
+                    self._rccl = rccl.Communicator(torch.device(dev), group)
+                except Exception as exc:  # noqa: BLE001
+                    import warnings
+                    warnings.warn("direct RCCL communicator unavailable (%s); using torch.distributed.all_gather_into_tensor" % exc)
+                    self._rccl = None
+
+    def _all_gather(self, recv, send, stream):
+        if self._rccl is not None:
+            self._rccl.all_gather_f64(send.data_ptr(), recv.data_ptr(), self.width, stream.cuda_stream)
+        else:
+            dist.all_gather_into_tensor(recv, send, group=self.group)
 
     def step(self, global_action, overlap=False):
         p = self.plan
@@ -90,9 +107,11 @@ class ShardedStepper:
             self._ready[b].record(torch.cuda.current_stream())
             self.comm.wait_event(self._ready[b])
             with torch.cuda.stream(self.comm):
-                dist.all_gather_into_tensor(recv, send, group=self.group)
+                self._all_gather(recv, send, self.comm)
                 self._done[b].record(self.comm)
             self._pending[b] = True
+        elif self._gpu:
+            self._all_gather(recv, send, torch.cuda.current_stream())
         else:
             dist.all_gather_into_tensor(recv, send, group=self.group)
         self.k += 1

@@ -1,0 +1,68 @@
+"""RCCL called directly (ctypes) for the ONE data-path collective of the sharded step.
+
+torch.distributed stays the launcher / rendezvous layer (`backend="nccl"` is RCCL), but its ProcessGroup runs
+every collective on an internal stream and hops to and from the caller's stream with events -- two cross-stream
+waits per step, which is most of what the per-step all-gather costs on xGMI-sized messages.  A communicator
+created here from the same ranks enqueues `ncclAllGather` straight into the stream the step kernels run in
+(or into the caller's communication stream), with no hop.  The unique id travels through the existing
+torch.distributed group; there is no second rendezvous."""
+import ctypes as C
+import os
+
+import torch
+import torch.distributed as dist
+
+NCCL_UNIQUE_ID_BYTES = 128
+ncclFloat64 = 8
+
+
+class _UniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * NCCL_UNIQUE_ID_BYTES)]
+
+
+def _load():
+    cands = [os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "/opt/rocm/lib/librccl.so", "librccl.so"]
+    last = None
+    for c in cands:   # torch's own copy first: the process then holds ONE RCCL
+        try:
+            return C.CDLL(c)
+        except OSError as e:
+            last = e
+    raise OSError("librccl.so not found (%s)" % last)
+
+
+class Communicator:
+    """one RCCL communicator over the ranks of a torch.distributed group (default: WORLD)."""
+
+    def __init__(self, device, group=None):
+        self.lib = _load()
+        L = self.lib
+        L.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
+        L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
+        L.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        L.ncclCommDestroy.argtypes = [C.c_void_p]
+        L.ncclGetErrorString.argtypes = [C.c_int]
+        L.ncclGetErrorString.restype = C.c_char_p
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        uid = _UniqueId()
+        if self.rank == 0:
+            self._check(L.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        raw = bytes((C.c_ubyte * NCCL_UNIQUE_ID_BYTES).from_buffer_copy(uid))   # (raw memory: the id may contain NULs)
+        buf = torch.tensor(list(raw), dtype=torch.uint8, device=torch.device("cuda", torch.cuda.current_device()))
+        dist.broadcast(buf, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        C.memmove(C.byref(uid), bytes(buf.cpu().tolist()), NCCL_UNIQUE_ID_BYTES)
+        self.comm = C.c_void_p()   # (created on the process's current device, as set by the launcher)
+        self._check(L.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed: %s" % (what, self.lib.ncclGetErrorString(rc).decode()))
+
+    def all_gather_f64(self, send_ptr, recv_ptr, count, stream):
+        """recv[r*count:(r+1)*count] = rank r's send[0:count] (doubles), enqueued in `stream` (a hipStream_t handle)."""
+        self._check(self.lib.ncclAllGather(send_ptr, recv_ptr, count, ncclFloat64, self.comm, stream), "ncclAllGather")
+
+    def close(self):
+        if self.comm:
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = C.c_void_p()

@@ -582,3 +582,42 @@ def test_rollout_equals_single_steps(hip, E, m, K, H, propagator, obs_type, resa
         for sidx in (L.STAT_MAX_DPOS, L.STAT_CNT_LT_1E4, L.STAT_CNT_LT_1E7, L.STAT_N_FAILED):
             assert np.array_equal(a[7][so, :, sidx], b[7][so, :, sidx], equal_nan=True), (k, sidx)
     assert a[7][K % H, 0, L.STAT_N_FAILED] >= 1 and np.any(a[5][..., L.UPD_OBS_TAKEN] == 1.0)
+
+
+def test_direct_rccl_all_gather_equals_torch_distributed(hip):
+    """parallel.ShardedStepper enqueues RCCL's ncclAllGather itself (rccl.py) instead of going through the
+    ProcessGroup's internal stream; on a 1-rank group both routes must deliver the same payload (observation
+    block + statistics) for the same steps.  (More ranks: tests/test_parallel_gloo.py covers the host logic.)"""
+    import torch.distributed as dist
+    torch = hip.torch
+    from ssa_gym_amd import parallel
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29537", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+    try:
+        m = 1003
+        xt, x, P, g = make_batch(m, seed=5)
+        consts = hip.host.make_consts(g["Q"], g["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, g["obs_lla"])
+        n_time = c2t().shape[0]
+        got = []
+        for direct in (True, False):
+            zn = torch.zeros((n_time, m, 3), dtype=torch.float64, device="cuda")
+            eng = hip.engine.HotPathEngine(consts, m, 1, c2t(), zn, history=2, zn_stride_env=0)
+            eng.load_state(0, xt, x, P)
+            local = parallel.HipLocalStepper(eng, consts, fast_stats=True)
+            sh = parallel.ShardedStepper(parallel.ShardPlan(m, 1, 0), local, direct_rccl=direct)
+            assert (sh._rccl is not None) == direct
+            for k in range(3):
+                sh.step(7 * k + 1, overlap=(k == 2))
+            sh.wait()
+            torch.cuda.synchronize()
+            got.append((sh.global_obs().cpu().numpy(), sh.global_stats(), sh.recv[0].cpu().numpy(), sh.recv[1].cpu().numpy()))
+            if sh._rccl is not None:
+                sh._rccl.close()
+        for a, b in zip(got[0], got[1]):
+            assert np.array_equal(a, b, equal_nan=True)
+        assert np.abs(got[0][0]).max() > 0
+    finally:
+        if created:
+            dist.destroy_process_group()
