@@ -317,6 +317,8 @@ def main():
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
+        if sharded is not None:
+            sharded.close()
         dist.destroy_process_group()
 
 

@@ -116,6 +116,13 @@ class ShardedStepper:
             dist.all_gather_into_tensor(recv, send, group=self.group)
         self.k += 1
 
+    def close(self):
+        """release the direct RCCL communicator (after the last collective has completed)."""
+        if self._rccl is not None:
+            torch.cuda.synchronize()
+            self._rccl.close()
+            self._rccl = None
+
     def wait(self):
         """make the current stream wait for every all-gather issued so far."""
         if self._gpu:
