@@ -335,23 +335,37 @@ SSA_DEV void tile_commit(Tiles& t, const TileRegs& r, int lane)
     else if (lane >= 48 && lane < 60) reinterpret_cast<double2*>(t.T)[lane - 48] = r.aux;
     else if (lane >= 60) t.St[lane - 60] = __double2loint(r.aux.x);
 }
+typedef double v2d __attribute__((ext_vector_type(2)));
+// one 16-byte lane of a tile store.  NT (non-temporal): for launches of up to 20 480 objects and for rollouts the
+// outputs are marked streaming, which leaves less dirty data for the end-of-kernel L2 write-back (-0.55 us per launch
+// at 20 000 objects).  Not for the multi-tile step kernel: at 160 000 objects the next step re-reads 61 MB of these
+// outputs from the Infinity Cache, and streaming them past it cost 19 %.
+template <bool NT>
+SSA_DEV void store16(double* dst, const double* src)
+{
+#ifdef SSA_PLAIN_STORES   // diagnostic: never stream
+    *reinterpret_cast<v2d*>(dst) = *reinterpret_cast<const v2d*>(src);
+#else
+    if (NT) __builtin_nontemporal_store(*reinterpret_cast<const v2d*>(src), reinterpret_cast<v2d*>(dst));
+    else *reinterpret_cast<v2d*>(dst) = *reinterpret_cast<const v2d*>(src);
+#endif
+}
+template <bool NT>
 SSA_DEV void store_tile(const Tiles& t, const ssa_step_params& p, int lane, int64_t base, int cnt)
 {
-    double2* P2 = reinterpret_cast<double2*>(p.P_out + base * 36);
-    const double2* tP = reinterpret_cast<const double2*>(t.P);
     for (int i = lane; i < 72; i += 64)
-        if (i < cnt * 18) P2[i] = tP[i];
+        if (i < cnt * 18) store16<NT>(p.P_out + base * 36 + 2 * i, t.P + 2 * i);
     if (lane < 12) {
-        if (lane < cnt * 3) reinterpret_cast<double2*>(p.x_out + base * 6)[lane] = reinterpret_cast<const double2*>(t.X)[lane];
+        if (lane < cnt * 3) store16<NT>(p.x_out + base * 6 + 2 * lane, t.X + 2 * lane);
     } else if (lane >= 16 && lane < 28) {
         const int i = lane - 16;
-        if (i < cnt * 3) reinterpret_cast<double2*>(p.x_true_out + base * 6)[i] = reinterpret_cast<const double2*>(t.T)[i];
+        if (i < cnt * 3) store16<NT>(p.x_true_out + base * 6 + 2 * i, t.T + 2 * i);
     } else if (lane >= 32 && lane < 36) {
         const int i = lane - 32;
         if (i < cnt) p.status[base + i] = t.St[i];
     } else if (lane >= 40 && lane < 64) {
         const int i = lane - 40;
-        if (i < cnt * 6) reinterpret_cast<double2*>(p.obs + base * 12)[i] = reinterpret_cast<const double2*>(t.Obs)[i];
+        if (i < cnt * 6) store16<NT>(p.obs + base * 12 + 2 * i, t.Obs + 2 * i);
     }
     if (lane < 16) {   // metrics [E][4][m]: four 32-byte runs per tile
         const int kk = lane >> 2, jj = lane & 3;
@@ -873,7 +887,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     wave_lds_sync();
     SSA_TR(7);
     {
-        store_tile(t, p, lane, base, cnt);
+        store_tile<TILE != 1>(t, p, lane, base, cnt);
         SSA_TR(8);
         // O3 by sharded atomics: max delta_pos (as ordered bits: non-negative doubles and NaN order like unsigned
         // integers, so NaN wins exactly as in np.max), trinary counts (packed in one word), failures
