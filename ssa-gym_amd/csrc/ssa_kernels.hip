@@ -306,22 +306,24 @@ struct alignas(16) Tiles {   // LDS working set of one wavefront (4 objects)
 //                `aux` by lane: 0-7 the tail of P | 32-43 x_filter | 48-59 x_true | 60-63 status (bits)
 //   tile_commit: registers -> LDS tiles (rows beyond `cnt` are zero / marked failed)
 struct TileRegs { double2 main, aux; };
+// one 16-byte lane of a tile load (plain: marking the inputs streaming was measured slower, 45.4 k vs 46.5 k)
+SSA_DEV double2 load16(const double* src) { return *reinterpret_cast<const double2*>(src); }
 SSA_DEV void tile_issue(TileRegs& r, const ssa_step_params& p, int lane, int64_t base, int cnt)
 {
     const double2 zero = make_double2(0.0, 0.0);
     r.main = zero;
     r.aux = zero;
     if (cnt <= 0) return;
-    const double2* P2 = reinterpret_cast<const double2*>(p.P_in + base * 36);
-    if (lane < cnt * 18) r.main = P2[lane];
+    const double* Pin = p.P_in + base * 36;
+    if (lane < cnt * 18) r.main = load16(Pin + 2 * lane);
     if (lane < 8) {
-        if (64 + lane < cnt * 18) r.aux = P2[64 + lane];
+        if (64 + lane < cnt * 18) r.aux = load16(Pin + 2 * (64 + lane));
     } else if (lane >= 32 && lane < 44) {
         const int i = lane - 32;
-        if (i < cnt * 3) r.aux = reinterpret_cast<const double2*>(p.x_in + base * 6)[i];
+        if (i < cnt * 3) r.aux = load16(p.x_in + base * 6 + 2 * i);
     } else if (lane >= 48 && lane < 60) {
         const int i = lane - 48;
-        if (i < cnt * 3) r.aux = reinterpret_cast<const double2*>(p.x_true_in + base * 6)[i];
+        if (i < cnt * 3) r.aux = load16(p.x_true_in + base * 6 + 2 * i);
     } else if (lane >= 60) {
         const int i = lane - 60;
         r.aux.x = __hiloint2double(0, (i < cnt) ? p.status[base + i] : SSA_ST_PREDICT_NAN);
