@@ -117,3 +117,36 @@ def test_host_constants_match_oracle_and_reference(pkg):
     # enu matrix is orthonormal and maps the local vertical to +w
     T = np.array(c.enu).reshape(3, 3)
     np.testing.assert_allclose(T.T @ T, np.eye(3), atol=1e-15)
+
+
+def test_bench_cpu_share_respects_cgroup_quota(tmp_path, monkeypatch):
+    """bench.host_cpu_share(): the all-cores CPU baseline must size its thread pool by the container's CPU quota, not
+    by the CPUs it can see (256 visible / 16 granted on the GPU boxes)."""
+    import builtins
+    import importlib.util
+    import os
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    real_open = builtins.open
+
+    def fake(content):
+        def _open(path, *a, **k):
+            if path == "/sys/fs/cgroup/cpu.max":
+                f = tmp_path / "cpu.max"
+                f.write_text(content)
+                return real_open(f, *a, **k)
+            return real_open(path, *a, **k)
+        return _open
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)))
+    monkeypatch.setattr(builtins, "open", fake("1600000 100000\n"))
+    assert bench.host_cpu_share() == 16
+    monkeypatch.setattr(builtins, "open", fake("max 100000\n"))
+    assert bench.host_cpu_share() == 256
+    monkeypatch.setattr(builtins, "open", fake("50000 100000\n"))
+    assert bench.host_cpu_share() == 1

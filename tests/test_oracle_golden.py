@@ -299,3 +299,32 @@ def test_episode_vs_composite_golden(oracle, name):
     assert np.median(ratios) < 1.0   # within one filter sigma of each other
     assert np.mean(np.abs(rewards - ep["rewards"])) < 2e-2
     assert np.max(np.abs(rewards - ep["rewards"])) <= 2.0 / m + 1e-12
+
+
+def test_openmp_oracle_build_equals_serial_build():
+    """bench.py's all-host-cores CPU baseline is the SAME restatement with its per-object loops spread over threads
+    (libssa_oracle_omp.so): its results must equal the serial build's bit for bit, update and failures included."""
+    import oracle as orc
+    g = golden("ukf_step_golden.npz")
+    cat = golden("catalogue_subset.npy")
+    rs = np.random.RandomState(4)
+    m = 257
+    xt = cat[rs.randint(0, len(cat), m)]
+    x = xt + rs.normal(size=(m, 6)) * np.array([1e5] * 3 + [1e2] * 3)
+    x[11, 0] = np.nan
+    P = np.tile(g["P0"], (m, 1, 1))
+    Wm, Wc, scale = orc.merwe_weights(1e-4, 2.0, -3)
+    M = golden("c2t_2020-05-04_dt20_n480.npy")[3].reshape(3, 3)
+    outs = []
+    for omp in (False, True):
+        o = orc.Oracle(omp=omp)
+        if omp:
+            assert o.lib.orc_omp_threads(4) == 4
+        st = np.zeros(m, dtype=np.int32)
+        r = o.env_step(xt, x, P, st, 20.0, g["Q"], g["R"], Wm, Wc, scale, 5, M, g["obs_lla"], g["obs_itrs"], -np.pi / 2,
+                       np.array([1e-6, -2e-6, 30.0]))
+        outs.append((r, st))
+    (a, sa), (b, sb) = outs
+    assert np.array_equal(sa, sb) and sa[11] != 0
+    for k in ("x_true", "x", "P", "obs", "metrics"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
