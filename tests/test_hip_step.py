@@ -621,3 +621,28 @@ def test_direct_rccl_all_gather_equals_torch_distributed(hip):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_full_size_20000_parity_with_update(hip, oracle, oracle_ld):
+    """BASELINE config 3 size against the oracle itself (not only properties): 20 000 objects, alpha = 1e-4,
+    the selected object updated, fp64 oracle and 80-bit witness on the same inputs (a few seconds of CPU).
+    Tolerances: north_star (1e-6 means, 1e-5 covariances), criterion of check_parity."""
+    m = 20000
+    xt, x, P, g = make_batch(m, seed=2024)
+    a = 12345
+    gpu = run_gpu(hip, xt, x, P, g, [a], 2, 1e-4)
+    zn = gpu["z_noise"][0, 2, a]
+    f64 = run_oracle(oracle, xt, x, P, g, a, 2, 1e-4, z_noise3=zn)
+    ld = run_oracle(oracle_ld, xt, x, P, g, a, 2, 1e-4, centred=True, z_noise3=zn)
+    assert np.all(gpu["status"] == 0) and np.all(f64["status"] == 0)
+    assert_states_close(gpu["x_true"], f64["x_true"], 1e-9, "truth")
+    others = np.arange(m) != a
+    sub = lambda d: {k: d[k][others] for k in ("x", "P")}       # the updated object is judged separately (finding 3 of DESIGN section 4)
+    check_parity(sub(gpu), sub(f64), sub(ld), exact_bound=True)
+    assert gpu["upd"][0, hip.lib.UPD_OBS_TAKEN] == 1.0
+    # the update: posterior mean within the reference arithmetic's own distance from the witness (x3), trace P collapsed
+    ep = np.linalg.norm(gpu["x"][a, :3] - ld["x"][a, :3]) / np.linalg.norm(ld["x"][a, :3])
+    rp = np.linalg.norm(f64["x"][a, :3] - ld["x"][a, :3]) / np.linalg.norm(ld["x"][a, :3])
+    assert ep <= 3 * rp + 1e-9, (ep, rp)
+    assert np.trace(gpu["P"][a]) < 1e-3 * np.trace(P[a])
+    assert gpu["stats"][0, hip.lib.STAT_N_FAILED] == 0
