@@ -232,9 +232,13 @@ class SSA_Tasker_Env(Env):
         m, n = self.m, self.n
         x_true0 = np.empty((m, 6))
         N = self.orbits.shape[0]
-        for j in range(m):   # draw order of :206-209: (row, 6 normals) per object ...
-            x_true0[j] = self.orbits[self.np_random.randint(low=0, high=N), :]
-            self.x_noise[j] = self.np_random.normal(size=6) * self.x_sigma
+        if self._device_rng:   # bulk draws (this mode is not seed-compatible with the reference anyway): 1 ms instead of 40 at m = 20 000
+            x_true0[:] = self.orbits[self.np_random.randint(low=0, high=N, size=m)]
+            self.x_noise[:] = self.np_random.normal(size=(m, 6)) * self.x_sigma
+        else:
+            for j in range(m):   # draw order of :206-209: (row, 6 normals) per object ...
+                x_true0[j] = self.orbits[self.np_random.randint(low=0, high=N), :]
+                self.x_noise[j] = self.np_random.normal(size=6) * self.x_sigma
         x_filter0 = x_true0 + self.x_noise
         # ... then n*m*3 normals (:219-221); RandomState.normal keeps its Box-Muller cache across
         # calls, so one bulk draw consumes the stream exactly like the reference's n*m size-3 draws
