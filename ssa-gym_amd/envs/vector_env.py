@@ -21,6 +21,7 @@ class SSA_Tasker_VecEnv:
         import torch
         from .. import engine
         self.E, self.m, self.n, self.dt = int(num_envs), config['rso_count'], config['steps'], config['time_step']
+        self._bulk_draws = bool(config.get('device_rng', False))
         self.obs_returned, self.reward_type = config['obs_returned'], config['reward_type']
         self.orbits = config['orbits']
         self.x_sigma = np.array(config['x_sigma'])
@@ -62,6 +63,9 @@ class SSA_Tasker_VecEnv:
     # ------------------------------------------------------------------
     def _draw(self, e):
         rs, N = self._rng[e], self.orbits.shape[0]
+        if self._bulk_draws:      # config['device_rng']: bulk draws, 1 ms instead of 40 per env at m = 20 000 (auto-reset cost)
+            xt = self.orbits[rs.randint(low=0, high=N, size=self.m)]
+            return xt, xt + rs.normal(size=(self.m, 6)) * self.x_sigma
         xt = np.empty((self.m, 6))
         noise = np.empty((self.m, 6))
         for j in range(self.m):   # reset() draw order of the reference (:206-209)
