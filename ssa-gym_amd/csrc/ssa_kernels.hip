@@ -705,7 +705,9 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         double* rec = p.upd ? p.upd + (int64_t)e * SSA_UPD_STRIDE : nullptr;
         double* W = &t.D[g * 78];
         bool taken = false, visible = false;
-        if (st_new == SSA_ST_OK) {
+        // a filter that has failed (earlier, or in this step's predict) is skipped entirely (:293): no z_true, no record
+        const bool attempted = (st_new == SSA_ST_OK);
+        if (attempted) {
             const double* M = p.trans + (int64_t)tmod * 9;
             // sigma points handed to update(): the propagated ones or, with
             // SSA_FLAG_RESAMPLE, a fresh set drawn from the prior (x, P now in t.X / t.P)
@@ -858,7 +860,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         if (rec && l == 0) {
             rec[SSA_UPD_OBS_TAKEN] = taken ? 1.0 : 0.0;
             rec[SSA_UPD_VISIBLE] = visible ? 1.0 : 0.0;
-            rec[SSA_UPD_ACTION] = (double)act;
+            rec[SSA_UPD_ACTION] = attempted ? (double)act : -1.0;
         }
     }
     // envs whose action selects nobody still get a cleared record (written by object 0's row)

@@ -13,7 +13,8 @@ from datetime import timedelta
 import numpy as np
 
 from .. import _lib, host
-from . import dynamics, transformations
+from . import transformations
+from ._config import resolve_kernel_variant
 from ._gymshim import Env, np_random, spaces
 from .results import error_failed
 
@@ -134,18 +135,7 @@ class SSA_Tasker_Env(Env):
         self.mean_z, self.residual_z, self.msqrt = config['mean_z'], config['residual_z'], config['msqrt']
         self.alpha, self.beta, self.kappa = config['alpha'], config['beta'], config['kappa']
         # operator plug points -> fused kernel variant (no CPU fallback for foreign callables)
-        fx_id = dynamics.kernel_id_of(self.fx, "fx")
-        hx_id = dynamics.kernel_id_of(self.hx, "hx")
-        mz_id = dynamics.kernel_id_of(self.mean_z, "mean_z")
-        rz_id = dynamics.kernel_id_of(self.residual_z, "residual_z")
-        dynamics.kernel_id_of(self.msqrt, "msqrt")
-        model = {(("hx", "aer"), ("mean_z", "uvw"), ("residual_z", "aer")): 'aer',
-                 (("hx", "xyz"), ("mean_z", "xyz"), ("residual_z", "xyz")): 'xyz'}.get((hx_id, mz_id, rz_id))
-        if model is None:
-            raise NotImplementedError("hx/mean_z/residual_z combination %s has no fused kernel" % ((hx_id, mz_id, rz_id),))
-        self._model = model
-        propagator = config.get('propagator', getattr(self.fx, 'propagator', 'fg'))
-        assert fx_id == ("fx", "farnocchia")
+        self._model, propagator = resolve_kernel_variant(config)
         # ---- arrays (:120-161)
         if config['P_0'] is None:
             self.P_0 = np.copy(np.diag(self.x_sigma ** 2))
@@ -414,6 +404,8 @@ class SSA_Tasker_Env(Env):
                 self.actions[i] = a
                 self._book_update(i, a, upd[k])
                 self._stats = stats[k]
+                if int(stats[k][_lib.STAT_N_FAILED]) != self._n_failed:
+                    self._record_failures(at_step=i)
                 done = self._reward_done(i, a, stats[k], -1) or (i + 1 >= self.n)
                 r = self.rewards[i]
                 rewards.append(r if (self.obs_returned == 'flatten' or np.isfinite(r)) else np.float64(0.5))
@@ -422,8 +414,6 @@ class SSA_Tasker_Env(Env):
                     break
             pos += kk
         self._argmax_sigma = -1
-        if int(self._stats[_lib.STAT_N_FAILED]) != self._n_failed:
-            self._record_failures()
         slot = self.i % e.H
         if self.obs_returned == 'aer':
             from .. import device
@@ -438,9 +428,14 @@ class SSA_Tasker_Env(Env):
         return obs, np.asarray(rewards), np.asarray(dones, dtype=bool), {}
 
     # ------------------------------------------------------------------ failures (:369-382)
-    def _record_failures(self):
+    def _record_failures(self, at_step=None):
+        """filter_error() bookkeeping (:369-382) for the filters that failed in step self.i.  Inside a rollout launch
+        (at_step given) the device status already reflects LATER steps of the launch as well: only the objects whose
+        state carries the failure sentinel in history slot `at_step` have failed by then."""
         s = time.time()
         status = self._engine.status.cpu().numpy()
+        if at_step is not None:
+            status = np.where(self.x_filter[at_step][:, 0] == host.X_FAILED[0], status, 0)
         kinds = {_lib.ST_PREDICT_NAN: ('predict', ', predict returned nan. '),
                  _lib.ST_PREDICT_LINALG: ('predict', ', LinAlgError. '),
                  _lib.ST_UPDATE_NAN: ('update', ', update returned nan. '),

@@ -12,7 +12,8 @@ consumes noise in a step (ssa_tasker_simple_2.py:301).
 import numpy as np
 
 from .. import _lib, host
-from . import dynamics, transformations
+from . import transformations
+from ._config import resolve_kernel_variant
 from ._gymshim import np_random, spaces
 
 
@@ -31,13 +32,11 @@ class SSA_Tasker_VecEnv:
         self.P_0 = np.diag(self.x_sigma ** 2) if config['P_0'] is None else np.copy(config['P_0'])
         R = np.diag(self.z_sigma ** 2) if config['R'] is None else np.copy(config['R'])
         Q = host.Q_discrete_white_noise(dim=2, dt=self.dt, var=config['q_sigma'] ** 2, block_size=3, order_by_dim=False)
-        ids = [dynamics.kernel_id_of(config[k], r) for k, r in (('hx', 'hx'), ('mean_z', 'mean_z'), ('residual_z', 'residual_z'))]
-        dynamics.kernel_id_of(config['fx'], 'fx'), dynamics.kernel_id_of(config['msqrt'], 'msqrt')
-        model = 'aer' if ids[0] == ('hx', 'aer') else 'xyz'
+        model, propagator = resolve_kernel_variant(config)   # same acceptance rules as SSA_Tasker_Env
         obs_lla = np.array(config['observer']) * [host.deg2rad, host.deg2rad, 1]
         self._consts = host.make_consts(Q, R, config['alpha'], config['beta'], config['kappa'], self.dt,
                                         np.radians(config['obs_limit']), obs_lla, obs_type=model,
-                                        propagator=config.get('propagator', 'fg'),
+                                        propagator=propagator,
                                         resample=bool(config.get('resample_sigmas', False)),
                                         update_interval=config['update_interval'])
         trans = (np.asarray(config['trans_matrix']) if config.get('trans_matrix') is not None

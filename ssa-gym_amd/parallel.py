@@ -51,6 +51,30 @@ class ShardPlan:
         return j if r == self.rank else -1
 
 
+def _direct_communicator(dev, group):
+    """rccl.Communicator for `group`, or None -- decided COLLECTIVELY: the ranks agree (all-reduce MIN of a success
+    flag over the process group) before any of them uses it, so that a rank on which librccl cannot be loaded or
+    ncclCommInitRank fails never leaves the others issuing ncclAllGather on a private communicator while it calls
+    all_gather_into_tensor on the process group (mismatched collectives hang).  Every rank takes part in the unique-id
+    broadcast inside rccl.Communicator whether or not its own library load succeeded."""
+    import warnings
+    from . import rccl
+    comm, err = None, None
+    try:
+        comm = rccl.Communicator(dev, group)
+    except Exception as exc:  # noqa: BLE001
+        err = exc
+    ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) == 1:
+        return comm
+    if comm is not None:
+        comm.close()
+    warnings.warn("direct RCCL communicator unavailable on at least one rank (%s); every rank uses "
+                  "torch.distributed.all_gather_into_tensor" % (err if err is not None else "another rank failed"))
+    return None
+
+
 class ShardedStepper:
     """one env of m_total objects, one rank per shard.
 
@@ -76,13 +100,7 @@ class ShardedStepper:
             # the all-gather enqueued by RCCL itself in our stream (no ProcessGroup stream hops, rccl.py); the
             # torch.distributed collective remains the fallback
             if direct_rccl and dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl":
-                try:
-                    from . import rccl
-                    self._rccl = rccl.Communicator(torch.device(dev), group)
-                except Exception as exc:  # noqa: BLE001
-                    import warnings
-                    warnings.warn("direct RCCL communicator unavailable (%s); using torch.distributed.all_gather_into_tensor" % exc)
-                    self._rccl = None
+                self._rccl = _direct_communicator(torch.device(dev), group)
 
     def _all_gather(self, recv, send, stream):
         if self._rccl is not None:

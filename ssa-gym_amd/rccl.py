@@ -35,24 +35,45 @@ class Communicator:
     """one RCCL communicator over the ranks of a torch.distributed group (default: WORLD)."""
 
     def __init__(self, device, group=None):
-        self.lib = _load()
-        L = self.lib
-        L.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
-        L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
-        L.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
-        L.ncclCommDestroy.argtypes = [C.c_void_p]
-        L.ncclGetErrorString.argtypes = [C.c_int]
-        L.ncclGetErrorString.restype = C.c_char_p
+        self.comm = C.c_void_p()
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        err = None
+        try:
+            self.lib = _load()
+            L = self.lib
+            L.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
+            L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
+            L.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+            L.ncclCommDestroy.argtypes = [C.c_void_p]
+            L.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+            L.ncclGetErrorString.argtypes = [C.c_int]
+            L.ncclGetErrorString.restype = C.c_char_p
+        except (OSError, AttributeError) as exc:
+            self.lib, err = None, exc
         uid = _UniqueId()
-        if self.rank == 0:
-            self._check(L.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        if self.rank == 0 and err is None:
+            rc = self.lib.ncclGetUniqueId(C.byref(uid))
+            if rc != 0:
+                err = RuntimeError("ncclGetUniqueId failed: %s" % self.lib.ncclGetErrorString(rc).decode())
+        # every rank takes part in the broadcast and in the agreement below, whether or not its own load succeeded:
+        # a one-sided failure must not leave the other ranks blocked in a collective
+        dev = torch.device("cuda", torch.cuda.current_device())
         raw = bytes((C.c_ubyte * NCCL_UNIQUE_ID_BYTES).from_buffer_copy(uid))   # (raw memory: the id may contain NULs)
-        buf = torch.tensor(list(raw), dtype=torch.uint8, device=torch.device("cuda", torch.cuda.current_device()))
+        buf = torch.tensor(list(raw), dtype=torch.uint8, device=dev)
         dist.broadcast(buf, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) != 1:
+            raise RuntimeError("direct RCCL communicator: library load / unique id failed on at least one rank (%s)" % (err,))
         C.memmove(C.byref(uid), bytes(buf.cpu().tolist()), NCCL_UNIQUE_ID_BYTES)
-        self.comm = C.c_void_p()   # (created on the process's current device, as set by the launcher)
-        self._check(L.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
+        # (created on the process's current device, as set by the launcher)
+        self._check(self.lib.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
+
+    def count(self):
+        """number of ranks of the communicator as RCCL itself reports it (ncclCommCount)"""
+        n = C.c_int(0)
+        self._check(self.lib.ncclCommCount(self.comm, C.byref(n)), "ncclCommCount")
+        return int(n.value)
 
     def _check(self, rc, what):
         if rc != 0:
