@@ -32,6 +32,8 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_OBJECT_STEP = 896   # r+w x_true 48, x 48, P 288 each way; obs 96; metrics 32
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_FLOP_PER_OBJECT_STEP = 9400  # profiles/*fp64_counters.json: (ADD + MUL + 2 FMA + TRANS) x 64 lanes / 4 objects per wavefront
+FP64_PEAK_TFLOPS = 78.6           # MI355X datasheet fp64 vector peak (an FMA micro-benchmark reaches 63.2 on these boxes)
 
 
 def build_problem(m, seed, n_time=480):
@@ -102,6 +104,130 @@ def cpu_baseline(m, budget_s=15.0, all_cores=False):
                       % (steps, m, cores, " -fopenmp" if all_cores else "", el)}
 
 
+def local_variant_rate(m, K, W, propagator, resample=False, seed=100):
+    """the N=1 measurement of `value` for another kernel variant on the same workload: K timed per-step launches (one
+    launch per step, deferred statistics fold, episodes of 480 steps with device-side resets) after W warm-up steps"""
+    import torch
+    from ssa_gym_amd import engine, host, parallel
+    pb = build_problem(m, seed=seed)
+    consts = host.make_consts(pb["Q"], pb["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, pb["obs_lla"], obs_type='aer',
+                              propagator=propagator, resample=resample)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    zn = torch.randn((1, 480, m, 3), dtype=torch.float64, device="cuda", generator=gen) * torch.as_tensor(pb["z_sigma"], device="cuda")
+    eng = engine.HotPathEngine(consts, m, 1, pb["trans"], zn, history=2)
+    eng.load_state(0, pb["x_true"], pb["x"], np.broadcast_to(pb["P0"], (m, 6, 6)))
+    local = parallel.HipLocalStepper(eng, consts, fast_stats=True, defer_fold=True)
+    local.load_schedule(list(np.arange(W + K) % m))
+    snap = eng.snapshot(0)
+    i = 0
+
+    def run(n):
+        nonlocal i
+        for _ in range(n):
+            if i == 479:
+                local.reset_episode(snap, 480)
+                i = 0
+            i += 1
+            local.step(-1)
+    run(W)
+    local.flush()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(K)
+    local.flush()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out = {"value": round(K / el * (m / 20000.0), 2), "ms_per_step": round(1e3 * el / K, 5),
+           "failed_filters": int((eng.status != 0).sum().item())}
+    del eng, local, zn
+    return out
+
+
+def gym_api_rate(m, mode, n=300):
+    """env.step() through the gym API (host in the loop: action in, launch, one sync, statistics + observation out over
+    PCIe): the closed-loop rate an unmodified agents.py / RLlib worker sees.  Never `value`."""
+    from ssa_gym_amd.envs import env_config, make
+    cfg = dict(env_config)
+    cfg.update(rso_count=m, steps=480, reward_type='trinary', obs_returned=mode, seed=0, history=2, device_rng=True)
+    env = make(config=cfg)
+    for k in range(20):
+        env.step(k % m)
+    t0 = time.perf_counter()
+    for k in range(n):
+        env.step((20 + k) % m)
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(1.0 / dt * (m / 20000.0), 2), "ms_per_step": round(1e3 * dt, 5),
+            "obs_bytes_per_step": m * (12 if mode == 'flatten' else 4) * 8}
+
+
+def self_launch(argv, n):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as CHILD processes of a parent
+    that never touches the GPU (no torch import here, no HIP call), relay rank 0's JSON line and exit with the
+    launcher's code.  One process per GPU, rendezvous on 127.0.0.1."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.lstrip().startswith("{") and '"metric"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    raise SystemExit(rc if rc else (0 if line is not None else 1))
+
+
+def dry_run(args):
+    """launcher / rendezvous / collective plumbing of the N-rank path without a GPU (CPU test of `--gpus N`): gloo
+    process group, the ShardedStepper host logic over a payload-only local stepper (no step arithmetic: nothing here
+    computes the hot path), rank 0 prints the JSON line."""
+    import torch
+    import torch.distributed as dist
+    from ssa_gym_amd import parallel
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    m = args.objects
+    plan = parallel.ShardPlan(m * world, world, rank)
+
+    class PayloadOnly:
+        device = "cpu"
+
+        def step(self, local_action, obs_out=None, stats_out=None, profile_slot=None):
+            obs_out.fill_(float(rank))
+            stats_out.zero_()
+            stats_out[parallel.STAT_CNT_LT_1E7] = plan.m_local
+            stats_out[parallel.STAT_ARGMAX_SPOS] = -1.0
+    sh = parallel.ShardedStepper(plan, PayloadOnly())
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        sh.step(k % plan.m_total)
+    dist.barrier()
+    el = time.perf_counter() - t0
+    obs, st = sh.global_obs(), sh.global_stats()
+    ok = bool(obs.numel() == 4 * plan.m_total and st[parallel.STAT_CNT_LT_1E7] == plan.m_total and
+              all(float(obs[4 * plan.offsets[r]]) == float(r) for r in range(world)))
+    if rank == 0:
+        print(json.dumps({"metric": "env_steps_per_sec_at_20k_objects", "value": None, "dry_run": True, "n_gpus": world,
+                          "steps": args.steps, "ms_per_step": round(1e3 * el / max(1, args.steps), 5),
+                          "config": {"workload": "DRY RUN (gloo, no GPU, no step arithmetic): launcher + all-gather plumbing",
+                                     "ranks": dist.get_world_size(), "payload_ok": ok}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,7 +239,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rollout", type=int, default=60,
                     help="steps per launch of the additional open-loop rollout measurement (0 = skip); never `value`")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU rehearsal of the N-rank launch path (gloo, no GPU, no step arithmetic); never a measurement")
+    ap.add_argument("--no-legs", action="store_true", help="skip the additional N=1 legs (j2, elements, resample, gym_api, closed_loop)")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(sys.argv[1:], args.gpus)      # does not return
+    if args.dry_run:
+        return dry_run(args)
 
     import torch
     import torch.distributed as dist
@@ -124,8 +259,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or "RANK" in os.environ   # under torch.distributed.run even 1 rank goes through RCCL
     if use_dist:
@@ -232,7 +366,9 @@ def main():
     if rank == 0:
         # whole steps exactly as in the timed region, back to back; launch k of the dominant kernel is timed by the
         # HIP event pair bound to that dispatch (on the launch stream)
-        nl = min(K, 480, _lib.PROFILE_SLOTS)
+        nl = min(ep_len - 1, _lib.PROFILE_SLOTS)   # one whole 479-step episode, whatever --steps was
+        local.reset_episode(snap, ep_len)
+        state["i"] = 0
         torch.cuda.synchronize()
         for k in range(nl):   # (sharded runs: the same kernel, timed on the local stepper without the collective)
             one_step(0, profile_slot=k, local_only=True)
@@ -248,11 +384,18 @@ def main():
                 traffic = json.load(open(tj)).get("%s_%d" % (args.propagator, m))
             except Exception:  # noqa: BLE001
                 traffic = None
+        fp64_tflops = FP64_FLOP_PER_OBJECT_STEP * m / (kern_ms * 1e-3) / 1e12
         roof = {"bound": "hbm", "kernel": "ssa::step_fast_kernel<%d>" % {"elements": 0, "fg": 1, "j2": 2}[args.propagator],
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "kernel_ms": round(kern_ms, 5), "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": nl,
-                "note": "fp64 VALU / latency bound, not HBM bound: ~14 Kepler solves per object-step (SURVEY 8d)"}
+                "fp64_frac": round(fp64_tflops / FP64_PEAK_TFLOPS, 4),
+                "fp64": {"flop_per_object_step": FP64_FLOP_PER_OBJECT_STEP, "achieved_tflops": round(fp64_tflops, 2),
+                         "peak_tflops": FP64_PEAK_TFLOPS,
+                         "note": "flop count from the SQ_INSTS_VALU_*_F64 counters of the fg kernel (profiles/); datasheet vector peak"},
+                "limiter": "per-wavefront dependency chain + VALU / LDS issue (HBM idles between the load and store bursts); "
+                           "`bound` names the roofline north_star declares for the path, the kernel is not memory-bound",
+                "note": "whole 479-step episode of back-to-back per-step launches, HIP event pair bound to each dispatch"}
 
     # ---- additional line (never `value`): the same K steps through ssa_env_rollout_f64, `--rollout` steps per
     # launch -- what an open-loop schedule such as this protocol's round-robin allows (state resident in LDS across
@@ -281,6 +424,24 @@ def main():
                 "failed_filters": int((eng.status != 0).sum().item()),
                 "note": "open-loop schedule only (actions of a launch known up front); bit-identical to per-step launches"}
 
+    # ---- additional N=1 legs on the same 20 000-object workload, each measured exactly like `value` (never `value`):
+    # the J2 extension (BASELINE config 3's "J2 on"), the reference-operation-order propagator, the redraw variant of
+    # predict() (the UKF default is parity-unpinned: filterpy is absent), and the gym API with the host in the loop
+    legs = {}
+    if rank == 0 and world == 1 and not use_dist and not args.no_legs:
+        Kl, Wl = min(K, 1000), min(W, 100)
+        for name, kw in (("j2", dict(propagator="j2")), ("elements", dict(propagator="elements")),
+                         ("resample", dict(propagator=args.propagator, resample=True))):
+            if name == args.propagator:
+                continue
+            legs[name] = local_variant_rate(m, Kl, Wl, **kw)
+        if "j2" in legs:
+            legs["j2"].update(note="EXTENSION without reference counterpart (SURVEY section 0): two-body + J2, RK4, 4 sub-steps")
+        legs["resample"].update(note="predict() redraws the sigma points from the prior (SSA_FLAG_RESAMPLE); `value` keeps the "
+                                     "propagated points; which of the two the reference's unpinned filterpy does is unverifiable offline")
+        legs["gym_api"] = {"flatten": gym_api_rate(m, 'flatten'), "aer": gym_api_rate(m, 'aer'),
+                           "note": "SSA_Tasker_Env.step() per call, host in the loop, PCIe + one sync inclusive (20 000 objects)"}
+
     cpu, cpu_all = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N=1 only
         cpu = cpu_baseline(m)
@@ -306,11 +467,15 @@ def main():
                        "allgather_api": (("RCCL ncclAllGather enqueued directly in the compute/communication stream"
                                           if sharded._rccl is not None else "torch.distributed.all_gather_into_tensor")
                                          if sharded is not None else None),
-                       "allgather_warmup_probe": allgather_probe},
+                       "allgather_warmup_probe": allgather_probe,
+                       "rccl_ranks": (sharded._rccl.count() if (sharded is not None and sharded._rccl is not None)
+                                      else (dist.get_world_size() if use_dist else None)),
+                       "ukf_variant": "keep propagated sigma points for update() (default; PARITY-UNPINNED, see `resample`)"},
             "object_steps_per_sec": round(steps_per_s * m * world, 1),
             "failed_filters": n_failed,
             "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "rollout": roll,
         }
+        out.update(legs)
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(steps_per_s * world / cpu["value"], 1)
             out["speedup_vs_cpu_baseline_all_cores"] = round(steps_per_s * world / cpu_all["value"], 1)

@@ -59,7 +59,11 @@ extern "C" {
                                acceleration, classical RK4 with ssa_consts.rk4_substeps sub-steps per dt */
 
 /* flags of ssa_step_params.flags */
-#define SSA_FLAG_RESAMPLE 1u /* redraw sigma points from the prior before update() (filterpy-master predict()) */
+#define SSA_FLAG_RESAMPLE 1u /* predict() ends by redrawing the sigma points from the prior, for every filter (the
+                                predict() of filterpy's development branch); default off = the propagated points are
+                                kept for update() (believed to be what the released filterpy 1.4.5 does).  Which
+                                of the two the reference's unpinned `filterpy` requirement resolved to cannot be checked
+                                offline (the package is absent): the default is PARITY-UNPINNED, both are tested. */
 
 /* layout of the per-env update record written by ssa_env_step_f64 (doubles) */
 #define SSA_UPD_STRIDE 64

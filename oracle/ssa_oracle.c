@@ -821,6 +821,11 @@ void orc_env_step(const double *x_true_in, double *x_true_out, const double *x_i
         int fail = status[j];
         if (!fail) {
             int rc = ukf_predict(x, P, qq, (real)dt, (real)scale, wm, wc, centred, sf);
+            if (rc == ST_OK && resample) { /* filterpy development branch: predict() ends with sigma_points(x, P) for EVERY
+                                            * filter -> an exhausted robust_cholesky ladder is a PREDICT failure of this step */
+                int rung;
+                if (sigma_points(x, P, (real)scale, sf, &rung)) rc = ST_PREDICT_LINALG;
+            }
             if (rc != ST_OK) { status[j] = rc; fail = 1; }
         }
         if (!fail && do_update && j == action) { /* update with observation (:292-315) */
@@ -833,7 +838,7 @@ void orc_env_step(const double *x_true_in, double *x_true_out, const double *x_i
             st(zt, upd_out + 1, 3);
             if (aer[1] >= (real)obs_limit) { /* object_visible (:418-425) uses the true elevation */
                 for (int c = 0; c < 3; ++c) z[c] = (real)((double)zt[c] + z_noise3[c]);
-                int rc = ukf_update(x, P, sf, z, rr, wm, wc, (real)scale, obs_type, centred, resample, mm, ll, oo, y, S, sh);
+                int rc = ukf_update(x, P, sf, z, rr, wm, wc, (real)scale, obs_type, centred, 0 /* redrawn in predict */, mm, ll, oo, y, S, sh);
                 if (rc == ST_OK || rc == ST_UPDATE_NAN) {
                     upd_out[0] = 1.0;
                     st(y, upd_out + 4, 3); st(S, upd_out + 7, 9); st(sh, sigmas_h_out, NS * NZ);

@@ -694,6 +694,14 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         if (chol_fail) st_new = SSA_ST_PREDICT_LINALG;
         else if (nan_x) st_new = SSA_ST_PREDICT_NAN;
     }
+    // SSA_FLAG_RESAMPLE (the predict() of filterpy's development branch): sigma_points(x_prior, P_prior) is drawn at the
+    // end of predict() for EVERY filter, so an exhausted robust_cholesky ladder fails the filter in THIS step's predict
+    // (not one step later); the update then uses those points (t.U holds the factor rows)
+    if (C.flags & SSA_FLAG_RESAMPLE) {
+        const int rg = robust_chol_row_lds(t, C.scale, g, l);
+        wave_lds_sync();
+        if (active && st_new == SSA_ST_OK && rg == 16) st_new = SSA_ST_PREDICT_LINALG;
+    }
 
     // ---- U5: the one update of this env (ssa_tasker_simple_2.py:292-315), in the row that owns the
     // selected object.  Cross-lane traffic is row-level (DPP / bpermute); the small matrices are staged
@@ -710,15 +718,11 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         if (attempted) {
             const double* M = p.trans + (int64_t)tmod * 9;
             // sigma points handed to update(): the propagated ones or, with
-            // SSA_FLAG_RESAMPLE, a fresh set drawn from the prior (x, P now in t.X / t.P)
+            // SSA_FLAG_RESAMPLE, the set drawn from the prior at the end of predict (factor rows in t.U)
             double sf[6];
 #pragma unroll
             for (int c = 0; c < 6; ++c) sf[c] = o[c];
-            bool rs_fail = false;
             if (C.flags & SSA_FLAG_RESAMPLE) {
-                const int rg = robust_chol_row_lds(t, C.scale, g, l);
-                wave_lds_sync();
-                rs_fail = (rg == 16);
                 const int krow = is_pm ? (l - 1) % 6 : 0;
                 const double sgn = (l >= 1 && l <= 6) ? 1.0 : ((l >= 7 && l <= 12) ? -1.0 : 0.0);
 #pragma unroll
@@ -742,9 +746,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
 #pragma unroll
                 for (int c = 0; c < 3; ++c) rec[SSA_UPD_Z_TRUE + c] = z[c];
             }
-            if (visible && rs_fail) {
-                st_new = SSA_ST_UPDATE_LINALG;
-            } else if (visible) {
+            if (visible) {
                 // H3/H5: predicted measurement
                 double zp[3];
                 const double wl = (l == 0) ? C.Wc0 : (is_pm ? C.Wi : 0.0);

@@ -150,3 +150,60 @@ def test_bench_cpu_share_respects_cgroup_quota(tmp_path, monkeypatch):
     assert bench.host_cpu_share() == 256
     monkeypatch.setattr(builtins, "open", fake("50000 100000\n"))
     assert bench.host_cpu_share() == 1
+
+
+# ---------------------------------------------------------------- register budget of the built code object
+def _code_object(tmp_path):
+    """the gfx950 code object embedded in the built libssa_hip.so (the file that ships), its metadata and disassembly"""
+    import shutil
+    import subprocess
+    import ssa_gym_amd
+    from ssa_gym_amd import _build
+    ssa_gym_amd.build()
+    b = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(b, "clang-offload-bundler")):
+        pytest.skip("no ROCm LLVM tools here")
+    fb, co = str(tmp_path / "fb.bin"), str(tmp_path / "dev.co")
+    subprocess.check_call([os.path.join(b, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fb, _build.LIB, str(tmp_path / "copy.so")])
+    subprocess.check_call([os.path.join(b, "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                           "--input=" + fb, "--output=" + co])
+    notes = subprocess.check_output([os.path.join(b, "llvm-readelf"), "--notes", co], text=True)
+    dis = subprocess.check_output([os.path.join(b, "llvm-objdump"), "-d", "--no-show-raw-insn", co], text=True)
+    shutil.rmtree(str(tmp_path), ignore_errors=True)
+    return notes, dis
+
+
+def test_step_kernels_keep_their_register_budget(tmp_path):
+    """The step / rollout kernels must fit 96 VGPRs (5 wavefronts per SIMD = the whole 20 000-object step resident in
+    one round) and must not spill on the common path: the build relies on a whole-TU compiler switch
+    (-disable-machine-licm, _build.py), so a toolchain change that brings the spills back (41.7 MB of scratch traffic
+    per launch when it happened) has to fail HERE, not show up as a slower bench.  Scratch accesses are allowed only
+    as the save / restore around the rare out-of-line calls (non-elliptic conics, the complete farnocchia())."""
+    import re
+    notes, dis = _code_object(tmp_path)
+    kern = {}
+    for blk in notes.split("- .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        kern[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1)) for k in
+                      ("vgpr_count", "sgpr_count", "private_segment_fixed_size", "vgpr_spill_count", "group_segment_fixed_size")}
+    hot = [k for k in kern if "step_fast_kernel" in k or "rollout_kernel" in k]
+    assert len(hot) == 9, hot                      # 3 propagators x {one tile, multi tile} + 3 rollout instances
+    for k in hot:
+        assert kern[k]["vgpr_count"] <= 96, (k, kern[k])
+        assert kern[k]["private_segment_fixed_size"] <= 128, (k, kern[k])     # the callees' frames only
+        assert kern[k]["group_segment_fixed_size"] <= 160 * 1024 // 20, (k, kern[k])   # 20 wavefronts' tiles per CU
+    # disassembly: every scratch access of a hot kernel lies next to an out-of-line call (s_swappc_b64)
+    bodies = re.split(r"\n[0-9a-f]+ <([^>]+)>:\n", dis)
+    checked = 0
+    for name, body in zip(bodies[1::2], bodies[2::2]):
+        if not ("step_fast_kernel" in name or "rollout_kernel" in name):
+            continue
+        ins = [ln.split()[0] for ln in body.splitlines() if ln.strip() and not ln.strip().startswith(("//", ";"))]
+        calls = [i for i, op in enumerate(ins) if op == "s_swappc_b64"]
+        stray = [i for i, op in enumerate(ins) if op.startswith("scratch_") and not (calls and min(abs(i - c) for c in calls) <= 96)]
+        if "Lb0E" in name:      # one tile per wavefront (every launch up to 20 480 objects: the headline kernels): none
+            assert not stray, (name, stray[:8], "scratch access away from any call: a spill on the common path")
+        else:                   # grid-stride / rollout instances carry staging registers around a loop: a bounded handful
+            assert kern[name]["vgpr_spill_count"] <= 24, (name, kern[name], "more spilled registers than the recorded ceiling")
+        checked += 1
+    assert checked == 9

@@ -64,7 +64,7 @@ def make_batch(m, seed, tight_fraction=0.0):
 
 
 def run_gpu(hip, xt, x, P, g, action, tix, alpha, obs_type='aer', propagator='fg', resample=False,
-            obs_limit=-np.pi / 2, E=1, status=None, R=None, z_noise=None):
+            obs_limit=-np.pi / 2, E=1, status=None, R=None, z_noise=None, zn_strides=None):
     m = x.shape[0] // E
     R = g["R"] if R is None else R
     consts = hip.host.make_consts(g["Q"], R, alpha, 2.0, -3, 20.0, obs_limit, g["obs_lla"], obs_type=obs_type,
@@ -72,7 +72,11 @@ def run_gpu(hip, xt, x, P, g, action, tix, alpha, obs_type='aer', propagator='fg
     rs = np.random.RandomState(99)
     if z_noise is None:
         z_noise = rs.normal(size=(E, 480, m, 3)) * np.array([4.8e-6, 4.8e-6, 1e3])
-    eng = hip.engine.HotPathEngine(consts, m, E, c2t(), z_noise, history=2)
+    if zn_strides is None:
+        eng = hip.engine.HotPathEngine(consts, m, E, c2t(), z_noise, history=2)
+    else:   # (env, time, object) strides of a compact noise table
+        eng = hip.engine.HotPathEngine(consts, m, E, c2t(), z_noise, history=2, zn_stride_env=zn_strides[0],
+                                       zn_stride_time=zn_strides[1], zn_stride_obj=zn_strides[2])
     eng.load_state(0, xt, x, P)
     if status is not None:
         eng.status.copy_(hip.torch.as_tensor(status))
@@ -118,14 +122,35 @@ def inclination(x):
     return np.arctan2(np.hypot(h[:, 0], h[:, 1]), h[:, 2])
 
 
-def check_parity(gpu, f64, ld, exact_bound, tol_x=1e-6, tol_P=1e-5, well_frac=0.5):
-    """the two-sided criterion of the module docstring; returns the error arrays."""
+def reference_floor(oracle, ld, xt, x, P, g, action, tix, alpha, n_pert=8, **kw):
+    """per-object fp64 floor of the REFERENCE arithmetic: the largest distance from the exact value (80-bit witness
+    `ld`) over the unperturbed run and n_pert runs whose filter states are moved by at most one ulp per component.
+    One run is a single realisation of the rounding noise (an object can sit close to the exact value by luck); the
+    maximum over nine tells how well the reference value of that object is DEFINED."""
+    rs = np.random.RandomState(5)
+    fl = np.zeros((3, x.shape[0]))
+    for k in range(n_pert + 1):
+        xp = x if k == 0 else x * (1 + 2.220446049250313e-16 * rs.randint(-1, 2, size=x.shape))
+        f = run_oracle(oracle, xt, xp, P, g, action, tix, alpha, **kw)
+        fl = np.maximum(fl, np.array(errs(f, ld)))
+    return fl
+
+
+def check_parity(gpu, f64, ld, exact_bound, tol_x=1e-6, tol_P=1e-5, well_frac=0.5, min_well=0.25, floor=None, tag=""):
+    """the two-sided criterion of the module docstring; returns the error arrays.  `floor` (reference_floor) replaces
+    the single-realisation distance f64-vs-exact in the definition of "well defined"; `min_well` is the measured
+    fraction of well-defined objects of the batch (oracle-only quantity), asserted so that the strict comparison
+    cannot silently shrink."""
     ep, ev, eP = errs(gpu, f64)
     rp, rv, rP = errs(f64, ld)      # the reference arithmetic's own distance from the exact value
     gp, gv, gP = errs(gpu, ld)
     # (1) objects whose reference value is itself defined 2x tighter than the tolerance
-    well = (rp < well_frac * tol_x) & (rv < well_frac * tol_x) & (rP < well_frac * tol_P)
-    assert well.mean() > 0.25, well.mean()
+    fp, fv, fP = (rp, rv, rP) if floor is None else floor
+    well = (fp < well_frac * tol_x) & (fv < well_frac * tol_x) & (fP < well_frac * tol_P)
+    print("[parity%s] strictly compared (reference value defined to %.1f x tol): %.4f of %d objects; max |gpu-ref| there: "
+          "pos %.2e vel %.2e cov %.2e; all objects gpu-vs-exact max pos %.2e, reference-vs-exact max pos %.2e"
+          % (tag, well_frac, well.mean(), len(well), ep[well].max(), ev[well].max(), eP[well].max(), gp.max(), rp.max()))
+    assert well.mean() >= min_well, (well.mean(), min_well)
     assert ep[well].max() < tol_x and ev[well].max() < tol_x, (ep[well].max(), ev[well].max())
     assert eP[well].max() < tol_P, eP[well].max()
     # (2) every object: the kernel is at least as accurate as the reference arithmetic
@@ -149,10 +174,17 @@ def test_predict_parity_2000_objects(hip, oracle, oracle_ld, alpha, propagator):
     assert np.all(gpu["status"] == 0) and np.all(f64["status"] == 0)
     # truth propagation: plain Kepler parity
     assert_states_close(gpu["x_true"], f64["x_true"], 1e-9, "truth")
-    # the element path carries the same (independent) rounding sensitivity as the reference, so its
-    # distance to the reference value is the sum of both: judge it on the tighter-conditioned objects
-    ep, rp, gp = check_parity(gpu, f64, ld, exact_bound=(propagator == "fg"),
-                              well_frac=0.5 if propagator == "fg" else 0.1)
+    # Fraction of objects whose reference value is defined to 0.5 x tolerance (oracle-only numbers, measured for this
+    # batch): alpha = 1e-3: 1.0; alpha = 1e-4: 0.8865 by the single run, 0.8365 by the nine-realisation floor.
+    # SSA_PROP_FG is compared on the former set (and against the exact value on ALL objects); SSA_PROP_ELEMENTS
+    # carries the same, independent, rounding sensitivity as the reference (its distance to the reference value is
+    # the sum of both), so it is compared on the objects whose reference value is defined to 0.5 x tolerance under
+    # one-ulp input perturbations -- the excluded 16 % are the objects where the reference's own fp64 result moves
+    # by more than half the tolerance when an input changes by one ulp.
+    floor = reference_floor(oracle, ld, xt, x, P, g, -1, 1, alpha, z_noise3=np.zeros(3)) if propagator == "elements" else None
+    min_well = {("fg", 1e-3): 0.99, ("fg", 1e-4): 0.88, ("elements", 1e-3): 0.99, ("elements", 1e-4): 0.83}[(propagator, alpha)]
+    ep, rp, gp = check_parity(gpu, f64, ld, exact_bound=(propagator == "fg"), well_frac=0.5, min_well=min_well, floor=floor,
+                              tag=" %s alpha=%g" % (propagator, alpha))
     # obs / metrics are consistent with the state the kernel wrote
     assert np.array_equal(gpu["obs"][:, :6], gpu["x"])
     assert np.array_equal(gpu["obs"][:, 6:], np.einsum('jii->ji', gpu["P"]))
@@ -296,6 +328,10 @@ def test_failure_sentinels_and_skip(hip, oracle):
     ld = run_oracle(orc.Oracle(True), xt, x, P, g, 2, 1, alpha, status=status, centred=True, z_noise3=np.zeros(3))
     assert_states_close(gpu["x"][ok], ld["x"][ok], 1e-6, "healthy objects")
     assert gpu["upd"][0, hip.lib.UPD_OBS_TAKEN] == 0.0         # action pointed at a failed filter
+    # ... which the reference skips entirely (:293): no z_true, the record says "no update attempted"
+    assert gpu["upd"][0, hip.lib.UPD_ACTION] == -1.0
+    gpu9 = run_gpu(hip, xt, x, P, g, [9], 1, alpha, status=status)           # a filter that had failed in an EARLIER step
+    assert gpu9["upd"][0, hip.lib.UPD_ACTION] == -1.0 and gpu9["upd"][0, hip.lib.UPD_OBS_TAKEN] == 0.0
     assert gpu["stats"][0, hip.lib.STAT_N_FAILED] == 4
     assert gpu["stats"][0, hip.lib.STAT_MAX_DPOS] > 1e19       # sentinel dominates -> 'jones' done
 
@@ -638,7 +674,7 @@ def test_full_size_20000_parity_with_update(hip, oracle, oracle_ld):
     assert_states_close(gpu["x_true"], f64["x_true"], 1e-9, "truth")
     others = np.arange(m) != a
     sub = lambda d: {k: d[k][others] for k in ("x", "P")}       # the updated object is judged separately (finding 3 of DESIGN section 4)
-    check_parity(sub(gpu), sub(f64), sub(ld), exact_bound=True)
+    check_parity(sub(gpu), sub(f64), sub(ld), exact_bound=True, min_well=0.875, tag=" fg 20000 objects")   # measured 0.8842
     assert gpu["upd"][0, hip.lib.UPD_OBS_TAKEN] == 1.0
     # the update: posterior mean within the reference arithmetic's own distance from the witness (x3), trace P collapsed
     ep = np.linalg.norm(gpu["x"][a, :3] - ld["x"][a, :3]) / np.linalg.norm(ld["x"][a, :3])
@@ -689,3 +725,201 @@ def test_predict_only_drift_over_150_steps(hip, oracle, oracle_ld):
     nP = lambda c: np.max(np.abs(c - res["ld"][2]) / (sd[:, :, None] * sd[:, None, :]), axis=(1, 2))
     eP_gpu, eP_ref = nP(gP), nP(res["f64"][2])
     assert np.median(eP_gpu) <= 3 * np.median(eP_ref) + 1e-12 and eP_gpu.max() <= 3 * eP_ref.max() + 1e-9
+
+
+@pytest.mark.parametrize("propagator", ["fg", "elements"])
+@pytest.mark.parametrize("resample", [False, True])
+def test_reference_test6_test7_on_the_hip_path(hip, resample, propagator):
+    """The reference's only numeric UKF pins (tests.py:118-188), run through ssa_env_step_f64 and held to the
+    reference's OWN thresholds: Test 6 -- 50 predicts at dt = 30 s, alpha = 1e-3, P0 = diag(1000 x3, 1 x3), qvar 1e-6^2:
+    |pos error| < 1 m, |vel error| < 1e-4 m/s; Test 7 -- one update with the exact position (hx_xyz, R given 1-D =
+    125 * ones(3,3) after filterpy's broadcast): both < 1e-2; 50 more predicts and a second
+    exact update: both < 1e-2 again (tests.py:174-186).  The env step propagates the truth and predicts in the same
+    launch; the update of step 50 uses that step's propagated sigma points exactly as predict() x 50 then update()."""
+    g = golden("test67_golden.npz")
+    gs = golden("ukf_step_golden.npz")
+    m = 5                                     # the same object in every row of a ragged tile (4 + 1)
+    dt, alpha = float(g["dt"]), 1e-3
+    R = 125.0 * np.ones((3, 3))
+    consts = hip.host.make_consts(g["Q"], R, alpha, 2.0, -3, dt, -np.pi / 2, gs["obs_lla"], obs_type='xyz',
+                                  propagator=propagator, resample=resample)
+    zn = hip.torch.zeros((1, 480, m, 3), dtype=hip.torch.float64, device="cuda")      # z = x_true[:3] exactly
+    eng = hip.engine.HotPathEngine(consts, m, 1, c2t(), zn, history=2)
+    eng.load_state(0, np.tile(g["x0"], (m, 1)), np.tile(g["x0"], (m, 1)), np.tile(g["P0"], (m, 1, 1)))
+
+    def err(slot, j):
+        d = eng.x_filter[slot, j].cpu().numpy() - eng.x_true[slot, j].cpu().numpy()
+        return np.linalg.norm(d[:3]), np.linalg.norm(d[3:])
+
+    k = 0
+    for _ in range(49):
+        eng.set_actions([-1])
+        eng.launch_step(k % 2, (k + 1) % 2, k + 1)
+        k += 1
+    # Test 6: state after the 50th predict = prior of step 50; take it from a predict-only twin of that step
+    eng.set_actions([-1])
+    eng.launch_step(k % 2, (k + 1) % 2, k + 1)
+    hip.torch.cuda.synchronize()
+    np.testing.assert_allclose(eng.x_true[(k + 1) % 2, 0].cpu().numpy(), g["xt50"], rtol=1e-12)
+    e6 = err((k + 1) % 2, 0)
+    P50 = eng.P_filter[(k + 1) % 2, 0].cpu().numpy()
+    np.testing.assert_allclose(P50, g["P50"], rtol=1e-5, atol=1e-5 * np.abs(g["P50"]).max())
+    # the same step again, now with the update of object 2 (slot k still holds the state after 49 steps)
+    eng.set_actions([2])
+    eng.launch_step(k % 2, (k + 1) % 2, k + 1)
+    hip.torch.cuda.synchronize()
+    k += 1
+    assert eng.upd[k % 2, 0, hip.lib.UPD_OBS_TAKEN].item() == 1.0 and int((eng.status != 0).sum().item()) == 0
+    e7 = err(k % 2, 2)
+    e6_twin = err(k % 2, 0)                   # rows that were not selected stay predict-only
+    x50u = eng.x_filter[k % 2, 2].cpu().numpy()
+    for _ in range(49):
+        eng.set_actions([-1])
+        eng.launch_step(k % 2, (k + 1) % 2, k + 1)
+        k += 1
+    eng.set_actions([2])
+    eng.launch_step(k % 2, (k + 1) % 2, k + 1)
+    hip.torch.cuda.synchronize()
+    k += 1
+    e7b = err(k % 2, 2)
+    print("[Test 6/7 on HIP, %s%s] after 50 predicts: pos %.4g m vel %.4g m/s | after update: pos %.4g vel %.4g | "
+          "after 50 more predicts + update: pos %.4g vel %.4g   (reference restatement: %s)"
+          % (propagator, " resample" if resample else "", *e6, *e7, *e7b, g["err_rs" if resample else "err"]))
+    assert e6 == e6_twin
+    assert e6[0] < 1.0 and e6[1] < 1.0e-4                 # tests.py:156-157
+    assert e7[0] < 1.0e-2 and e7[1] < 1.0e-2              # tests.py:170-171
+    assert e7b[0] < 1.0e-2 and e7b[1] < 1.0e-2            # tests.py:185-186
+    # and the posterior agrees with the restated-filterpy value of the same scenario (composite golden)
+    ref = g["x50u_rs" if resample else "x50u"]
+    assert np.linalg.norm((x50u - ref)[:3]) < 2e-2 and np.linalg.norm((x50u - ref)[3:]) < 2e-3
+
+
+def _energy_j2(s, j2, r_eq):
+    """specific energy including the J2 potential (conserved by the J2 dynamics; z-angular momentum too)"""
+    mu = 398600441800000.0
+    r = np.linalg.norm(s[:, :3], axis=1)
+    sinphi = s[:, 2] / r
+    return 0.5 * np.sum(s[:, 3:] ** 2, 1) - mu / r + mu * j2 * r_eq ** 2 / (2 * r ** 3) * (3 * sinphi ** 2 - 1)
+
+
+def test_full_size_20000_j2_leg(hip):
+    """BASELINE config 3 with "J2 on" at its full size (20 000 objects): the extension propagator in the fused step.
+    No reference counterpart -> size-independent properties on all objects (J2 energy and h_z
+    conserved along the truth, covariances SPD, bitwise determinism, the J2 = 0 limit reproduces the two-body
+    kernel's filter output) plus spot parity of the truth against scipy DOP853 (the reference's unused
+    fx_xyz_cowell configuration, dynamics.py:184-193) on 24 objects."""
+    import j2_reference as J
+    m = 20000
+    xt, x, P, g = make_batch(m, seed=77)
+    a = run_gpu(hip, xt, x, P, g, [4321], 1, 1e-4, propagator='j2')
+    b = run_gpu(hip, xt, x, P, g, [4321], 1, 1e-4, propagator='j2')
+    for k in ("x", "P", "x_true", "obs", "metrics"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.all(a["status"] == 0) and a["upd"][0, hip.lib.UPD_OBS_TAKEN] == 1.0
+    assert np.linalg.eigvalsh(a["P"]).min() > 0
+    j2, req = hip.host.J2_EARTH, hip.host.R_EQ_EARTH
+    np.testing.assert_allclose(_energy_j2(a["x_true"], j2, req), _energy_j2(xt, j2, req), rtol=2e-12)
+    hz = lambda s: s[:, 0] * s[:, 4] - s[:, 1] * s[:, 3]   # noqa: E731
+    np.testing.assert_allclose(hz(a["x_true"]), hz(xt), rtol=1e-11, atol=1e-3)
+    # J2 really acts: the truth differs from the two-body truth by metres in LEO, and matches DOP853 + J2
+    kep = run_gpu(hip, xt, x, P, g, [4321], 1, 1e-4, propagator='fg')
+    d = np.linalg.norm((a["x_true"] - kep["x_true"])[:, :3], axis=1)
+    assert d.max() > 1.0 and np.median(d) > 1e-3
+    rs = np.random.RandomState(0)
+    for j in rs.choice(m, 24, replace=False):
+        ref = J.fx_xyz_cowell_j2(xt[j], 20.0)
+        assert np.linalg.norm((a["x_true"][j] - ref)[:3]) / np.linalg.norm(ref[:3]) < 1e-10
+        assert np.linalg.norm((a["x_true"][j] - ref)[3:]) / np.linalg.norm(ref[3:]) < 1e-9
+    # the filter side: with j2 = 0 the RK4 path must reproduce the parity-checked two-body kernel
+    c0 = hip.host.make_consts(g["Q"], g["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, g["obs_lla"], propagator='j2', j2=0.0)
+    eng = hip.engine.HotPathEngine(c0, m, 1, c2t(), kep["z_noise"], history=2)
+    eng.load_state(0, xt, x, P)
+    eng.set_actions([4321])
+    eng.launch_step(0, 1, 1)
+    hip.torch.cuda.synchronize()
+    x0 = eng.x_filter[1].cpu().numpy()
+    others = np.arange(m) != 4321
+    assert_states_close(x0[others], kep["x"][others], 1e-6, "J2 = 0 limit vs two-body kernel")
+    sd = np.sqrt(np.einsum('jii->ji', kep["P"]))
+    eP = np.max(np.abs(eng.P_filter[1].cpu().numpy() - kep["P"]) / (sd[:, :, None] * sd[:, None, :]), axis=(1, 2))
+    assert eP[others].max() < 1e-5
+
+
+def test_160000_objects_single_launch_and_8x20000_vector(hip, oracle):
+    """The per-GPU loads of BASELINE configs 4 and 5 at full size on one GPU: 160 000 objects of ONE env in a single
+    launch (each wavefront advances 8 tiles, prefetching the next), and the same objects as 8 envs x 20 000 with one
+    action per env.  Objects are independent, so (i) every object that is not selected must come out bit-identical
+    in both groupings and identical to a 20 000-object single-tile launch of its block; (ii) a sample is compared
+    with the CPU oracle; (iii) statistics equal numpy reductions over the metrics."""
+    m, E = 20000, 8
+    N = m * E
+    xt, x, P, g = make_batch(N, seed=4242)
+    rs = np.random.RandomState(7)
+    zn = rs.normal(size=(480, 3)) * np.array([4.8e-6, 4.8e-6, 1e3])     # one noise triple per time step (strides 0, 3, 0)
+    one = run_gpu(hip, xt, x, P, g, [150001], 3, 1e-4, z_noise=zn, zn_strides=(0, 3, 0))   # config 4's object count, one env
+    acts = [11, 19999, 0, 7777, 12345, 1, 19998, 4242]
+    vec = run_gpu(hip, xt, x, P, g, acts, 3, 1e-4, E=E, z_noise=zn, zn_strides=(0, 3, 0))
+    assert np.all(one["status"] == 0) and np.all(vec["status"] == 0)
+    sel_one = np.zeros(N, dtype=bool)
+    sel_one[150001] = True
+    sel_vec = np.zeros(N, dtype=bool)
+    sel_vec[[e * m + a for e, a in enumerate(acts)]] = True
+    same = ~(sel_one | sel_vec)
+    for k in ("x", "P", "x_true", "obs"):
+        assert np.array_equal(one[k][same], vec[k][same]), k
+    assert np.array_equal(one["metrics"].reshape(4, N)[:, same], np.transpose(vec["metrics"], (1, 0, 2)).reshape(4, N)[:, same])
+    for e in range(E):
+        assert vec["upd"][e, hip.lib.UPD_OBS_TAKEN] == 1.0 and vec["upd"][e, hip.lib.UPD_ACTION] == acts[e]
+    assert one["upd"][0, hip.lib.UPD_ACTION] == 150001
+    # a 20 000-object launch (one tile per wavefront) of block 5 gives the same bits as the 8-tile wavefronts
+    sl = slice(5 * m, 6 * m)
+    blk = run_gpu(hip, xt[sl], x[sl], P[sl], g, [-1], 3, 1e-4)
+    keep = same[sl]
+    for k in ("x", "P", "x_true"):
+        assert np.array_equal(blk[k][keep], one[k][sl][keep]), k
+    # statistics of the 160 000-object env and of each 20 000-object env against numpy
+    dp = one["metrics"][0, 0]
+    assert one["stats"][0, hip.lib.STAT_MAX_DPOS] == dp.max()
+    assert one["stats"][0, hip.lib.STAT_CNT_LT_1E4] == (dp < 1e4).sum() and one["stats"][0, hip.lib.STAT_CNT_LT_1E7] == (dp < 1e7).sum()
+    for e in range(E):
+        dpe = vec["metrics"][e, 0]
+        assert vec["stats"][e, hip.lib.STAT_MAX_DPOS] == dpe.max() and vec["stats"][e, hip.lib.STAT_CNT_LT_1E7] == (dpe < 1e7).sum()
+    # oracle parity on a sample of 2 000 objects spread over the whole range (incl. the last, ragged-free, tile)
+    idx = np.sort(rs.choice(N, 2000, replace=False))
+    f64 = run_oracle(oracle, xt[idx], x[idx], P[idx], g, -1, 3, 1e-4, z_noise3=np.zeros(3))
+    ok = same[idx]
+    assert_states_close(one["x_true"][idx], f64["x_true"], 1e-9, "truth 160k")
+    ep = np.linalg.norm((one["x"][idx] - f64["x"])[:, :3], axis=1) / np.linalg.norm(f64["x"][:, :3], axis=1)
+    assert np.median(ep[ok]) < 1e-6 and (ep[ok] < 1e-6).mean() > 0.85
+
+
+@pytest.mark.parametrize("resample", [False, True])
+def test_resample_variant_fails_in_the_predict_that_draws_the_points(hip, oracle, resample):
+    """The two published predict() variants differ in WHEN an exhausted robust_cholesky ladder is seen: the variant that
+    keeps the propagated points draws sigma points only at the start of the NEXT predict (failure flagged one step later);
+    the variant that redraws at the end of predict() fails the filter in the SAME step -- for every filter, not only the
+    one being updated.  A hugely negative process noise makes the prior indefinite beyond the ladder (1e9 I)."""
+    m, alpha = 6, 1e-3
+    xt, x, P, g = make_batch(m, seed=21)
+    Q = g["Q"].copy()
+    Q[2, 2] = -1e30
+    consts = hip.host.make_consts(Q, g["R"], alpha, 2.0, -3, 20.0, -np.pi / 2, g["obs_lla"], resample=resample)
+    eng = hip.engine.HotPathEngine(consts, m, 1, c2t(), np.zeros((1, 480, m, 3)), history=2)
+    eng.load_state(0, xt, x, P)
+    Wm, Wc, scale = orc.merwe_weights(alpha, 2.0, -3)
+    st = np.zeros(m, dtype=np.int32)
+    a, b, c = xt, x, P
+    for k in (1, 2):
+        eng.set_actions([1])
+        eng.launch_step((k - 1) % 2, k % 2, k)
+        hip.torch.cuda.synchronize()
+        r = oracle.env_step(a, b, c, st, 20.0, Q, g["R"], Wm, Wc, scale, 1, c2t()[k], g["obs_lla"], g["obs_itrs"], -np.pi / 2,
+                            np.zeros(3), resample=resample)
+        a, b, c = r["x_true"], r["x"], r["P"]
+        gst = eng.status.cpu().numpy()
+        assert np.array_equal(gst, st), (k, gst, st)
+        if k == 1:
+            assert np.all(gst == (2 if resample else 0))       # redraw: every filter fails in step 1's predict
+        else:
+            assert np.all(gst == 2)                            # keep: the same failure, one step later
+    assert np.array_equal(eng.x_filter[0].cpu().numpy(), np.tile(hip.host.X_FAILED, (m, 1)))

@@ -111,3 +111,22 @@ def test_sharded_env_matches_unsharded_world2():
         obs, st = sh.global_obs().numpy(), sh.global_stats()
         assert np.array_equal(obs, outs[i][0])          # bit-identical observation vector
         assert np.array_equal(st, outs[i][1])           # identical reward statistics (incl. global arg-max)
+
+
+def test_bench_self_launches_its_ranks_dry_run():
+    """`python bench.py --gpus 2` must start its two ranks itself (parent stays GPU-free and relays rank 0's JSON line):
+    rehearsed on CPU with --dry-run (gloo, payload-only stepper: launcher, rendezvous on 127.0.0.1, the sharded
+    all-gather host logic; no step arithmetic, never a measurement)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "4", "--objects", "37"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["dry_run"] is True and rec["config"]["ranks"] == 2 and rec["config"]["payload_ok"] is True
