@@ -294,6 +294,7 @@ struct alignas(16) Tiles {   // LDS working set of one wavefront (4 objects)
     double M[OBJ_PER_WAVE * 12];       // s = Wi sum d_i | m' = mean - sigma_0
     double Obs[OBJ_PER_WAVE * 12];
     double Met[OBJ_PER_WAVE * 4];
+    double Z[6];                       // six zeros: the "factor row" of the lanes that add nothing (sigma_0, truth, idle)
     int St[OBJ_PER_WAVE];
 };
 
@@ -483,42 +484,53 @@ SSA_DEV void wave_lds_sync()
 #endif
 }
 
-// U2 (common case): upper Cholesky of scale*P for the row's object, lane-distributed through LDS:
-// lane c owns column c; step j forms the pivot and row j (LAPACK dpotf2('U') order).  Ten VGPRs
-// instead of the 84 of a per-lane register factorisation.  Returns false (row-uniform) when a
-// pivot is <= 0 / NaN or P holds a non-finite entry -> robust_cholesky's ladder (out of line).
+// U2 (common case): upper Cholesky of scale*P for the row's object, lane-distributed: lane c owns column c of the factor in
+// registers; step j (LAPACK dpotf2('U') order) needs column j's finished entries U[i][j], i < j, and the pivot -- all held
+// by lane j -- in every lane, which is one v_mov_b64_dpp row_newbcast:j each (21 per factorisation, no LDS round trip, no
+// wait; the earlier version went through LDS and paid a write -> read hand-off per pivot).  Lane j forms the pivot from its
+// own column with the same operations as before (same bits).  The factor rows land in t.U at the end (the sigma points
+// need ROWS of U: lane l reads row (l-1)%6, a transposition of the register layout).
+// Returns false (row-uniform) when a pivot is <= 0 / NaN or P holds a non-finite entry -> the ladder.
+template <int J>
+SSA_DEV void chol_step(const double (&a)[6], double (&uc)[6], int lc, bool& ok)
+{
+    double v = a[J];                          // A[J][lc] (meaningful for lc >= J; lane J: the diagonal)
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+        const double uij = row_bcast<J>(uc[i]);   // U[i][J]
+        v = fma(-uij, uc[i], v);                  // lane J: ajj -= U[i][J]^2 ; lane c > J: A[J][c] -= U[i][J] U[i][c]
+    }
+    const double y = row_bcast<J>(rsqrt_nr(v));   // 1 / sqrt(pivot) of lane J; NaN / inf when the pivot is <= 0 or NaN
+    ok = ok && (y > 0.0) && (y <= 1.79769313486231570e308);
+    uc[J] = (lc >= J) ? v * y : 0.0;              // lane J: ajj / sqrt(ajj) = the diagonal entry
+}
 SSA_DEV bool chol_row_lds(Tiles& t, double scale, double jit, int g, int l)
 {
     const double* Pg = &t.P[g * 36];
     double* Ug = &t.U[g * 36];
+    const int lc = l < 6 ? l : 5;   // lanes 6..15 shadow column 5 (their stores are masked)
+    // column lc of the UPPER triangle of scale*P + jit*I (scipy.linalg.cholesky reads the upper triangle only); the six
+    // owning lanes see all 36 entries between them: scipy's check_finite
+    double a[6], uc[6];
     bool ok = true;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {   // scipy check_finite looks at all 36 entries
-        int idx = l + 16 * r;
-        if (idx < 36) ok = ok && (fabs(Pg[idx]) <= 1.79769313486231570e308);
+    for (int j = 0; j < 6; ++j) {
+        const double pv = Pg[j * 6 + lc];
+        ok = ok && (fabs(pv) <= 1.79769313486231570e308);
+        a[j] = scale * pv + ((lc == j) ? jit : 0.0);
     }
     ok = ((__ballot(!ok) >> (g * 16)) & 0xFFFFull) == 0;
-    // Lane c keeps its own column of U in registers (it wrote every entry of it itself); the only cross-lane
-    // traffic is column j read by the whole row at step j -- and from those values every lane forms the
-    // pivot redundantly, with the operations of the owning lane (same bits), instead of a broadcast.
-    const int lc = l < 6 ? l : 5;   // lanes 6..15 shadow column 5 (their stores are masked)
-    double uc[6];
+    chol_step<0>(a, uc, lc, ok);
+    chol_step<1>(a, uc, lc, ok);
+    chol_step<2>(a, uc, lc, ok);
+    chol_step<3>(a, uc, lc, ok);
+    chol_step<4>(a, uc, lc, ok);
+    chol_step<5>(a, uc, lc, ok);
+    if (l < 6) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        double v = scale * Pg[j * 6 + lc] + ((lc == j) ? jit : 0.0);
-        double ajj = scale * Pg[j * 7] + jit;
-#pragma unroll
-        for (int i = 0; i < j; ++i) {
-            const double uij = Ug[i * 6 + j];
-            v = fma(-uij, uc[i], v);
-            ajj = fma(-uij, uij, ajj);
-        }
-        ok = ok && (ajj > 0.0);
-        const double y = rsqrt_nr(ajj);
-        uc[j] = (lc == j) ? ajj * y : (lc > j ? v * y : 0.0);
-        if (l < 6) Ug[j * 6 + l] = uc[j];
-        wave_lds_sync();
+        for (int j = 0; j < 6; ++j) Ug[j * 6 + l] = uc[j];
     }
+    wave_lds_sync();
     return ok;
 }
 
@@ -590,6 +602,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
 
     if (TILE == 0) tile_issue(pf, p, lane, base, cnt);   // one tile per wavefront: plain load, no staging registers kept
     if (TILE != 2) tile_commit(t, pf, lane);            // TILE 1: requested one tile ago (or by the kernel prologue)
+    if (lane < 6) t.Z[lane] = 0.0;
     wave_lds_sync();
     SSA_TR(1);
 
@@ -610,14 +623,15 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     const bool is_pm = (l >= 1 && l <= 12);
     double s[6];
     {
-        const int krow = is_pm ? (l - 1) % 6 : 0;
-        const double sgn = (l >= 1 && l <= 6) ? 1.0 : ((l >= 7 && l <= 12) ? -1.0 : 0.0);
+        const int krow = (l >= 7) ? l - 7 : l - 1;          // factor row of lanes 1..12
+        const double sgn = (l >= 7) ? -1.0 : 1.0;
         const bool use_filter = active && !chol_fail && l != 13;
+        // inactive rows (failed / out-of-range objects) and lane 13 propagate the true state; sigma_0 and the idle lanes
+        // add the zero row: the operands are chosen by ADDRESS (three 16-byte LDS reads each), not by value
+        const double* base = use_filter ? &t.X[g * 6] : &t.T[g * 6];
+        const double* urow = (use_filter && is_pm) ? &t.U[g * 36 + krow * 6] : &t.Z[0];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            // inactive rows (failed / out-of-range objects) and lane 13 propagate the true state
-            s[c] = use_filter ? (t.X[g * 6 + c] + sgn * t.U[g * 36 + krow * 6 + c]) : t.T[g * 6 + c];
-        }
+        for (int c = 0; c < 6; ++c) s[c] = fma(sgn, urow[c], base[c]);
     }
     // ---- P1-P5: one Kepler solve per lane; strong-elliptic fast path inline, every other conic
     // branch through the out-of-line complete restatement
@@ -667,7 +681,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     bool nan_x = false;
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-        const double s0 = row_bcast(o[c], 0);
+        const double s0 = row_bcast<0>(o[c]);
         const double d = is_pm ? (o[c] - s0) : 0.0;
         if (is_pm) t.D[(g * 13 + l) * 6 + c] = d;
         const double ssum = C.Wi * row_allsum(d);
@@ -741,7 +755,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                 if (C.obs_type == SSA_OBS_AER) { z[0] = aer[0]; z[1] = aer[1]; z[2] = aer[2]; }
                 else { z[0] = sf[0]; z[1] = sf[1]; z[2] = sf[2]; }
             }
-            visible = row_bcast(el_mine, 13) >= C.obs_limit;  // object_visible(): elevation of the TRUE state (:418-425)
+            visible = row_bcast<13>(el_mine) >= C.obs_limit;  // object_visible(): elevation of the TRUE state (:418-425)
             if (rec && l == 13) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) rec[SSA_UPD_Z_TRUE + c] = z[c];
@@ -755,7 +769,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                     aer2uvw(z, uvw);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        double u0 = row_bcast(uvw[c], 0);
+                        double u0 = row_bcast<0>(uvw[c]);
                         double du = is_pm ? (uvw[c] - u0) : 0.0;
                         um[c] = u0 + (C.sum_wm_m1 * u0 + C.Wi * row_allsum(du));
                     }
@@ -763,7 +777,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                 } else {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        double u0 = row_bcast(z[c], 0);
+                        double u0 = row_bcast<0>(z[c]);
                         double du = is_pm ? (z[c] - u0) : 0.0;
                         zp[c] = u0 + (C.sum_wm_m1 * u0 + C.Wi * row_allsum(du));
                     }
@@ -788,7 +802,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                 }
                 double y[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) y[c] = row_bcast(rz[c], 13);
+                for (int c = 0; c < 3; ++c) y[c] = row_bcast<13>(rz[c]);
                 // S = sum Wc rz rz^T + R ; Pxz = sum Wc (sigma_f - x)(rz)^T   -> LDS
 #pragma unroll
                 for (int a = 0; a < 3; ++a)

@@ -382,7 +382,10 @@ SSA_DEV bool kepler_fg_core(const double* x, double tof, double r0, double inv_r
             dG = 1.0 - ec * c + es * s;
         }
         if (G > 0.0) hi = xk; else lo = xk;
-        double dx = -G * rcp_nr(dG);
+        // Newton step with the hardware reciprocal estimate (2^-26): an inexact slope only perturbs the step by that
+        // relative amount -- the iterate lands within 1.5e-8 |dx| of the exact Newton iterate, far inside the stopping
+        // tolerance -- and saves the four refinement FMAs per iteration; the hyperbolic solver keeps the refined one
+        double dx = -G * (HYP ? rcp_nr(dG) : __builtin_amdgcn_rcp(dG));
         if (HYP) dx = fmin(fmax(dx, -1.0), 1.0);   // sinh/cosh grow fast: bounded steps
         double xn = xk + dx;
         if (!(xn >= lo && xn <= hi)) xn = 0.5 * (lo + hi);
@@ -651,13 +654,13 @@ SSA_DEV bool inv3(const double* S, double* SI)
 
 // ---------------------------------------------------------------------------
 // wave-level primitives: the 16-lane DPP rows of a wavefront are the "one sigma-point set".
+// 64-bit values move as one builtin: two v_mov_b32_dpp for the rotations, ONE v_mov_b64_dpp for a row broadcast
+// (row_newbcast is the DPP control gfx90a+ accepts on 64-bit operands); `old` = the source and bound_ctrl set, so no
+// preparatory move of the destination is needed.
 template <int CTRL>
 SSA_DEV double dpp_row(double v)
 {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, true);
 }
 // sum over the 16 lanes of a DPP row, result in every lane (row_ror 8,4,2,1 butterfly).
 SSA_DEV double row_allsum(double v)
@@ -668,11 +671,12 @@ SSA_DEV double row_allsum(double v)
     v += dpp_row<0x121>(v);  // row_ror:1
     return v;
 }
-// value of lane `src` (0..15) of the own row, in every lane of the row.
-SSA_DEV double row_bcast(double v, int src)
+// value of lane SRC (0..15) of the own row, in every lane of the row: v_mov_b64_dpp row_newbcast:SRC (no LDS crossbar
+// traffic, no lgkmcnt wait -- the former __shfl went through ds_bpermute_b32 twice per double).
+template <int SRC>
+SSA_DEV double row_bcast(double v)
 {
-    int lane = (int)(threadIdx.x & 63);
-    return __shfl(v, (lane & ~15) | src, 64);
+    return __builtin_amdgcn_update_dpp(v, v, 0x150 + SRC, 0xF, 0xF, true);
 }
 
 }  // namespace ssa

@@ -136,7 +136,8 @@ def reference_floor(oracle, ld, xt, x, P, g, action, tix, alpha, n_pert=8, **kw)
     return fl
 
 
-def check_parity(gpu, f64, ld, exact_bound, tol_x=1e-6, tol_P=1e-5, well_frac=0.5, min_well=0.25, floor=None, tag=""):
+def check_parity(gpu, f64, ld, exact_bound, tol_x=1e-6, tol_P=1e-5, well_frac=0.5, min_well=0.25, floor=None, tag="",
+                 jump_check=None):
     """the two-sided criterion of the module docstring; returns the error arrays.  `floor` (reference_floor) replaces
     the single-realisation distance f64-vs-exact in the definition of "well defined"; `min_well` is the measured
     fraction of well-defined objects of the batch (oracle-only quantity), asserted so that the strict comparison
@@ -151,8 +152,21 @@ def check_parity(gpu, f64, ld, exact_bound, tol_x=1e-6, tol_P=1e-5, well_frac=0.
           "pos %.2e vel %.2e cov %.2e; all objects gpu-vs-exact max pos %.2e, reference-vs-exact max pos %.2e"
           % (tag, well_frac, well.mean(), len(well), ep[well].max(), ev[well].max(), eP[well].max(), gp.max(), rp.max()))
     assert well.mean() >= min_well, (well.mean(), min_well)
-    assert ep[well].max() < tol_x and ev[well].max() < tol_x, (ep[well].max(), ev[well].max())
-    assert eP[well].max() < tol_P, eP[well].max()
+    bad = well & ((ep >= tol_x) | (ev >= tol_x) | (eP >= tol_P))
+    if jump_check is None:
+        assert not bad.any(), (np.where(bad)[0][:8], ep[well].max(), ev[well].max(), eP[well].max())
+    else:
+        # SSA_PROP_ELEMENTS evaluates the reference's own formulas, discontinuities included (rv2coe's branch thresholds,
+        # the 2 pi wraps, Newton's iteration count): on a few objects a one-ulp change of an input moves the REFERENCE
+        # value by more than the tolerance, rarely enough that nine realisations do not reveal it.  Such an object may
+        # differ between the kernel and the reference -- but only if the reference demonstrably differs from itself there:
+        # jump_check(j) = the largest movement of the reference value of object j over 200 one-ulp perturbations.
+        assert bad.sum() <= max(1, int(0.005 * len(well))), bad.sum()
+        for j in np.where(bad)[0]:
+            jp, jv, jP = jump_check(int(j))
+            print("[parity%s] object %d: |gpu-ref| pos %.2e vel %.2e cov %.2e; the reference value itself moves by pos %.2e "
+                  "vel %.2e cov %.2e under one-ulp input perturbations" % (tag, j, ep[j], ev[j], eP[j], jp, jv, jP))
+            assert jp >= 0.5 * ep[j] and jv >= 0.5 * ev[j] and jP >= 0.5 * eP[j], (j, ep[j], ev[j], eP[j], jp, jv, jP)
     # (2) every object: the kernel is at least as accurate as the reference arithmetic
     for g_, r_ in ((gp, rp), (gv, rv), (gP, rP)):
         assert np.median(g_) <= 3 * np.median(r_) + 1e-13
@@ -183,8 +197,18 @@ def test_predict_parity_2000_objects(hip, oracle, oracle_ld, alpha, propagator):
     # by more than half the tolerance when an input changes by one ulp.
     floor = reference_floor(oracle, ld, xt, x, P, g, -1, 1, alpha, z_noise3=np.zeros(3)) if propagator == "elements" else None
     min_well = {("fg", 1e-3): 0.99, ("fg", 1e-4): 0.88, ("elements", 1e-3): 0.99, ("elements", 1e-4): 0.83}[(propagator, alpha)]
+    def jump(j):
+        rs = np.random.RandomState(1000 + j)
+        sl = slice(j, j + 1)
+        base = {k: f64[k][sl] for k in ("x", "P")}
+        out = np.zeros(3)
+        for _ in range(200):
+            xp = x[sl] * (1 + 2.220446049250313e-16 * rs.randint(-1, 2, size=(1, 6)))
+            f = run_oracle(oracle, xt[sl], xp, P[sl], g, -1, 1, alpha, z_noise3=np.zeros(3))
+            out = np.maximum(out, np.array(errs(f, base))[:, 0])
+        return out
     ep, rp, gp = check_parity(gpu, f64, ld, exact_bound=(propagator == "fg"), well_frac=0.5, min_well=min_well, floor=floor,
-                              tag=" %s alpha=%g" % (propagator, alpha))
+                              tag=" %s alpha=%g" % (propagator, alpha), jump_check=jump if propagator == "elements" else None)
     # obs / metrics are consistent with the state the kernel wrote
     assert np.array_equal(gpu["obs"][:, :6], gpu["x"])
     assert np.array_equal(gpu["obs"][:, 6:], np.einsum('jii->ji', gpu["P"]))
