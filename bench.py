@@ -143,6 +143,54 @@ def local_variant_rate(m, K, W, propagator, resample=False, seed=100):
     return out
 
 
+def closed_loop_rate(m, K, W, seed=100):
+    """closed loop WITHOUT the host: per step one launch of the step kernel, then the device-side agent (the reference's
+    agent_visible_greedy, agents.py:36: arg-max of trace(P) over the visible objects -- ssa_agent_select_f64, two small
+    launches) writes the action word the next step reads, all in one stream.  Same workload, episodes of 480 steps."""
+    import torch
+    from ssa_gym_amd import _lib, engine, host
+    pb = build_problem(m, seed=seed)
+    consts = host.make_consts(pb["Q"], pb["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, pb["obs_lla"], obs_type='aer', propagator='fg')
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    zn = torch.randn((1, 480, m, 3), dtype=torch.float64, device="cuda", generator=gen) * torch.as_tensor(pb["z_sigma"], device="cuda")
+    eng = engine.HotPathEngine(consts, m, 1, pb["trans"], zn, history=2)
+    eng.load_state(0, pb["x_true"], pb["x"], np.broadcast_to(pb["P0"], (m, 6, 6)))
+    snap = eng.snapshot(0)
+    word = torch.zeros(1, dtype=torch.int32, device="cuda")
+    fb = torch.zeros(1, dtype=torch.int32, device="cuda")
+    picks = torch.zeros((K + W + 1, 2), dtype=torch.int64, device="cuda")
+    st = {"i": 0, "tick": 0, "n": 0}
+
+    def run(n):
+        for _ in range(n):
+            if st["i"] == 479:
+                eng.flush_stats()
+                st["tick"] += (-st["tick"]) % 480
+                eng.restore(st["tick"] % 2, snap)
+                st["i"] = 0
+                eng.launch_agent_select(st["tick"], st["tick"], _lib.AGENT_VISIBLE_GREEDY, word.data_ptr(), fallback_ptr=fb.data_ptr())
+            st["i"] += 1
+            st["tick"] += 1
+            t = st["tick"]
+            eng.launch_step((t - 1) % 2, t % 2, t, actions_ptr=word.data_ptr(), fast_stats=True, defer_fold=True)
+            eng.launch_agent_select(t, t, _lib.AGENT_VISIBLE_GREEDY, word.data_ptr(), fallback_ptr=fb.data_ptr(),
+                                    pick_ptr=picks.data_ptr() + 16 * st["n"])
+            st["n"] += 1
+    eng.launch_agent_select(0, 0, _lib.AGENT_VISIBLE_GREEDY, word.data_ptr(), fallback_ptr=fb.data_ptr())
+    run(W)
+    eng.flush_stats()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(K)
+    eng.flush_stats()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    chosen = picks[W:W + K, 0].cpu().numpy()
+    return {"value": round(K / el * (m / 20000.0), 2), "ms_per_step": round(1e3 * el / K, 5), "agent": "agent_visible_greedy (device)",
+            "distinct_objects_selected": int(len(set(chosen.tolist()))), "failed_filters": int((eng.status != 0).sum().item()),
+            "note": "closed loop on the device: step launch + ssa_agent_select_f64 (2 launches) per step, no host round trip"}
+
+
 def gym_api_rate(m, mode, n=300):
     """env.step() through the gym API (host in the loop: action in, launch, one sync, statistics + observation out over
     PCIe): the closed-loop rate an unmodified agents.py / RLlib worker sees.  Never `value`."""
@@ -439,6 +487,7 @@ def main():
             legs["j2"].update(note="EXTENSION without reference counterpart (SURVEY section 0): two-body + J2, RK4, 4 sub-steps")
         legs["resample"].update(note="predict() redraws the sigma points from the prior (SSA_FLAG_RESAMPLE); `value` keeps the "
                                      "propagated points; which of the two the reference's unpinned filterpy does is unverifiable offline")
+        legs["closed_loop"] = closed_loop_rate(m, Kl, Wl)
         legs["gym_api"] = {"flatten": gym_api_rate(m, 'flatten'), "aer": gym_api_rate(m, 'aer'),
                            "note": "SSA_Tasker_Env.step() per call, host in the loop, PCIe + one sync inclusive (20 000 objects)"}
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SSA_ABI_VERSION 12
+#define SSA_ABI_VERSION 13
 
 /* error codes */
 #define SSA_OK 0
@@ -252,6 +252,34 @@ int ssa_agent_scores_f64(const double *x_true, const double *x_cur, const double
  * NaN entries are skipped (the reference's agents run under np.errstate and np.argmax would return a
  * NaN's index; skipping is the documented deviation).  out[1] = the maximum (as double bits). */
 int ssa_masked_argmax_f64(const double *score, const uint8_t *mask, int64_t n, int64_t *out, void *stream);
+
+/* ------------------------------------------------ closed loop on the device
+ * The agent's choice for the NEXT step, made on the GPU from the state the step just wrote and stored into the int32
+ * action word(s) ssa_step_params.actions of that next step points at -- enqueue  step, select, step, select, ...  in one
+ * stream and a greedy agent runs at kernel rate with no host round trip (the reference's loop is
+ * `a = agent(obs, env); obs, r, done, _ = env.step(a)`, run_environment.py / compare_agents.py).
+ *   kind                        score (first maximum wins, NaN scores skipped)              objects considered
+ *   SSA_AGENT_NAIVE_GREEDY      trace(P_cur[j])                              agents.py:7    all
+ *   SSA_AGENT_VISIBLE_GREEDY    trace(P_cur[j])                              agents.py:36   visible (elevation of x_true >= obs_limit)
+ *   SSA_AGENT_SHANNON           log(det P_cur[j] / det P_prev[j])            agents.py:15   visible
+ *   SSA_AGENT_POS_ERROR         |x_cur[j][:3] - x_true[j][:3]|               agents.py:66   visible
+ *   SSA_AGENT_VEL_ERROR         |x_cur[j][3:] - x_true[j][3:]|               agents.py:75   visible
+ * Per env e (objects e*n_obj .. +n_obj): action_out[e] = index of the first maximum, or fallback[e] when no object
+ * qualifies (the reference calls action_space.sample() there; the caller supplies that draw), or -1 with fallback NULL.
+ * The GCRS->ITRS matrix is row (env_time[e] + time_offset) % n_time of `trans`, as in the step.  pick_out (optional,
+ * [E][2] int64): the arg-max (-1 = none) and the winning score's bit pattern.  workspace: ssa_agent_select_workspace_bytes().
+ * P_prev may be NULL (no previous step yet): the Shannon score is then NaN for every object -> fallback, as agents.py at i = 0.
+ * Two small launches (per-block first maxima over all CUs, then one wavefront per env). */
+#define SSA_AGENT_NAIVE_GREEDY 0
+#define SSA_AGENT_VISIBLE_GREEDY 1
+#define SSA_AGENT_SHANNON 2
+#define SSA_AGENT_POS_ERROR 3
+#define SSA_AGENT_VEL_ERROR 4
+int ssa_agent_select_f64(const ssa_consts *c_host, int32_t kind, const double *x_true, const double *x_cur,
+                         const double *P_cur, const double *P_prev, const double *trans, const int32_t *env_time,
+                         int32_t time_offset, int32_t n_time, const int32_t *fallback, void *workspace,
+                         int32_t *action_out, int64_t *pick_out, int64_t n_obj, int32_t n_env, void *stream);
+int64_t ssa_agent_select_workspace_bytes(int64_t n_obj, int32_t n_env);
 
 /* library identification */
 int ssa_abi_version(void);

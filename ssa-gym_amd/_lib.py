@@ -45,7 +45,7 @@ class ssa_rollout_params(C.Structure):
 
 
 # constants of include/ssa_hip.h
-ABI_VERSION = 12
+ABI_VERSION = 13
 ST_OK, ST_PREDICT_NAN, ST_PREDICT_LINALG, ST_UPDATE_NAN, ST_UPDATE_LINALG = range(5)
 OBS_AER, OBS_XYZ = 0, 1
 PROP_ELEMENTS, PROP_FG, PROP_J2_RK4 = 0, 1, 2
@@ -54,6 +54,7 @@ UPD_STRIDE, UPD_OBS_TAKEN, UPD_Z_TRUE, UPD_Y, UPD_S, UPD_SIGMAS_H, UPD_VISIBLE, 
 STAT_SHARDS = 64
 PROFILE_SLOTS = 1024
 LAUNCH_DEFER_FOLD = 8
+AGENT_NAIVE_GREEDY, AGENT_VISIBLE_GREEDY, AGENT_SHANNON, AGENT_POS_ERROR, AGENT_VEL_ERROR = range(5)
 STAT_STRIDE, STAT_MAX_DPOS, STAT_CNT_LT_1E4, STAT_CNT_LT_1E7, STAT_ARGMAX_SPOS, STAT_N_FAILED, STAT_MAX_SPOS = 8, 0, 1, 2, 3, 4, 5
 
 # every symbol the header declares, with its ctypes signature
@@ -81,6 +82,9 @@ SIGNATURES = {
     "ssa_agent_scores_f64": (C.c_int, [c_dp, c_dp, c_dp, c_dp, c_dp, C.POINTER(ssa_consts), c_dp, c_dp, C.c_int64, c_dp]),
     "ssa_masked_argmax_f64": (C.c_int, [c_dp, c_dp, C.c_int64, c_dp, c_dp]),
     "ssa_aer_obs_f64": (C.c_int, [c_dp, c_dp, c_dp, C.POINTER(ssa_consts), c_dp, C.c_int64, c_dp]),
+    "ssa_agent_select_f64": (C.c_int, [C.POINTER(ssa_consts), C.c_int32, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int32, C.c_int32,
+                                       c_dp, c_dp, c_dp, c_dp, C.c_int64, C.c_int32, c_dp]),
+    "ssa_agent_select_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
 }
 
 _lib = None

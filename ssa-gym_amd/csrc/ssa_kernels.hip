@@ -285,18 +285,24 @@ struct StepK {
 constexpr int OBJ_PER_WAVE = 4;
 constexpr double X_FAILED_POS = 1e20, X_FAILED_VEL = 1e12;  // ssa_tasker_simple_2.py:157-158
 
-struct alignas(16) Tiles {   // LDS working set of one wavefront (4 objects)
+// LDS working set of one wavefront (4 objects): 7 600 bytes, so that 20 wavefronts (5 per SIMD) share the CU's 160 KB.
+// D holds the centred propagated sigma points d_i = sigma_i' - sigma_0' (i = 1..12) of the four objects as rows of 8
+// doubles [d_i[0..5], 1.0, 0.0]: the layout the matrix unit reads its operands from (below); the object blocks start at
+// {0, 100, 208, 308} doubles so that the 32 lanes of one ds_read_b64 half hit 32 different 8-byte bank slots.
+struct alignas(16) Tiles {
     double P[OBJ_PER_WAVE * 36];       // P_in, later P_out
-    double X[OBJ_PER_WAVE * 6];        // x_in, later x_out
+    double X[OBJ_PER_WAVE * 6];        // x_in, then sigma_0', then x_out
     double T[OBJ_PER_WAVE * 6];        // x_true_in, later x_true_out
-    double U[OBJ_PER_WAVE * 36];       // Cholesky factor rows
-    double D[OBJ_PER_WAVE * 13 * 6];   // centred propagated sigma points d_i
-    double M[OBJ_PER_WAVE * 12];       // s = Wi sum d_i | m' = mean - sigma_0
+    double UA[OBJ_PER_WAVE * 48];      // Cholesky factor rows [4][36]; later the moment sums A[4][6][8] of the transform
+    double D[408];                     // centred propagated sigma points (see above); scratch of the update
+    double M[OBJ_PER_WAVE * 12];       // s = Wi sum d_i | m' = mean - sigma_0'
+    double Q[36];                      // process noise (read per covariance entry with a lane-dependent index)
     double Obs[OBJ_PER_WAVE * 12];
     double Met[OBJ_PER_WAVE * 4];
-    double Z[6];                       // six zeros: the "factor row" of the lanes that add nothing (sigma_0, truth, idle)
+    double Z[8];                       // six zeros: the "factor row" of the lanes that add nothing (sigma_0, truth, idle)
     int St[OBJ_PER_WAVE];
 };
+SSA_DEV int dbase(int g) { return g * 96 + (g & 1) * 4 + (g >> 1) * 16; }   // 0, 100, 208, 308
 
 // Wave-contiguous tile I/O: the 4 objects of a wavefront are consecutive, so P / x / x_true / obs are
 // single contiguous spans (1152 / 192 / 192 / 384 B) moved as 16-byte lanes -- whole cache lines per
@@ -399,20 +405,48 @@ SSA_DEV void observe_rows(Tiles& t, int g, int l)
     }
 }
 
+// U3 on the matrix unit.  With D^(g) the 12 x 8 matrix of object g's rows [d_i, 1, 0], the transform needs
+//   A^(g) = D^T D :  A[a][b] = sum_i d_i[a] d_i[b]  (a, b < 6)   and   A[a][6] = sum_i d_i[a]
+// -- 21 row reductions over the 16 lanes plus 6 more for the mean if done with DPP butterflies.  v_mfma_f64_4x4x4_4b_f64
+// multiplies four independent 4x4x4 blocks per instruction; its block index is lane bits 3:2, its k (operands) / i
+// (result) index lane bits 5:4, its i / j index lane bits 1:0 (measured, build_ablate/probe): block b = object b, three
+// k-chunks of four sigma points, 4x4 tiles (0,0), (0,1), (1,1) of the symmetric 8x8 result = 9 instructions of 16 cycles
+// on the otherwise idle matrix pipe, operands by six conflict-free ds_read_b64.  Lane (hi, mid, lo) ends up with
+// A^(mid)[hi][lo], A^(mid)[hi][4 + lo], A^(mid)[4 + hi][4 + lo] and stores them to t.UA.
+SSA_DEV void moment_sums_mfma(Tiles& t, int lane)
+{
+    const int hi = lane >> 4, mid = (lane >> 2) & 3, lo = lane & 3;
+    const double* src = &t.D[dbase(mid) + hi * 8 + lo];
+    double a0[3], a1[3];
+#pragma unroll
+    for (int kc = 0; kc < 3; ++kc) {
+        a0[kc] = src[kc * 32];
+        a1[kc] = src[kc * 32 + 4];
+    }
+    double c00 = 0.0, c01 = 0.0, c11 = 0.0;
+#pragma unroll
+    for (int kc = 0; kc < 3; ++kc) {
+        c00 = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[kc], a0[kc], c00, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[kc], a1[kc], c01, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[kc], a1[kc], c11, 0, 0, 0);
+    }
+    double* A = &t.UA[mid * 48];
+    A[hi * 8 + lo] = c00;
+    A[hi * 8 + 4 + lo] = c01;
+    if (hi < 2) A[(4 + hi) * 8 + 4 + lo] = c11;
+}
+
 // U3 (second half): P = sum Wc_i y_i y_i^T + Q with y_i = sigma_i' - x, expanded around sigma_0':
-//   P = Wi sum_{i>=1} d_i d_i^T - m' s^T - s m'^T + sum(Wc) m' m'^T + Q       (d_i, s, m' in LDS)
+//   P = Wi A - m' s^T - s m'^T + sum(Wc) m' m'^T + Q       (A from moment_sums_mfma; s, m' in t.M)
 SSA_DEV void covariance_rows(Tiles& t, const ssa_consts& C, int g, int l)
 {
     for (int idx = l; idx < 21; idx += 16) {
-        int a = 0, rem = idx;
-        while (rem >= 6 - a) { rem -= 6 - a; ++a; }
-        const int b = a + rem;
-        double acc = 0.0;
-#pragma unroll
-        for (int i = 1; i <= 12; ++i) acc = fma(t.D[(g * 13 + i) * 6 + a], t.D[(g * 13 + i) * 6 + b], acc);
+        const int a = (idx >= 6) + (idx >= 11) + (idx >= 15) + (idx >= 18) + (idx >= 20);   // row of the upper triangle
+        const int b = idx - (a * 6 - ((a * (a - 1)) >> 1)) + a;
+        const double acc = t.UA[g * 48 + a * 8 + b];
         const double sa_ = t.M[g * 12 + a], sb_ = t.M[g * 12 + b];
         const double ma = t.M[g * 12 + 6 + a], mb = t.M[g * 12 + 6 + b];
-        double Pab = C.Wi * acc - ma * sb_ - sa_ * mb + C.sum_wc * ma * mb + C.Q[a * 6 + b];
+        double Pab = C.Wi * acc - ma * sb_ - sa_ * mb + C.sum_wc * ma * mb + t.Q[a * 6 + b];
         t.P[g * 36 + a * 6 + b] = Pab;
         t.P[g * 36 + b * 6 + a] = Pab;
     }
@@ -507,7 +541,7 @@ SSA_DEV void chol_step(const double (&a)[6], double (&uc)[6], int lc, bool& ok)
 SSA_DEV bool chol_row_lds(Tiles& t, double scale, double jit, int g, int l)
 {
     const double* Pg = &t.P[g * 36];
-    double* Ug = &t.U[g * 36];
+    double* Ug = &t.UA[g * 36];
     const int lc = l < 6 ? l : 5;   // lanes 6..15 shadow column 5 (their stores are masked)
     // column lc of the UPPER triangle of scale*P + jit*I (scipy.linalg.cholesky reads the upper triangle only); the six
     // owning lanes see all 36 entries between them: scipy's check_finite
@@ -584,7 +618,7 @@ template <int PROP, int TILE>
 SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& p, int lane, int64_t obj, bool valid,
                           int64_t base, int cnt, TileRegs& pf, int64_t next_base, int next_cnt, int tile)
 {
-    const int g = lane >> 4, l = lane & 15;
+    int g = lane >> 4, l = lane & 15;
     // env of the object: no division for the single-env case, a 32-bit one otherwise (n_env * n_obj < 2^31)
     const int e = (valid && p.n_env > 1) ? (int)((uint32_t)obj / (uint32_t)p.n_obj) : 0;
     const int64_t j = valid ? obj - (int64_t)e * p.n_obj : 0;
@@ -602,7 +636,8 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
 
     if (TILE == 0) tile_issue(pf, p, lane, base, cnt);   // one tile per wavefront: plain load, no staging registers kept
     if (TILE != 2) tile_commit(t, pf, lane);            // TILE 1: requested one tile ago (or by the kernel prologue)
-    if (lane < 6) t.Z[lane] = 0.0;
+    if (lane < 8) t.Z[lane] = 0.0;
+    if (TILE != 2 && lane < 36) t.Q[lane] = C.Q[lane];   // (a rollout's later steps find it in place)
     wave_lds_sync();
     SSA_TR(1);
 
@@ -612,7 +647,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     // ---- U1/U2: sigma points
 #if defined(SSA_ABLATE) && (SSA_ABLATE & 2)
     const int rung = -1;
-    if (l < 6) for (int c = 0; c < 6; ++c) t.U[g * 36 + l * 6 + c] = 1e-3 * t.P[g * 36 + l * 6 + c];
+    if (l < 6) for (int c = 0; c < 6; ++c) t.UA[g * 36 + l * 6 + c] = 1e-3 * t.P[g * 36 + l * 6 + c];
 #else
     const int rung = robust_chol_row_lds(t, C.scale, g, l);
 #endif
@@ -629,7 +664,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         // inactive rows (failed / out-of-range objects) and lane 13 propagate the true state; sigma_0 and the idle lanes
         // add the zero row: the operands are chosen by ADDRESS (three 16-byte LDS reads each), not by value
         const double* base = use_filter ? &t.X[g * 6] : &t.T[g * 6];
-        const double* urow = (use_filter && is_pm) ? &t.U[g * 36 + krow * 6] : &t.Z[0];
+        const double* urow = (use_filter && is_pm) ? &t.UA[g * 36 + krow * 6] : &t.Z[0];
 #pragma unroll
         for (int c = 0; c < 6; ++c) s[c] = fma(sgn, urow[c], base[c]);
     }
@@ -670,6 +705,12 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         }
     }
     wave_lds_sync();   // every lane has consumed t.X / t.T / t.U
+    // The propagator is the register-pressure peak of the kernel.  Re-derive the lane coordinates behind it, so that the
+    // lane-derived LDS addresses of the stages that follow are formed there instead of being carried across it (the
+    // alternative the allocator picks for the RK4 instance is a spill).
+    asm volatile("" : "+v"(lane));
+    g = lane >> 4;
+    l = lane & 15;
     SSA_TR(3);
     // the next tile's inputs: in flight during the transform / covariance / observation / store of this one
     if (TILE == 1) tile_issue(pf, p, lane, next_base, next_cnt);
@@ -677,26 +718,40 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     // ---- U3: unscented transform, centred form of x = dot(Wm, sigmas_f):
     //   x = sigma_0' + m',   m' = (sum(Wm) - 1) sigma_0' + Wi sum_{i>=1} (sigma_i' - sigma_0')
     // (the reference's sum evaluated without the 1e8-fold cancellation of Wm0 ~ -2e8)
-    double xb[6];
-    bool nan_x = false;
+    {
+        typedef double v2d_t __attribute__((ext_vector_type(2)));
+        double d[6];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        const double s0 = row_bcast<0>(o[c]);
-        const double d = is_pm ? (o[c] - s0) : 0.0;
-        if (is_pm) t.D[(g * 13 + l) * 6 + c] = d;
-        const double ssum = C.Wi * row_allsum(d);
-        const double mp = C.sum_wm_m1 * s0 + ssum;
-        xb[c] = s0 + mp;
-        nan_x = nan_x || (xb[c] != xb[c]);
-        if (l == 0) {
-            t.M[g * 12 + c] = ssum;
-            t.M[g * 12 + 6 + c] = mp;
-            t.X[g * 6 + c] = xb[c];
+        for (int c = 0; c < 6; ++c) d[c] = o[c] - row_bcast<0>(o[c]);
+        if (is_pm) {          // row [d_i, 1, 0] of the operand matrix
+            v2d_t* dst = reinterpret_cast<v2d_t*>(&t.D[dbase(g) + (l - 1) * 8]);
+            dst[0] = v2d_t{d[0], d[1]};
+            dst[1] = v2d_t{d[2], d[3]};
+            dst[2] = v2d_t{d[4], d[5]};
+            dst[3] = v2d_t{1.0, 0.0};
+        } else if (l == 0 || l == 13) {   // sigma_0' (until the mean replaces it) | x_true[i]
+            v2d_t* dst = reinterpret_cast<v2d_t*>(l == 0 ? &t.X[g * 6] : &t.T[g * 6]);
+            dst[0] = v2d_t{o[0], o[1]};
+            dst[1] = v2d_t{o[2], o[3]};
+            dst[2] = v2d_t{o[4], o[5]};
         }
-        if (l == 13) t.T[g * 6 + c] = o[c];   // x_true[i]
     }
     wave_lds_sync();
+    moment_sums_mfma(t, lane);
+    wave_lds_sync();
     SSA_TR(4);
+    double xb_l = 0.0;   // lanes 0..5: component l of the prior mean
+    if (l < 6) {
+        const double s0 = t.X[g * 6 + l];
+        const double ssum = C.Wi * t.UA[g * 48 + l * 8 + 6];
+        const double mp = C.sum_wm_m1 * s0 + ssum;
+        xb_l = s0 + mp;
+        t.M[g * 12 + l] = ssum;
+        t.M[g * 12 + 6 + l] = mp;
+        t.X[g * 6 + l] = xb_l;
+    }
+    const bool nan_x = ((__ballot(l < 6 && xb_l != xb_l) >> (g * 16)) & 0xFFFFull) != 0;
+    wave_lds_sync();
 #if !(defined(SSA_ABLATE) && (SSA_ABLATE & 4))
     covariance_rows(t, C, g, l);
 #endif
@@ -725,7 +780,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     if (my_update) {
         const int tmod = (p.n_time > 0) ? tix % p.n_time : 0;   // row of `trans` / `z_noise` (episodes wrap)
         double* rec = p.upd ? p.upd + (int64_t)e * SSA_UPD_STRIDE : nullptr;
-        double* W = &t.D[g * 78];
+        double* W = &t.D[dbase(g)];
         bool taken = false, visible = false;
         // a filter that has failed (earlier, or in this step's predict) is skipped entirely (:293): no z_true, no record
         const bool attempted = (st_new == SSA_ST_OK);
@@ -733,15 +788,18 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
             const double* M = p.trans + (int64_t)tmod * 9;
             // sigma points handed to update(): the propagated ones or, with
             // SSA_FLAG_RESAMPLE, the set drawn from the prior at the end of predict (factor rows in t.U)
-            double sf[6];
+            double sf[6], xb[6];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) sf[c] = o[c];
+            for (int c = 0; c < 6; ++c) {
+                sf[c] = o[c];
+                xb[c] = t.X[g * 6 + c];   // the prior mean
+            }
             if (C.flags & SSA_FLAG_RESAMPLE) {
                 const int krow = is_pm ? (l - 1) % 6 : 0;
                 const double sgn = (l >= 1 && l <= 6) ? 1.0 : ((l >= 7 && l <= 12) ? -1.0 : 0.0);
 #pragma unroll
                 for (int c = 0; c < 6; ++c)
-                    if (l != 13) sf[c] = xb[c] + sgn * t.U[g * 36 + krow * 6 + c];
+                    if (l != 13) sf[c] = xb[c] + sgn * t.UA[g * 36 + krow * 6 + c];
             }
             // H1/H2: measurement of every sigma point (lanes 0-12) and of the true state (lane 13)
             double z[3];
@@ -1088,6 +1146,7 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) rollout_kernel(const RollK
             wave_lds_sync();   // the previous tile's last stores have read the tiles
             tile_issue(pf, p0, lane, base, cnt);
             tile_commit(t, pf, lane);
+            if (lane < 36) t.Q[lane] = k_arg.c.Q[lane];   // process_wave<.., 2> expects the process noise in place
         }
         unsigned wave_slot;   // the wavefront's slot on its SIMD (HW_ID bits 3:0)
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(wave_slot));
@@ -1463,55 +1522,150 @@ __global__ void aer_obs_kernel(const double* __restrict__ x, const double* __res
     for (int c = 0; c < 4; ++c) out[i * 4 + c] = (fabs(v[c]) <= 1.79769313486231570e308) ? v[c] : 0.001;
 }
 
-// agents.py score arrays + visibility in one pass (one lane per object)
+// agents.py score arrays + visibility (one lane per object).  sc[0..3] = trace P | log(det P_cur / det P_prev) | |dpos| | |dvel|;
+// WANT selects what is evaluated (bit k = row k, bit 4 = visibility) -- the two log-determinants are the expensive part.
+template <int WANT>
+SSA_DEV bool agent_score_rows(const double* __restrict__ xt, const double* __restrict__ x, const double* __restrict__ Pc,
+                              const double* __restrict__ Pp, const double* __restrict__ M, const GeoK& g, int64_t i, double* sc)
+{
+    double A[21], U[21];
+    if (WANT & 3) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = r; c < 6; ++c) A[tri(r, c)] = Pc[i * 36 + r * 6 + c];
+    }
+    if (WANT & 1) {
+        double tr = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) tr += A[tri(c, c)];
+        sc[0] = tr;
+    }
+    if (WANT & 2) {
+        // log det through the (plain) Cholesky factor: det > 0 for the covariances the filter keeps; anything
+        // else gives NaN, which the arg-max skips
+        double ld_c = __builtin_nan(""), ld_p = __builtin_nan("");
+        if (chol6_upper(A, 0.0, U)) {
+            ld_c = 0.0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) ld_c += 2.0 * log(U[tri(c, c)]);
+        }
+        if (Pp) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = r; c < 6; ++c) A[tri(r, c)] = Pp[i * 36 + r * 6 + c];
+            if (chol6_upper(A, 0.0, U)) {
+                ld_p = 0.0;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) ld_p += 2.0 * log(U[tri(c, c)]);
+            }
+        }
+        sc[1] = ld_c - ld_p;
+    }
+    if (WANT & 12) {
+        double d[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) d[c] = x[i * 6 + c] - xt[i * 6 + c];
+        sc[2] = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        sc[3] = sqrt(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+    }
+    bool vis = true;
+    if (WANT & 16) {
+        double Mm[9], xx[3] = {xt[i * 6], xt[i * 6 + 1], xt[i * 6 + 2]}, zz[3];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) Mm[c] = M[c];
+        hx_aer(xx, Mm, g.enu, g.obs, zz);
+        vis = zz[1] >= g.obs_limit;
+    }
+    return vis;
+}
 __global__ void agent_scores_kernel(const double* __restrict__ xt, const double* __restrict__ x, const double* __restrict__ Pc,
                                     const double* __restrict__ Pp, const double* __restrict__ M, GeoK g,
                                     double* __restrict__ scores, uint8_t* __restrict__ mask, int64_t n)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    double A[21], U[21];
-    double tr = 0.0;
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = r; c < 6; ++c) A[tri(r, c)] = Pc[i * 36 + r * 6 + c];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) tr += A[tri(c, c)];
-    // log det through the (plain) Cholesky factor: det > 0 for the covariances the filter keeps; anything
-    // else gives NaN, which ssa_masked_argmax_f64 skips
-    double ld_c = __builtin_nan(""), ld_p = __builtin_nan("");
-    if (chol6_upper(A, 0.0, U)) {
-        ld_c = 0.0;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) ld_c += 2.0 * log(U[tri(c, c)]);
+    double sc[4];
+    bool vis;
+    if (mask) vis = agent_score_rows<31>(xt, x, Pc, Pp, M, g, i, sc);
+    else vis = agent_score_rows<15>(xt, x, Pc, Pp, M, g, i, sc);
+    scores[i] = sc[0];
+    scores[n + i] = sc[1];
+    scores[2 * n + i] = sc[2];
+    scores[3 * n + i] = sc[3];
+    if (mask) mask[i] = vis ? 1 : 0;
+}
+
+// ---- closed loop on the device: the reference's heuristic agents (agents.py:7-81) choose the next action
+// from the state the step just wrote; here that choice never leaves the GPU.  agent_partial_kernel scores one object per
+// lane and reduces each block to its first maximum; agent_final_kernel folds the blocks of an env and writes the action
+// word the NEXT ssa_env_step_f64 reads (a fallback action when nothing is visible: the reference samples at random).
+struct AgentPart { double best; long long arg; };
+SSA_DEV void agent_merge(double& b, long long& a, double b2, long long a2)
+{
+    const bool take = a2 >= 0 && (a < 0 || b2 > b || (b2 == b && a2 < a));
+    if (take) { b = b2; a = a2; }
+}
+constexpr int AGENT_T = 256;
+template <int KIND>
+__global__ void __launch_bounds__(AGENT_T) agent_partial_kernel(const double* __restrict__ xt, const double* __restrict__ x,
+                                                                const double* __restrict__ Pc, const double* __restrict__ Pp,
+                                                                const double* __restrict__ trans, const int32_t* __restrict__ env_time,
+                                                                int32_t time_offset, int32_t n_time, GeoK g,
+                                                                AgentPart* __restrict__ parts, int64_t n)
+{
+    const int e = blockIdx.y, t = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * AGENT_T + t;
+    double best = 0.0;
+    long long arg = -1;
+    if (i < n) {
+        const int64_t obj = (int64_t)e * n + i;
+        const int tix = env_time[e] + time_offset;
+        const double* M = trans + (int64_t)((n_time > 0) ? tix % n_time : 0) * 9;
+        double sc[4];
+        constexpr int ROW = (KIND == SSA_AGENT_SHANNON) ? 1 : (KIND == SSA_AGENT_POS_ERROR) ? 2 : (KIND == SSA_AGENT_VEL_ERROR) ? 3 : 0;
+        constexpr int WANT = (ROW == 0 ? 1 : ROW == 1 ? 2 : 12) | (KIND == SSA_AGENT_NAIVE_GREEDY ? 0 : 16);
+        const bool vis = agent_score_rows<WANT>(xt, x, Pc, Pp, M, g, obj, sc);
+        const double v = sc[ROW];
+        if (vis && v == v) { best = v; arg = i; }
     }
-    if (Pp) {
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = r; c < 6; ++c) A[tri(r, c)] = Pp[i * 36 + r * 6 + c];
-        if (chol6_upper(A, 0.0, U)) {
-            ld_p = 0.0;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) ld_p += 2.0 * log(U[tri(c, c)]);
-        }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double b2 = __shfl_down(best, off, 64);
+        const long long a2 = __shfl_down(arg, off, 64);
+        agent_merge(best, arg, b2, a2);
     }
-    double d[6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) d[c] = x[i * 6 + c] - xt[i * 6 + c];
-    scores[i] = tr;
-    scores[n + i] = ld_c - ld_p;
-    scores[2 * n + i] = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-    scores[3 * n + i] = sqrt(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
-    if (mask) {
-        double Mm[9], xx[3] = {xt[i * 6], xt[i * 6 + 1], xt[i * 6 + 2]}, zz[3];
-#pragma unroll
-        for (int c = 0; c < 9; ++c) Mm[c] = M[c];
-        hx_aer(xx, Mm, g.enu, g.obs, zz);
-        mask[i] = zz[1] >= g.obs_limit ? 1 : 0;
+    __shared__ AgentPart part[AGENT_T / 64];
+    if ((t & 63) == 0) { part[t >> 6].best = best; part[t >> 6].arg = arg; }
+    __syncthreads();
+    if (t == 0) {
+        for (int w = 1; w < AGENT_T / 64; ++w) agent_merge(best, arg, part[w].best, part[w].arg);
+        AgentPart r;
+        r.best = best; r.arg = arg;
+        parts[(int64_t)e * gridDim.x + blockIdx.x] = r;
     }
 }
+__global__ void __launch_bounds__(64) agent_final_kernel(const AgentPart* __restrict__ parts, int nparts,
+                                                         const int32_t* __restrict__ fallback, int32_t* __restrict__ action_out,
+                                                         int64_t* __restrict__ pick_out)
+{
+    const int e = blockIdx.x, t = threadIdx.x;
+    double best = 0.0;
+    long long arg = -1;
+    for (int i = t; i < nparts; i += 64) agent_merge(best, arg, parts[(int64_t)e * nparts + i].best, parts[(int64_t)e * nparts + i].arg);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double b2 = __shfl_down(best, off, 64);
+        const long long a2 = __shfl_down(arg, off, 64);
+        agent_merge(best, arg, b2, a2);
+    }
+    if (t == 0) {
+        action_out[e] = (arg >= 0) ? (int32_t)arg : (fallback ? fallback[e] : -1);
+        if (pick_out) { pick_out[2 * e] = arg; pick_out[2 * e + 1] = __double_as_longlong(best); }
+    }
+}
+
 // first maximum of score over mask (single block; 8 loads in flight per thread)
 __global__ void __launch_bounds__(1024) masked_argmax_kernel(const double* __restrict__ score, const uint8_t* __restrict__ mask,
                                                              int64_t n, int64_t* __restrict__ out)
@@ -1839,6 +1993,38 @@ int ssa_agent_scores_f64(const double* x_true, const double* x_cur, const double
     if (!x_true || !x_cur || !P_cur || !scores || !c || n < 0 || (mask && !M)) return SSA_E_INVALID;
     hipLaunchKernelGGL(agent_scores_kernel, dim3(nblk(n, 64)), dim3(64), 0, (hipStream_t)stream, x_true, x_cur, P_cur, P_prev, M,
                        make_geo(c), scores, mask, n);
+    return launch_status();
+}
+
+int64_t ssa_agent_select_workspace_bytes(int64_t n_obj, int32_t n_env)
+{
+    if (n_obj <= 0 || n_env <= 0) return 0;
+    return (int64_t)n_env * ((n_obj + AGENT_T - 1) / AGENT_T) * (int64_t)sizeof(AgentPart);
+}
+int ssa_agent_select_f64(const ssa_consts* c, int32_t kind, const double* x_true, const double* x_cur, const double* P_cur,
+                         const double* P_prev, const double* trans, const int32_t* env_time, int32_t time_offset, int32_t n_time,
+                         const int32_t* fallback, void* workspace, int32_t* action_out, int64_t* pick_out, int64_t n_obj,
+                         int32_t n_env, void* stream)
+{
+    if (!c || !x_true || !x_cur || !P_cur || !trans || !env_time || !workspace || !action_out || n_obj <= 0 || n_env <= 0)
+        return SSA_E_INVALID;
+    const int nparts = (int)((n_obj + AGENT_T - 1) / AGENT_T);
+    const dim3 grid(nparts, n_env), block(AGENT_T);
+    hipStream_t s = (hipStream_t)stream;
+    AgentPart* parts = (AgentPart*)workspace;
+    const GeoK g = make_geo(c);
+#define SSA_AGENT_LAUNCH(K) hipLaunchKernelGGL(agent_partial_kernel<K>, grid, block, 0, s, x_true, x_cur, P_cur, P_prev, trans, env_time, \
+                                               time_offset, n_time, g, parts, n_obj)
+    switch (kind) {
+        case SSA_AGENT_NAIVE_GREEDY: SSA_AGENT_LAUNCH(SSA_AGENT_NAIVE_GREEDY); break;
+        case SSA_AGENT_VISIBLE_GREEDY: SSA_AGENT_LAUNCH(SSA_AGENT_VISIBLE_GREEDY); break;
+        case SSA_AGENT_SHANNON: SSA_AGENT_LAUNCH(SSA_AGENT_SHANNON); break;
+        case SSA_AGENT_POS_ERROR: SSA_AGENT_LAUNCH(SSA_AGENT_POS_ERROR); break;
+        case SSA_AGENT_VEL_ERROR: SSA_AGENT_LAUNCH(SSA_AGENT_VEL_ERROR); break;
+        default: return SSA_E_INVALID;
+    }
+#undef SSA_AGENT_LAUNCH
+    hipLaunchKernelGGL(agent_final_kernel, dim3(n_env), dim3(64), 0, s, (const AgentPart*)parts, nparts, fallback, action_out, pick_out);
     return launch_status();
 }
 

@@ -439,6 +439,25 @@ SSA_DEV bool kepler_fg_fast(const double* x, double tof, double* out)
     const bool hyp = sane && hyper && (ecc2 > 1.01 * 1.01);
     const bool band = sane && !ell && !hyp && (ecc2 >= 0.99 * 0.99) && (ecc2 <= 1.01 * 1.01);
     bool ok = false;
+#ifdef SSA_HYP_INLINE
+    // diverged (hyperbolic) filter states are common late in an episode (a quarter of the predict-only filters by step
+    // 300): their solver runs inline under a whole-wave branch -- no call, no register save / restore through scratch;
+    // only the rare near-parabolic band (universal variables) stays out of line
+    if (__any(band)) {
+        if (band) {
+            Vec6 xi;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) xi.v[i] = x[i];
+            Vec7 o = kepler_nonelliptic_v<TAG>(xi, tof, r0, alpha, rv, 1);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) out[i] = o.v[i];
+            ok = o.v[6] != 0.0;
+        }
+    }
+    if (__any(hyp)) {
+        if (hyp) ok = kepler_fg_core<true>(x, tof, r0, inv_r0, alpha, rv, out);
+    }
+#else
     if (__any(!ell)) {   // whole-wave branch: the call is skipped when every lane is strong-elliptic
         if (hyp || band) {
             Vec6 xi;
@@ -450,6 +469,7 @@ SSA_DEV bool kepler_fg_fast(const double* x, double tof, double* out)
             ok = o.v[6] != 0.0;
         }
     }
+#endif
     if (ell) ok = kepler_fg_core<false>(x, tof, r0, inv_r0, alpha, rv, out);
     return ok;
 }

@@ -194,6 +194,23 @@ class HotPathEngine:
         if rc:
             raise _lib.SsaHipError("ssa_env_rollout_f64 failed with code %d" % rc)
 
+    def launch_agent_select(self, slot_cur, time_offset, kind, action_ptr, fallback_ptr=0, pick_ptr=0, stream=None, have_prev=True):
+        """enqueue the device-side agent (include/ssa_hip.h: ssa_agent_select_f64): choose, for every env, the action of
+        the NEXT step from history slot `slot_cur` (and the slot before it for the Shannon agent) and store it in the
+        int32 word(s) at `action_ptr` -- the pointer the next launch_step() is given as actions_ptr.  No host sync."""
+        if getattr(self, "_agent_ws", None) is None:
+            nb = self._lib.ssa_agent_select_workspace_bytes(self.m, self.E)
+            self._agent_ws = torch.empty(max(int(nb), 16), dtype=torch.uint8, device=self.dev)
+        s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        sc = int(slot_cur) % self.H
+        sp = (sc + self.H - 1) % self.H
+        rc = self._lib.ssa_agent_select_f64(self._cref, int(kind), self._bx_t + sc * self._sx, self._bx + sc * self._sx,
+                                            self._bP + sc * self._sP, (self._bP + sp * self._sP) if have_prev else 0, self.trans.data_ptr(),
+                                            self.env_time0.data_ptr(), int(time_offset), self.n_time, fallback_ptr,
+                                            self._agent_ws.data_ptr(), action_ptr, pick_ptr, self.m, self.E, s)
+        if rc:
+            raise _lib.SsaHipError("ssa_agent_select_f64 failed with code %d" % rc)
+
     def profile_ms(self, slot):
         """duration [ms] of the dominant kernel of the step launched with profile_slot=slot (waits for it)."""
         ms = C.c_float(0.0)

@@ -427,6 +427,79 @@ class SSA_Tasker_Env(Env):
             obs = e.obs[slot].cpu().numpy()
         return obs, np.asarray(rewards), np.asarray(dones, dtype=bool), {}
 
+    AGENT_KINDS = {'agent_naive_greedy': _lib.AGENT_NAIVE_GREEDY, 'agent_visible_greedy': _lib.AGENT_VISIBLE_GREEDY,
+                   'agent_visible_greedy_aer': _lib.AGENT_VISIBLE_GREEDY, 'agent_shannon': _lib.AGENT_SHANNON,
+                   'agent_pos_error_greedy': _lib.AGENT_POS_ERROR, 'agent_vel_error_greedy': _lib.AGENT_VEL_ERROR}
+
+    def run_agent(self, agent, n_steps, fallback_actions=None):
+        """Closed loop on the device (no reference counterpart as ONE call): the loop
+            a = agent(obs, env); obs, r, done, _ = env.step(a)
+        of the reference's drivers (run_environment.py, compare_agents.py) for one of its greedy agents (agents.py: `agent`
+        is the function or its name), with the agent's arg-max computed on the GPU and handed to the next step's launch
+        in-stream -- no host round trip per step.  `fallback_actions[k]` replaces the reference's action_space.sample()
+        when no object is visible at decision k (default: draws from the env's action space, as the reference does).
+        Stops at the first `done`.  Returns (observation after the last executed step, actions[k], rewards[k], dones[k]).
+        Rewards 'jones' and 'trinary' (as rollout())."""
+        import torch
+        name = agent if isinstance(agent, str) else getattr(agent, "__name__", None)
+        if name not in self.AGENT_KINDS:
+            raise NotImplementedError("run_agent: %r has no device-side version (supported: %s)" % (agent, sorted(self.AGENT_KINDS)))
+        if self.reward_type == 'shaped':
+            raise NotImplementedError("run_agent: reward_type 'shaped' needs argmax(sigma_pos) per step; use step()")
+        kind = self.AGENT_KINDS[name]
+        e = self._engine
+        K = min(int(n_steps), self.n - 1 - self.i)
+        if fallback_actions is None:
+            fallback_actions = [self.action_space.sample() for _ in range(K + 1)]
+        fb = torch.as_tensor(np.asarray(fallback_actions, dtype=np.int32)[:K + 1]).to(e.dev)
+        assert fb.numel() >= K, "one fallback action per decision"
+        log = torch.full((K + 1,), -1, dtype=torch.int32, device=e.dev)     # log[k] = action of step i0 + k + 1
+        actions, rewards, dones = [], [], []
+        pos, done = 0, False
+        e.launch_agent_select(self.i, self.i, kind, log.data_ptr(), fallback_ptr=fb.data_ptr(), have_prev=self.i >= 1)
+        while pos < K and not done:
+            kk = min(K - pos, e.H - 1)
+            i0 = self.i
+            for k in range(kk):
+                i = i0 + k + 1
+                e.launch_step((i - 1) % e.H, i % e.H, i, actions_ptr=log.data_ptr() + 4 * (pos + k), fast_stats=True, defer_fold=True)
+                if pos + k + 1 < K:     # (the decision for the step after this one)
+                    e.launch_agent_select(i, i, kind, log.data_ptr() + 4 * (pos + k + 1), fallback_ptr=fb.data_ptr() + 4 * (pos + k + 1))
+            e.flush_stats()
+            slots = [(i0 + 1 + k) % e.H for k in range(kk)]
+            stats = e.stats[slots, 0].cpu().numpy()          # synchronises the stream
+            upd = e.upd[slots, 0].cpu().numpy()
+            acts = log[pos:pos + kk].cpu().numpy()
+            for k in range(kk):
+                self.i += 1
+                i, a = self.i, int(acts[k])
+                self.actions[i] = a
+                self._book_update(i, a, upd[k])
+                self._stats = stats[k]
+                if int(stats[k][_lib.STAT_N_FAILED]) != self._n_failed:
+                    self._record_failures(at_step=i)
+                done = self._reward_done(i, a, stats[k], -1) or (i + 1 >= self.n)
+                r = self.rewards[i]
+                actions.append(a)
+                rewards.append(r if (self.obs_returned == 'flatten' or np.isfinite(r)) else np.float64(0.5))
+                dones.append(done)
+                if done:
+                    break
+            pos += kk
+        self._argmax_sigma = -1
+        slot = self.i % e.H
+        if self.obs_returned == 'aer':
+            from .. import device
+            M = e.trans[self.i % e.n_time].reshape(3, 3)
+            device.aer_obs(e.x_filter[slot], e.P_filter[slot], M, self._consts, out=self._aer_dev.view(self.m, 4))
+            self.observation[:] = self._aer_dev.cpu().numpy()
+            obs = self.observation
+        elif self.obs_returned == 'flatten':
+            obs = e.obs[slot].cpu().numpy().reshape(-1)
+        else:
+            obs = e.obs[slot].cpu().numpy()
+        return obs, np.asarray(actions, dtype=int), np.asarray(rewards), np.asarray(dones, dtype=bool)
+
     # ------------------------------------------------------------------ failures (:369-382)
     def _record_failures(self, at_step=None):
         """filter_error() bookkeeping (:369-382) for the filters that failed in step self.i.  Inside a rollout launch

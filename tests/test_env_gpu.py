@@ -360,3 +360,54 @@ def test_failed_action_leaves_no_update_record_and_rollout_dates_failures(envs):
     env.rollout([0, 1, 2, 0, 1, 2])
     assert env.failed_filters_id == [3, 4]
     assert ' step %d' % (i0 + 1) in env.failed_filters_msg[4][0], env.failed_filters_msg[4]
+
+
+@pytest.mark.parametrize("agent_name,lim", [("agent_visible_greedy", 10.0), ("agent_shannon", 10.0), ("agent_pos_error_greedy", 5.0),
+                                            ("agent_vel_error_greedy", 5.0), ("agent_naive_greedy", -90.0), ("agent_visible_greedy", 89.9)])
+@pytest.mark.parametrize("hist", ['full', 2])
+def test_closed_loop_on_device_equals_host_loop(envs, agent_name, lim, hist):
+    """SURVEY 8f-1 / agents.py:7-81: env.run_agent() -- the agent's arg-max chained into the next step's launch on the
+    device -- against the host loop `a = agent(obs, env); env.step(a)` of the reference's drivers (here with
+    ssa_gym_amd.agents, whose scores come from the same device arithmetic): identical action sequence, bit-identical
+    states, same rewards.  obs_limit 89.9 deg: nothing is ever visible -> every decision is the fallback draw."""
+    from ssa_gym_amd import agents
+    cfg = dict(envs.env_config)
+    cfg.update(rso_count=37, steps=40, reward_type='trinary', obs_returned='flatten', seed=11, obs_limit=lim, history=hist)
+    K = 25
+    rs = np.random.RandomState(5)
+    fallback = rs.randint(0, 37, size=K + 1)
+    host = envs.make(config=cfg)
+    dev = envs.make(config=cfg)
+    agent = getattr(agents, agent_name)
+
+    class _Fixed:            # the reference's random fallback, replayed identically on both sides
+        def __init__(self, seq):
+            self.seq, self.k = list(seq), 0
+
+        def sample(self):
+            return int(self.seq[self.k])
+    acts, rews = [], []
+    for k in range(K):
+        space = host.action_space
+        host.action_space = type("S", (), {"sample": lambda self_, k=k: int(fallback[k]), "contains": space.contains, "n": space.n})()
+        a = int(agent(None, host))
+        host.action_space = space
+        _, r, d, _ = host.step(a)
+        acts.append(a)
+        rews.append(r)
+    obs, dacts, drews, ddones = dev.run_agent(agent_name, K, fallback_actions=fallback)
+    assert list(dacts) == acts, (list(dacts), acts)
+    np.testing.assert_array_equal(drews, np.array(rews))
+    assert dev.i == host.i == K and not ddones.any()
+    assert np.array_equal(dev.x_filter[K], host.x_filter[K]) and np.array_equal(dev.P_filter[K], host.P_filter[K])
+    assert np.array_equal(dev.x_true[K], host.x_true[K]) and np.array_equal(obs, host.obs[K].reshape(-1))
+    if lim > 89:
+        assert acts == [int(v) for v in fallback[:K]]
+    elif agent_name != "agent_naive_greedy":
+        assert len(set(acts)) > 3                      # the agent really moves between objects
+    # the update bookkeeping of the device loop equals the host loop's
+    assert np.array_equal(dev.obs_taken[1:K + 1], host.obs_taken[1:K + 1])
+    # and the env keeps stepping normally afterwards
+    o1, r1, _, _ = dev.step(3)
+    o2, r2, _, _ = host.step(3)
+    assert np.array_equal(o1, o2) and r1 == r2
