@@ -19,6 +19,8 @@ open(p,'w').write(s)
 p=w+'/ssa-gym_amd/csrc/ssa_math.hpp'; m=open(p).read()
 a="if (__any(!ell)) {   // whole-wave branch"
 assert a in m; m=m.replace(a,"if (false) {   // whole-wave branch")
+a="if (__any(!handled)) {   // whole-wave branch"
+if a in m: m=m.replace(a,"if (false) {")
 open(p,'w').write(m)
 PY
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=fast -mllvm -disable-machine-licm -gline-tables-only -S --cuda-device-only ${EXTRA} -o $W/hot.s $W/ssa-gym_amd/csrc/ssa_kernels.hip 2>/dev/null

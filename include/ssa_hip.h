@@ -281,6 +281,13 @@ int ssa_agent_select_f64(const ssa_consts *c_host, int32_t kind, const double *x
                          int32_t *action_out, int64_t *pick_out, int64_t n_obj, int32_t n_env, void *stream);
 int64_t ssa_agent_select_workspace_bytes(int64_t n_obj, int32_t n_env);
 
+/* ------------------------------------------------ consistency diagnostics
+ * NEES  nees[k] = d^T inv(P[k]) d, d = x_true[k] - x[k]   for n (step, object) pairs  (anees(), ssa_tasker_simple_2.py:436-446;
+ *       fitness_test() :764-768) -- LU with partial pivoting per lane, NaN where P is singular;
+ * NIS   nis[k] = y[k]^T inv(S[k]) y[k]                     (fitness_test() :750-754). */
+int ssa_nees_f64(const double *x_true, const double *x, const double *P, double *nees, int64_t n, void *stream);
+int ssa_nis_f64(const double *y, const double *S, double *nis, int64_t n, void *stream);
+
 /* library identification */
 int ssa_abi_version(void);
 const char *ssa_build_info(void);

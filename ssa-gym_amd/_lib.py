@@ -85,6 +85,8 @@ SIGNATURES = {
     "ssa_agent_select_f64": (C.c_int, [C.POINTER(ssa_consts), C.c_int32, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int32, C.c_int32,
                                        c_dp, c_dp, c_dp, c_dp, C.c_int64, C.c_int32, c_dp]),
     "ssa_agent_select_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
+    "ssa_nees_f64": (C.c_int, [c_dp, c_dp, c_dp, c_dp, C.c_int64, c_dp]),
+    "ssa_nis_f64": (C.c_int, [c_dp, c_dp, c_dp, C.c_int64, c_dp]),
 }
 
 _lib = None

@@ -1708,6 +1708,74 @@ __global__ void __launch_bounds__(1024) masked_argmax_kernel(const double* __res
     }
 }
 
+// ---- diagnostic reductions of SURVEY 8f-4 (ssa_tasker_simple_2.py:436-446, 750-775): NEES = d^T inv(P) d with
+// d = x_true - x_filter, NIS = y^T inv(S) y.  One lane per (step, object): Gaussian elimination with partial pivoting on
+// the augmented system [P | d] (the arithmetic class of numpy.linalg.inv's LU), then the dot product.
+__global__ void nees_kernel(const double* __restrict__ xt, const double* __restrict__ x, const double* __restrict__ P,
+                            double* __restrict__ out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double A[6][7], d[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        d[r] = xt[i * 6 + r] - x[i * 6 + r];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) A[r][c] = P[i * 36 + r * 6 + c];
+        A[r][6] = d[r];
+    }
+    bool singular = false;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        // pivot: the largest |A[r][k]|, r >= k, swapped into row k with compile-time indices (registers, no scratch)
+#pragma unroll
+        for (int r = k + 1; r < 6; ++r) {
+            const bool sw = fabs(A[r][k]) > fabs(A[k][k]);
+#pragma unroll
+            for (int c = k; c < 7; ++c) {
+                const double a = A[k][c], b = A[r][c];
+                A[k][c] = sw ? b : a;
+                A[r][c] = sw ? a : b;
+            }
+        }
+        singular = singular || (A[k][k] == 0.0);
+        const double inv = 1.0 / A[k][k];
+#pragma unroll
+        for (int r = k + 1; r < 6; ++r) {
+            const double f = A[r][k] * inv;
+#pragma unroll
+            for (int c = k + 1; c < 7; ++c) A[r][c] = fma(-f, A[k][c], A[r][c]);
+        }
+    }
+    double z[6];
+#pragma unroll
+    for (int r = 5; r >= 0; --r) {
+        double acc = A[r][6];
+#pragma unroll
+        for (int c = r + 1; c < 6; ++c) acc = fma(-A[r][c], z[c], acc);
+        z[r] = acc / A[r][r];
+    }
+    double q = 0.0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) q = fma(d[r], z[r], q);
+    out[i] = singular ? __builtin_nan("") : q;   // numpy raises LinAlgError('Singular matrix') there
+}
+__global__ void nis_kernel(const double* __restrict__ y, const double* __restrict__ S, double* __restrict__ out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s[9], si[9], yy[3];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) s[c] = S[i * 9 + c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) yy[c] = y[i * 3 + c];
+    if (!inv3(s, si)) { out[i] = __builtin_nan(""); return; }
+    double q = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) q += yy[a] * (si[a * 3] * yy[0] + si[a * 3 + 1] * yy[1] + si[a * 3 + 2] * yy[2]);
+    out[i] = q;
+}
+
 static GeoK make_geo(const ssa_consts* c)
 {
     GeoK g;
@@ -1993,6 +2061,21 @@ int ssa_agent_scores_f64(const double* x_true, const double* x_cur, const double
     if (!x_true || !x_cur || !P_cur || !scores || !c || n < 0 || (mask && !M)) return SSA_E_INVALID;
     hipLaunchKernelGGL(agent_scores_kernel, dim3(nblk(n, 64)), dim3(64), 0, (hipStream_t)stream, x_true, x_cur, P_cur, P_prev, M,
                        make_geo(c), scores, mask, n);
+    return launch_status();
+}
+
+int ssa_nees_f64(const double* x_true, const double* x, const double* P, double* nees, int64_t n, void* stream)
+{
+    if (n == 0) return SSA_OK;
+    if (!x_true || !x || !P || !nees || n < 0) return SSA_E_INVALID;
+    hipLaunchKernelGGL(nees_kernel, dim3(nblk(n, 64)), dim3(64), 0, (hipStream_t)stream, x_true, x, P, nees, n);
+    return launch_status();
+}
+int ssa_nis_f64(const double* y, const double* S, double* nis, int64_t n, void* stream)
+{
+    if (n == 0) return SSA_OK;
+    if (!y || !S || !nis || n < 0) return SSA_E_INVALID;
+    hipLaunchKernelGGL(nis_kernel, dim3(nblk(n, 64)), dim3(64), 0, (hipStream_t)stream, y, S, nis, n);
     return launch_status();
 }
 

@@ -196,3 +196,21 @@ def env_step(consts, params):
     """E1: the fused step.  `params` is a filled _lib.ssa_step_params."""
     lib = _lib.load()
     _lib.check(lib.ssa_env_step_f64(C.byref(consts), C.byref(params), _stream()), "ssa_env_step_f64")
+
+
+def nees(x_true, x, P):
+    """d^T inv(P) d for every row (anees() / fitness_test() of the reference)."""
+    lib = _lib.load()
+    n = x.shape[0]
+    out = torch.empty(n, dtype=f64, device=x.device)
+    _lib.check(lib.ssa_nees_f64(_chk(x_true, "x_true"), _chk(x, "x"), _chk(P, "P"), _chk(out, "nees"), n, _stream()), "ssa_nees_f64")
+    return out
+
+
+def nis(y, S):
+    """y^T inv(S) y for every row (fitness_test() of the reference)."""
+    lib = _lib.load()
+    n = y.shape[0]
+    out = torch.empty(n, dtype=f64, device=y.device)
+    _lib.check(lib.ssa_nis_f64(_chk(y, "y"), _chk(S, "S"), _chk(out, "nis"), n, _stream()), "ssa_nis_f64")
+    return out

@@ -527,6 +527,30 @@ class SSA_Tasker_Env(Env):
         self._n_failed = len(self.failed_filters_id)
         self.runtime['filter_error'] += time.time() - s
 
+    def anees(self):
+        """:436-446 -- average normalised estimation error squared over the episode so far: NEES on the device for every
+        resident (step, object) of the history (the reference loops n * m numpy inversions); fills self.nees (n, m)."""
+        from .. import device
+        s = time.time()
+        e = self._engine
+        self.nees = np.full((self.n, self.m), np.nan)
+        lo = max(0, self.i - e.H + 1)
+        for i in range(lo, self.i + 1):
+            sl = i % e.H
+            self.nees[i] = device.nees(e.x_true[sl], e.x_filter[sl], e.P_filter[sl]).cpu().numpy()
+        self.runtime['anees'] += time.time() - s
+        return float(np.mean(self.nees[lo:self.i + 1]))
+
+    def nis(self):
+        """normalised innovation squared of every update taken so far (fitness_test(), :750-754); NaN where no update ran"""
+        import torch
+        from .. import device
+        out = np.full(self.n, np.nan)
+        k = np.where(self.obs_taken[:self.i + 1])[0]
+        if len(k):
+            out[k] = device.nis(torch.as_tensor(self._y[k]).to("cuda"), torch.as_tensor(self._S_sel[k]).to("cuda")).cpu().numpy()
+        return out
+
     def failed_filters(self):
         if not self.failed_filters_id:
             print("No failed Objects")

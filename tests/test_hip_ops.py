@@ -262,3 +262,30 @@ def test_reward_stats_vs_numpy(hip):
     met[0, 2, 40] = np.nan
     stats = hip.dev.reward_stats(hip.up(met), hip.up(np.zeros(100, np.int32), hip.torch.int32), 100, 1).cpu().numpy()
     assert np.isnan(stats[0, 0]) and stats[0, 3] == 40
+
+
+def test_nees_nis_vs_numpy(hip):
+    """NEES = d^T inv(P) d and NIS = y^T inv(S) y against the reference's own expression
+    `delta @ np.linalg.inv(P) @ delta` (ssa_tasker_simple_2.py:443, :751-753) evaluated with numpy.  Tolerance:
+    cond(P) ~ 1e6..1e12 for these covariances, so two LU evaluations agree to ~cond * eps relative (1e-6 asserted on the
+    posterior-like covariances, 1e-10 on the diagonal initial ones)."""
+    g = golden("ukf_step_golden.npz")
+    rs = np.random.RandomState(3)
+    n = 64
+    P = np.concatenate([np.tile(g["P0"], (n, 1, 1)), 0.5 * (g["Pu_a3"][:n] + np.swapaxes(g["Pu_a3"][:n], 1, 2))])
+    xt = np.tile(g["x_true"][:n], (2, 1))
+    d = np.concatenate([rs.normal(size=(n, 6)) * np.sqrt(np.diag(g["P0"])), rs.normal(size=(n, 6)) * np.array([30.0] * 3 + [0.05] * 3)])
+    x = xt - d
+    got = hip.dev.nees(hip.dev.as_dev(xt), hip.dev.as_dev(x), hip.dev.as_dev(P)).cpu().numpy()
+    dd = xt - x
+    ref = np.array([dd[k] @ np.linalg.inv(P[k]) @ dd[k] for k in range(2 * n)])
+    np.testing.assert_allclose(got[:n], ref[:n], rtol=1e-10)
+    np.testing.assert_allclose(got[n:], ref[n:], rtol=1e-6)
+    assert 2.0 < np.mean(got[:n]) < 12.0                      # chi-square with 6 degrees of freedom: mean 6
+    Ps = P.copy()
+    Ps[3] = 0.0                                               # singular -> numpy raises LinAlgError; here NaN
+    assert np.isnan(hip.dev.nees(hip.dev.as_dev(xt), hip.dev.as_dev(x), hip.dev.as_dev(Ps)).cpu().numpy()[3])
+    S = g["S_a3"][:n] if "S_a3" in g.files else np.tile(np.diag([2e-11, 2e-11, 1e6]), (n, 1, 1))
+    y = rs.normal(size=(n, 3)) * np.sqrt(np.einsum('kii->ki', S))
+    nis = hip.dev.nis(hip.dev.as_dev(y), hip.dev.as_dev(S)).cpu().numpy()
+    np.testing.assert_allclose(nis, [y[k] @ np.linalg.inv(S[k]) @ y[k] for k in range(n)], rtol=1e-9)
