@@ -9,7 +9,13 @@ pb=bench.build_problem(m, seed=100)
 res={}
 for path in sorted(glob.glob(os.path.join(ROOT,'build_ablate','*.so'))):
     _lib._lib=None; _build.LIB=path
+    sig=dict(_lib.SIGNATURES)
+    import ctypes
+    probe=ctypes.CDLL(path)
+    _lib.SIGNATURES={k:v for k,v in sig.items() if hasattr(probe,k)}   # older ablation builds lack the newest entry points
+    _lib.ABI_VERSION=probe.ssa_abi_version()
     lib=_lib.load()
+    _lib.SIGNATURES=sig
     for prop in os.environ.get('PROPS','fg,elements').split(','):
         consts=host.make_consts(pb["Q"], pb["R"], 1e-4, 2.0, -3, 20.0, -np.pi/2, pb["obs_lla"], obs_type='aer', propagator=prop)
         z=torch.zeros((1,480,m,3),dtype=torch.float64,device='cuda')

@@ -133,11 +133,11 @@ typedef struct ssa_step_params {
     int32_t *work;             /* unused since ABI 12 (the exception queue is gone); may be NULL */
     void *stat_ws;             /* ssa_reward_stats_workspace_bytes(): per-block statistics partials */
     uint64_t *stat_shards;     /* [E][SSA_STAT_SHARDS][4] zero-initialised device words, or NULL.  When given the
-                                  step kernel accumulates max delta_pos / trinary
-                                  counts / failures itself with sharded atomics; a one-wave fold kernel -- or, with
-                                  aer_out, the post kernel's first wavefront -- writes `stats` and clears the words: two
-                                  launches per step instead of three.  arg-max sigma_pos (only the 'shaped' reward needs
-                                  it) is then NOT computed: stats[SSA_STAT_ARGMAX_SPOS] = -1, stats[SSA_STAT_MAX_SPOS] = NaN. */
+                                  step kernel accumulates max delta_pos / trinary counts / failures itself with sharded
+                                  atomics (and writes aer_out, if asked, in its epilogue); a one-wave fold kernel writes
+                                  `stats` and clears the words: two launches per step instead of three.  arg-max
+                                  sigma_pos (only the 'shaped' reward needs it) is then NOT computed:
+                                  stats[SSA_STAT_ARGMAX_SPOS] = -1, stats[SSA_STAT_MAX_SPOS] = NaN. */
     uint64_t *stat_shards_prev;/* deferred fold (with SSA_LAUNCH_DEFER_FOLD in launch_mask): the shard set the PREVIOUS step
                                   accumulated into, or NULL.  The step kernel then carries n_env extra wavefronts that fold
                                   it into stats_prev and clear it while the objects of THIS step are being advanced, and
@@ -145,8 +145,9 @@ typedef struct ssa_step_params {
                                   the next step passes them here or ssa_stats_fold_f64() folds them.  Alternate two sets. */
     double *stats_prev;        /* [E][SSA_STAT_STRIDE] destination of that fold */
     double *aer_out;           /* [E*m][4] aer_obs() of the NEW state (O4: az, el, range, trace P; NaN/inf -> 0.001;
-                                  ssa_tasker_simple_2.py:834-840), may be NULL.  Written by the post kernel, so the
-                                  'aer' observation / the sharded all-gather payload costs no extra launch. */
+                                  ssa_tasker_simple_2.py:834-840), may be NULL.  With stat_shards it is written by the step
+                                  kernel's epilogue from the on-chip tiles (no extra launch, no second pass over x / P);
+                                  without, by the post kernel: the 'aer' observation / the sharded all-gather payload. */
 } ssa_step_params;
 
 /* ---------------------------------------------------------------- fused hot path
@@ -154,8 +155,8 @@ typedef struct ssa_step_params {
  * the step kernel advances 4 objects per wavefront with complete semantics (robust_cholesky's jitter ladder inline,
  * conic branches beyond the strong-elliptic one as out-of-line calls), the update and -- with stat_shards -- the
  * reward statistics included.  Launches per step:
- *   stat_shards given : step kernel + a one-wave fold; or + the post kernel when aer_out asks for the O4 payload
- *       (it folds as well); or nothing more with SSA_LAUNCH_DEFER_FOLD (the next step's launch folds): 2 / 2 / 1;
+ *   stat_shards given : step kernel (aer_out, if asked, in its epilogue) + a one-wave fold; nothing more with
+ *       SSA_LAUNCH_DEFER_FOLD (the next step's launch folds): 2 / 1;
  *   stat_shards NULL  : step kernel + post kernel (exact statistics per block, arg-max sigma_pos included, and the
  *       payload) + a one-wave fold of those: 3 launches. */
 int ssa_env_step_f64(const ssa_consts *c_host, const ssa_step_params *p_host, void *stream);

@@ -962,6 +962,12 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     if (l == 0) t.St[g] = st_new;
     wave_lds_sync();
     observe_rows(t, g, l);
+    // O4 in the epilogue (atomics-statistics path): the (az, el, range, trace P) block of the NEW state -- the 'aer'
+    // observation mode and the multi-GPU all-gather payload -- from the tiles, so that no second pass over x / P (the
+    // former post kernel: 6.7 MB re-read per 20 000 objects plus a launch) is needed
+    if (p.aer_out && p.stat_shards) {
+        if (l == 0 && valid) aer_obs_row(&t.X[g * 6], &t.P[g * 36], p, C, e, obj);
+    }
     wave_lds_sync();
     SSA_TR(7);
     {
@@ -1219,10 +1225,7 @@ __global__ void __launch_bounds__(POST_T) step_post_kernel(const StepK k, StatAc
             aer_obs_row(p.x_out + obj * 6, p.P_out + obj * 36, p, C, e, obj);
         }
     }
-    if (p.stat_shards) {
-        // statistics were accumulated by the common-path kernel (complete before this launch): fold them here
-        if (blockIdx.x == 0 && w == 0) fold_stat_shards((unsigned long long*)p.stat_shards, p.stats, e, lane);
-    } else if (p.stats) {
+    if (p.stats) {
         const double* dpos = p.metrics + ((int64_t)e * 4 + 0) * m;
         const double* spos = p.metrics + ((int64_t)e * 4 + 2) * m;
         const int32_t* st = p.status + (int64_t)e * m;
@@ -1839,7 +1842,7 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
     const int64_t per_wave = (ntiles + slots - 1) / slots;
     const int nwork = (int)((ntiles + per_wave - 1) / per_wave);
     const bool fast_stats = p->stat_shards != nullptr;   // statistics by the common-path kernel's atomics
-    const bool defer = fast_stats && !p->aer_out && (p->launch_mask & SSA_LAUNCH_DEFER_FOLD);
+    const bool defer = fast_stats && (p->launch_mask & SSA_LAUNCH_DEFER_FOLD);
     if (defer && p->stat_shards_prev && (!p->stats_prev || p->stat_shards_prev == p->stat_shards)) return SSA_E_INVALID;
     const int nfold = (defer && p->stat_shards_prev) ? p->n_env : 0;
     dim3 grid((unsigned)(nwork + nfold)), block(64);
@@ -1862,7 +1865,8 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
             else hipExtLaunchKernelGGL((step_fast_kernel<2, true>), grid, block, 0, s, ev0, ev1, 0, k, nt, nwork);
         }
     }
-    if (fast_stats && !p->aer_out) {   // no payload: a one-wave fold finishes the step (2 launches), unless deferred (1 launch)
+    if (fast_stats) {   // (the aer_out payload, if any, was the step kernel's epilogue) a one-wave fold finishes the step
+                        // (2 launches), unless deferred (1 launch)
         if ((mask & 6u) && !defer)
             hipLaunchKernelGGL(reward_fold_kernel, dim3(p->n_env), dim3(64), 0, s, (unsigned long long*)p->stat_shards, p->stats);
         return launch_status();
@@ -1872,7 +1876,6 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
         else if (prop == SSA_PROP_ELEMENTS) hipLaunchKernelGGL(step_post_kernel<0>, dim3(nparts, p->n_env), dim3(POST_T), 0, s, k, parts, nparts);
         else hipLaunchKernelGGL(step_post_kernel<2>, dim3(nparts, p->n_env), dim3(POST_T), 0, s, k, parts, nparts);
     }
-    if (fast_stats) return launch_status();   // payload + fold were the post kernel's job (2 launches)
     // folds the per-block statistics
     if ((mask & 4u) && p->stats)
         hipLaunchKernelGGL(reward_final_kernel, dim3(p->n_env), dim3(64), 0, s, (const StatAcc*)parts, p->stats, nparts);

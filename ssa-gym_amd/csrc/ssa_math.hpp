@@ -427,8 +427,8 @@ __device__ __noinline__ Vec7 kepler_nonelliptic_v(Vec6 x, double tof, double r0,
 //     F(chi) = r0 chi + sigma0 chi^2 c2 + (1 - r0 alpha) chi^3 c3 - sqrt(mu) tof = 0,     sigma0 = r.v / sqrt(mu)
 // is the same expression for the strong-elliptic, the strong-hyperbolic and the near-parabolic branch of farnocchia()
 // (farnocchia.py:871-919, 946-1004 switch between E, F and D there), F' = r > 0, F'' = (1 - r0 alpha) chi (1 - z c3) +
-// sigma0 (1 - z c2).  For the steps of the env (tens of seconds: |z| is the squared eccentric-anomaly increment, < 0.2)
-// c2, c3 are 8-term series, the starter inverts the cubic truncation of F (relative error ~ z^(3/2)) and ONE Halley
+// sigma0 (1 - z c2).  For the steps of the env (tens of seconds: |z| is the squared eccentric-anomaly increment, << 1)
+// c2, c3 are 8-term series (a lane whose |z| leaves the series' range, 0.5, is handed to the branch-wise solvers), the starter inverts the cubic truncation of F (relative error ~ z^(3/2)) and ONE Halley
 // step lands within 1e-15 of the root; the loop runs a second one only where the first correction exceeded 1e-6.  Against
 // the 80-bit oracle: 1.3e-15 relative on the catalogue at dt = 20 .. 150 s, 2e-15 on hyperbolic and near-parabolic
 // states (the reference's own fp64 chain: 2.7e-14).  Because ellipses and hyperbolas share ONE instruction stream, a
@@ -469,7 +469,10 @@ SSA_DEV bool kepler_uv_fast(const double* x, double tof, double* out, bool& hand
     const double t1 = T * inv_r0, a2 = 0.5 * sig * inv_r0, a3 = k3 * inv_r0 * (1.0 / 6.0);
     double chi = t1 * (1.0 - t1 * (a2 - (2.0 * a2 * a2 - a3) * t1));
     // series domain (NaN / inf / r0 = 0 compare false)
-    const bool small = (fabs(alpha) * t1 * t1 < 0.2) && (fabs(a2 * t1) < 0.25) && (r0 > 0.0) && (fabs(chi) <= 1.79769313486231570e308);
+    // domain: the estimated |z| below 4 and a modest second-order term (NaN / inf / r0 = 0 compare false).  Beyond it are
+    // long steps and filter states that have collapsed towards the Earth's centre (0.1 % of the sigma points of a late
+    // episode): the branch-wise solvers take those.
+    const bool small = (fabs(alpha) * t1 * t1 < 4.0) && (fabs(a2 * t1) < 1.0) && (r0 > 0.0) && (fabs(chi) <= 1.79769313486231570e308);
     bool done = !small;
     double c2, c3, chi2, z;
 #pragma unroll 1
@@ -487,7 +490,7 @@ SSA_DEV bool kepler_uv_fast(const double* x, double tof, double* out, bool& hand
         const double d = -F * rad * y;              // Halley
         if (!done) {
             chi += d;
-            done = fabs(d) <= 1e-6 * fabs(chi);
+            done = (fabs(d) <= 1e-6 * fabs(chi)) || !(fabs(z) < 0.5);   // (beyond the series: not handled, see below)
         }
         if (__all(done)) break;
     }
@@ -506,7 +509,7 @@ SSA_DEV bool kepler_uv_fast(const double* x, double tof, double* out, bool& hand
     out[3] = fd * r[0] + gd * v[0];
     out[4] = fd * r[1] + gd * v[1];
     out[5] = fd * r[2] + gd * v[2];
-    handled = small && done && (fabs(z) < 0.5) && (rad > 0.0);
+    handled = small && done && (fabs(z) < 0.5) && (rad > 0.0) && (fabs(out[0]) <= 1.79769313486231570e308);
     return handled;
 }
 

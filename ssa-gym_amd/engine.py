@@ -149,7 +149,7 @@ class HotPathEngine:
         p.aer_out = aer_out
         # two-launch path (no arg-max of sigma_pos): see include/ssa_hip.h ssa_step_params.stat_shards
         s = torch.cuda.current_stream().cuda_stream if stream is None else stream
-        defer = bool(defer_fold and fast_stats and not aer_out)
+        defer = bool(defer_fold and fast_stats)
         if not defer and self._fold_pending is not None:
             self.flush_stats(s)       # a deferred step is followed by an immediate one: fold it first (same stream, in order)
         p.stat_shards = self._shard_sets[self._shard_cur].data_ptr() if fast_stats else 0

@@ -213,13 +213,13 @@ class HipLocalStepper:
         if self._sched is not None:
             k = (self.tick - 1 - self._sched_k0) % self._sched.numel()
             e.launch_step((self.tick - 1) % e.H, self.tick % e.H, self.tick, actions_ptr=self._sched.data_ptr() + 4 * k,
-                          aer_out=aer, stats_out=st, fast_stats=self.fast_stats, defer_fold=self.defer_fold,
+                          aer_out=aer, stats_out=st, fast_stats=self.fast_stats, defer_fold=self.defer_fold and stats_out is None,
                           profile_slot=profile_slot)
             return
         self._act[0] = int(local_action)
         e.actions.copy_(self._act)
         e.launch_step((self.tick - 1) % e.H, self.tick % e.H, self.tick, aer_out=aer, stats_out=st, fast_stats=self.fast_stats,
-                      defer_fold=self.defer_fold, profile_slot=profile_slot)
+                      defer_fold=self.defer_fold and stats_out is None, profile_slot=profile_slot)
 
     def rollout(self, n_steps):
         """advance n_steps of the pre-staged schedule in ONE launch (open-loop actions; HotPathEngine.launch_rollout)."""
