@@ -473,7 +473,7 @@ SSA_DEV bool kepler_uv_fast(const double* x, double tof, double* out, bool& hand
     // long steps and filter states that have collapsed towards the Earth's centre (0.1 % of the sigma points of a late
     // episode): the branch-wise solvers take those.
     const bool small = (fabs(alpha) * t1 * t1 < 4.0) && (fabs(a2 * t1) < 1.0) && (r0 > 0.0) && (fabs(chi) <= 1.79769313486231570e308);
-    bool done = !small;
+    bool live = small, conv = false;     // live: inside the series' range so far; conv: last correction below 1e-6
     double c2, c3, chi2, z;
 #pragma unroll 1
     for (int it = 0; it < 6; ++it) {
@@ -488,11 +488,12 @@ SSA_DEV bool kepler_uv_fast(const double* x, double tof, double* out, bool& hand
         double y = __builtin_amdgcn_rcp(den);
         y = y * fma(-den, y, 2.0);
         const double d = -F * rad * y;              // Halley
-        if (!done) {
+        live = live && (fabs(z) < 0.5);       // a lane whose |z| leaves the series' range stops here and is not handled
+        if (live && !conv) {
             chi += d;
-            done = (fabs(d) <= 1e-6 * fabs(chi)) || !(fabs(z) < 0.5);   // (beyond the series: not handled, see below)
+            conv = fabs(d) <= 1e-6 * fabs(chi);
         }
-        if (__all(done)) break;
+        if (__all(conv || !live)) break;
     }
     chi2 = chi * chi;
     z = alpha * chi2;
@@ -509,7 +510,7 @@ SSA_DEV bool kepler_uv_fast(const double* x, double tof, double* out, bool& hand
     out[3] = fd * r[0] + gd * v[0];
     out[4] = fd * r[1] + gd * v[1];
     out[5] = fd * r[2] + gd * v[2];
-    handled = small && done && (fabs(z) < 0.5) && (rad > 0.0) && (fabs(out[0]) <= 1.79769313486231570e308);
+    handled = live && conv && (fabs(z) < 0.5) && (rad > 0.0) && (fabs(out[0]) <= 1.79769313486231570e308);
     return handled;
 }
 
