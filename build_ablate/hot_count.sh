@@ -17,8 +17,6 @@ a="    if (C.flags & SSA_FLAG_RESAMPLE) {\n        const int rg"
 assert a in s; s=s.replace(a,"    if (false) {\n        const int rg")
 open(p,'w').write(s)
 p=w+'/ssa-gym_amd/csrc/ssa_math.hpp'; m=open(p).read()
-a="if (__any(!ell)) {   // whole-wave branch"
-assert a in m; m=m.replace(a,"if (false) {   // whole-wave branch")
 a="if (__any(!handled)) {   // whole-wave branch"
 if a in m: m=m.replace(a,"if (false) {")
 open(p,'w').write(m)

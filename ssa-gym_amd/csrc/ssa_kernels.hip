@@ -239,16 +239,6 @@ __device__ static void kepler_general_impl(const double* x, double tof, double* 
     }
 }
 
-template <int TAG>
-__device__ __noinline__ Vec7 kepler_nonelliptic_v(Vec6 x, double tof, double r0, double alpha, double rv, int band)
-{
-    Vec7 o;
-    bool ok;
-    if (band) ok = kepler_universal(x.v, tof, r0, alpha, rv, o.v);
-    else ok = kepler_fg_core<true>(x.v, tof, r0, 1.0 / r0, alpha, rv, o.v);
-    o.v[6] = ok ? 1.0 : 0.0;
-    return o;
-}
 __device__ __noinline__ Vec6 kepler_general_v(Vec6 x, double tof)
 {
     Vec6 o;
