@@ -52,6 +52,10 @@ for lab, sel in (("waves started < 1 us", early), ("waves started >= 1 us", ~ear
     print("%s: n=%d  lifetime %.2f us" % (lab, sel.sum(), life[sel].mean()))
     for k, nme in enumerate(names):
         print("    %-8s %6.2f us (p90 %6.2f)" % (nme, d[:, k].mean(), np.percentile(d[:, k], 90)))
+slow = np.argsort(life)[-8:]
+print("slowest waves (lifetime, per-stage us):")
+for w_ in slow:
+    print("   %.2f  " % life[w_], (np.diff(t[w_]) / 1e3).round(2))
 hw = tr[:, 15] & 0xffffffff
 xcc = (tr[:, 15] >> 32) & 0xf
 simd = (hw >> 4) & 3

@@ -338,7 +338,7 @@ SSA_DEV bool kepler_uv_fast(const double* x, double tof, double* out, bool& hand
 //     dchi = -5 F / (F' + sign(F') sqrt(|16 F'^2 - 20 F F''|)),
 // which converge from any starting point on this monotone F without bracketing (2-4 iterations on the reference's
 // catalogue up to one-day steps, <= 7 on 99.98 % of the diverged sigma points of a late episode; the 80-bit oracle and a
-// DOP853 integration agree with it to 3e-13 at dt = 86 400 s).  Twelve iterations without convergence is the analogue of
+// DOP853 integration agree with it to 3e-13 at dt = 86 400 s).  Sixteen iterations without convergence is the analogue of
 // newton() giving up (farnocchia.py:353): the caller sees NaN and the filter is marked failed.
 SSA_DEV bool kepler_uv_general(const double* x, double tof, double* out)
 {
@@ -351,12 +351,22 @@ SSA_DEV bool kepler_uv_general(const double* x, double tof, double* out)
     const double sig = rv * inv_sqrt_mu, T = sqrt_mu * tof;
     const double k3 = 1.0 - r0 * alpha;
     const double t1 = T * inv_r0;
-    double chi = (alpha > 0.0 && alpha * t1 * t1 > 1.0) ? T * alpha : t1;   // long elliptic steps: the mean-motion guess
+    // starter: first order for short steps; the mean-motion guess for long elliptic steps; for strongly hyperbolic steps
+    // (|z| > 1: F grows exponentially in chi) the logarithmic guess of the universal-variable literature (Vallado,
+    // algorithm 8) -- from chi = T / r0 the iteration would walk down the exponential for dozens of steps
+    const double z1 = alpha * t1 * t1;
+    double chi = t1;
+    if (z1 > 1.0) chi = T * alpha;
+    else if (z1 < -1.0) {
+        const double sa = sqrt(-alpha);
+        const double h = log((-2.0 * alpha * T) / (sig + k3 / sa)) / sa;
+        if (h > 0.0 && h <= 1.79769313486231570e308) chi = h;
+    }
     const bool sane = (r0 > 0.0) && (fabs(alpha) <= 1.79769313486231570e308) && (fabs(chi) <= 1.79769313486231570e308);
     bool conv = false;
     double c2, c3, chi2, z;
 #pragma unroll 1
-    for (int it = 0; it < 12; ++it) {
+    for (int it = 0; it < 16; ++it) {
         chi2 = chi * chi;
         z = alpha * chi2;
         stumpff(z, c2, c3);
