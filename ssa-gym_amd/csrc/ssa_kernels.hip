@@ -564,6 +564,10 @@ __constant__ double JITTER[16] = {1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1.0, 10.0,
 SSA_DEV int robust_chol_row_lds(Tiles& t, double scale, int g, int l)
 {
     if (chol_row_lds(t, scale, 0.0, g, l)) return -1;
+    // a wavefront that has to climb the ladder (up to 16 more factorisations) would finish long after its SIMD
+    // neighbours and hold the end of the launch: it takes issue priority for the rest of its life (the step kernels with
+    // several tiles / steps per wavefront re-set their priority at the next tile / step)
+    __builtin_amdgcn_s_setprio(3);
     bool finite = true;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {

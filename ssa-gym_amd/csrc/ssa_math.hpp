@@ -21,24 +21,21 @@ constexpr double NEWTON_TOL = 1.48e-08;   // farnocchia.py:337
 
 SSA_DEV double dot3(const double* a, const double* b) { return fma(a[2], b[2], fma(a[1], b[1], a[0] * b[0])); }
 
-// 1/v and 1/sqrt(v) to double precision (<= ~1 ulp) from the hardware estimates (v_rcp_f64 /
-// v_rsq_f64, ~2^-26) plus two Newton steps: 5 VALU instructions instead of the 10-15 of the IEEE
-// division / square-root sequences.  For finite, non-denormal positive-magnitude arguments.
+// 1/v and 1/sqrt(v) to double precision (<= ~1 ulp) from the hardware estimates (v_rcp_f64 / v_rsq_f64, relative
+// error e ~ 2^-26) plus ONE third-order correction -- 1/v = y (1 + e + e^2), 1/sqrt(v) = y (1 + e/2 + 3 e^2/8), residual
+// e^3 ~ 2^-78 -- 3 / 5 VALU instructions instead of the 10-15 of the IEEE division / square-root sequences (and 1 / 3
+// fewer than two Newton steps).  For finite, non-denormal positive-magnitude arguments.
 SSA_DEV double rcp_nr(double v)
 {
-    double y = __builtin_amdgcn_rcp(v);
-    double e = fma(-v, y, 1.0);
-    y = fma(y, e, y);
-    e = fma(-v, y, 1.0);
-    return fma(y, e, y);
+    const double y = __builtin_amdgcn_rcp(v);
+    const double e = fma(-v, y, 1.0);
+    return fma(y, fma(e, e, e), y);
 }
 SSA_DEV double rsqrt_nr(double v)
 {
-    double y = __builtin_amdgcn_rsq(v);
-    double e = fma(-v * y, y, 1.0);
-    y = fma(0.5 * y, e, y);
-    e = fma(-v * y, y, 1.0);
-    return fma(0.5 * y, e, y);
+    const double y = __builtin_amdgcn_rsq(v);
+    const double e = fma(-v * y, y, 1.0);
+    return fma(y, e * fma(0.375, e, 0.5), y);
 }
 
 // Python / numpy `a % (2 pi)` (result in [0, 2 pi)); exact remainder via one FMA.
@@ -409,6 +406,7 @@ SSA_DEV bool kepler_fg_fast(const double* x, double tof, double* out)
     bool handled;
     bool ok = kepler_uv_fast(x, tof, out, handled);
     if (__any(!handled)) {   // whole-wave branch
+        __builtin_amdgcn_s_setprio(3);   // a straggler in the making (see robust_chol_row_lds): issue priority from here on
         if (!handled) ok = kepler_uv_general(x, tof, out);
     }
     return ok;
