@@ -11,8 +11,6 @@ w=sys.argv[1]
 p=w+'/ssa-gym_amd/csrc/ssa_kernels.hip'; s=open(p).read()
 a="const bool my_update = valid && act >= 0 && (int64_t)act == j && interval_ok;"
 assert a in s; s=s.replace(a,"const bool my_update = false;")
-a="const int rung = robust_chol_row_lds(t, C.scale, g, l);\n#endif"
-assert a in s; s=s.replace(a,"const int rung = chol_row_lds(t, C.scale, 0.0, g, l) ? -1 : 16;\n#endif")
 a="    if (C.flags & SSA_FLAG_RESAMPLE) {\n        const int rg"
 assert a in s; s=s.replace(a,"    if (false) {\n        const int rg")
 open(p,'w').write(s)

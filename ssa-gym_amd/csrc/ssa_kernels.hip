@@ -528,14 +528,13 @@ SSA_DEV void chol_step(const double (&a)[6], double (&uc)[6], int lc, bool& ok)
     ok = ok && (y > 0.0) && (y <= 1.79769313486231570e308);
     uc[J] = (lc >= J) ? v * y : 0.0;              // lane J: ajj / sqrt(ajj) = the diagonal entry
 }
-SSA_DEV bool chol_row_lds(Tiles& t, double scale, double jit, int g, int l)
+// factorises the matrix at Pg (row-major 6x6 in LDS) in the calling row `grow`; the factor's column lc stays in uc[]
+SSA_DEV bool chol_row_regs(const double* Pg, double scale, double jit, int grow, int l, double (&uc)[6])
 {
-    const double* Pg = &t.P[g * 36];
-    double* Ug = &t.UA[g * 36];
     const int lc = l < 6 ? l : 5;   // lanes 6..15 shadow column 5 (their stores are masked)
     // column lc of the UPPER triangle of scale*P + jit*I (scipy.linalg.cholesky reads the upper triangle only); the six
     // owning lanes see all 36 entries between them: scipy's check_finite
-    double a[6], uc[6];
+    double a[6];
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -543,42 +542,72 @@ SSA_DEV bool chol_row_lds(Tiles& t, double scale, double jit, int g, int l)
         ok = ok && (fabs(pv) <= 1.79769313486231570e308);
         a[j] = scale * pv + ((lc == j) ? jit : 0.0);
     }
-    ok = ((__ballot(!ok) >> (g * 16)) & 0xFFFFull) == 0;
+    ok = ((__ballot(!ok) >> (grow * 16)) & 0xFFFFull) == 0;
     chol_step<0>(a, uc, lc, ok);
     chol_step<1>(a, uc, lc, ok);
     chol_step<2>(a, uc, lc, ok);
     chol_step<3>(a, uc, lc, ok);
     chol_step<4>(a, uc, lc, ok);
     chol_step<5>(a, uc, lc, ok);
+    return ok;
+}
+SSA_DEV void chol_store_rows(double* Ug, const double (&uc)[6], int l)
+{
     if (l < 6) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) Ug[j * 6 + l] = uc[j];
     }
-    wave_lds_sync();
-    return ok;
 }
 
-// robust_cholesky (dynamics.py:402-417) for the row's object: plain attempt, then a + 10^i I for
-// i = -6..9 (first success wins); returns -1, 0..15, or 16 (LinAlgError).  Row-level operations only.
+// robust_cholesky (dynamics.py:402-417) for the four objects of the wavefront: plain attempt, then a + 10^i I for
+// i = -6..9 (first success wins); returns the calling row's -1, 0..15, or 16 (LinAlgError).
+// The plain attempt runs row-parallel (each row its own object).  Rows that fail are then served ONE AT A TIME BY THE
+// WHOLE WAVEFRONT: the four rows try four consecutive rungs of that object's ladder at once and the lowest successful
+// one wins -- the same answer as the reference's sequential ladder in a quarter of the factorisations (a diverged
+// filter late in an episode needs rung 10-15: without this its wavefront ran 11-16 factorisations back to back and held
+// the end of the launch, build_ablate/wave_timeline.py).
 __constant__ double JITTER[16] = {1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1.0, 10.0, 100.0, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9};
 SSA_DEV int robust_chol_row_lds(Tiles& t, double scale, int g, int l)
 {
-    if (chol_row_lds(t, scale, 0.0, g, l)) return -1;
-    // a wavefront that has to climb the ladder (up to 16 more factorisations) would finish long after its SIMD
-    // neighbours and hold the end of the launch: it takes issue priority for the rest of its life (the step kernels with
-    // several tiles / steps per wavefront re-set their priority at the next tile / step)
-    __builtin_amdgcn_s_setprio(3);
-    bool finite = true;
+    double uc[6];
+    int rung = 16;
+    {
+        const bool ok = chol_row_regs(&t.P[g * 36], scale, 0.0, g, l, uc);
+        if (ok) {
+            chol_store_rows(&t.UA[g * 36], uc, l);
+            rung = -1;
+        }
+        const unsigned long long bad = __ballot(!ok);
+        wave_lds_sync();
+        if (bad == 0ull) return rung;                  // the common case, wave-uniform
+        __builtin_amdgcn_s_setprio(3);                 // a straggler in the making: issue priority for the rest of its life
+        for (int gf = 0; gf < OBJ_PER_WAVE; ++gf) {    // wave-uniform loop over the rows that failed
+            if (((bad >> (gf * 16)) & 1ull) == 0ull) continue;
+            const double* Pg = &t.P[gf * 36];
+            bool finite = true;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        int idx = l + 16 * r;
-        if (idx < 36) finite = finite && (fabs(t.P[g * 36 + idx]) <= 1.79769313486231570e308);
+            for (int r = 0; r < 3; ++r) {
+                const int idx = l + 16 * r;
+                if (idx < 36) finite = finite && (fabs(Pg[idx]) <= 1.79769313486231570e308);
+            }
+            int found = 16;
+            if (__ballot(!finite) == 0ull) {
+                for (int pass = 0; pass < 4; ++pass) {
+                    const bool okr = chol_row_regs(Pg, scale, JITTER[pass * 4 + g], g, l, uc);   // row g tries rung 4 pass + g
+                    const unsigned long long won = __ballot(okr);
+                    if (won != 0ull) {
+                        const int win = (won & 0xFFFFull) ? 0 : ((won >> 16) & 0xFFFFull) ? 1 : ((won >> 32) & 0xFFFFull) ? 2 : 3;
+                        found = pass * 4 + win;
+                        if (g == win) chol_store_rows(&t.UA[gf * 36], uc, l);
+                        break;
+                    }
+                }
+            }
+            if (g == gf) rung = found;
+            wave_lds_sync();
+        }
     }
-    finite = ((__ballot(!finite) >> (g * 16)) & 0xFFFFull) == 0;
-    if (!finite) return 16;
-    for (int r = 0; r < 16; ++r)
-        if (chol_row_lds(t, scale, JITTER[r], g, l)) return r;
-    return 16;
+    return rung;
 }
 
 // O4 for one object (ssa_tasker_simple_2.py:834-840): [hx(x_filter[:3]), trace(P)], NaN/inf -> 0.001
