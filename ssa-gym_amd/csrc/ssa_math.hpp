@@ -208,9 +208,11 @@ SSA_DEV void sinh_coshm1(double x, double& sh, double& chm1)
              (1.0 + x2 * (1.0 / 110.0) * (1.0 + x2 * (1.0 / 156.0) * (1.0 + x2 * (1.0 / 210.0))))))));
         chm1 = x2 * 0.5 * (1.0 + x2 * (1.0 / 12.0) * (1.0 + x2 * (1.0 / 30.0) * (1.0 + x2 * (1.0 / 56.0) * (1.0 + x2 * (1.0 / 90.0) *
                (1.0 + x2 * (1.0 / 132.0) * (1.0 + x2 * (1.0 / 182.0) * (1.0 + x2 * (1.0 / 240.0))))))));
-    } else {
-        sh = sinh(x);
-        chm1 = cosh(x) - 1.0;
+    } else {   // one exponential instead of two libm calls: no cancellation for |x| >= 0.5 (cosh x - 1 >= 0.127)
+        const double ex = exp(fabs(x)), ie = rcp_nr(ex);
+        const double shp = 0.5 * (ex - ie);
+        sh = (x < 0.0) ? -shp : shp;
+        chm1 = 0.5 * (ex + ie) - 1.0;
     }
 }
 
@@ -224,15 +226,17 @@ SSA_DEV void stumpff(double z, double& c2, double& c3)
         c3 = 1.0 / 6.0 - z * (1.0 / 120.0 - z * (1.0 / 5040.0 - z * (1.0 / 362880.0 - z * (1.0 / 39916800.0 - z * (1.0 / 6227020800.0 -
              z * (1.0 / 1307674368000.0 - z * (1.0 / 355687428096000.0)))))));
     } else if (z > 0.0) {
-        double sz = sqrt(z), sn, cs;
+        const double isz = rsqrt_nr(z), sz = z * isz, iz = isz * isz;
+        double sn, cs;
         sincos(sz, &sn, &cs);
-        c2 = (1.0 - cs) / z;
-        c3 = (sz - sn) / (sz * z);
+        c2 = (1.0 - cs) * iz;
+        c3 = (sz - sn) * (isz * iz);
     } else {
-        double sz = sqrt(-z), sh, chm1;
+        const double isz = rsqrt_nr(-z), sz = -z * isz, iz = isz * isz;
+        double sh, chm1;
         sinh_coshm1(sz, sh, chm1);
-        c2 = chm1 / (-z);
-        c3 = (sh - sz) / (sz * (-z));
+        c2 = chm1 * iz;
+        c3 = (sh - sz) * (isz * iz);
     }
 }
 
