@@ -79,6 +79,9 @@ class HotPathEngine:
         self.stat_shards = self._shard_sets[0]
         self._shard_cur = 0
         self._fold_pending = None      # (shard set index, stats destination) of a step whose fold was deferred
+        self._shard_ptr = [self._shard_sets[0].data_ptr(), self._shard_sets[1].data_ptr()]
+        self._actions_ptr = self.actions.data_ptr()
+        self._pcache = {}
         self._cref = C.byref(self.consts)
         self._pref = C.byref(self._p)
         # element strides of one history slot
@@ -131,43 +134,58 @@ class HotPathEngine:
         self.status.zero_()
 
     # ------------------------------------------------------------------ one step
+    def _step_params(self, slot_in, slot_out, aer_out, stats_out, upd_out, shard_set):
+        """parameter block of a step between two history slots: everything but the time index, the action pointer and the
+        deferred-fold hand-over is fixed per (slot pair, outputs, shard set), so the blocks are built once and cached -- a
+        step then costs a handful of field stores on the host instead of twenty"""
+        key = (slot_in, slot_out, aer_out, stats_out, upd_out, shard_set)
+        ent = self._pcache.get(key)
+        if ent is None:
+            p = _lib.ssa_step_params()
+            C.memmove(C.byref(p), C.byref(self._p), C.sizeof(p))
+            p.x_true_in, p.x_true_out = self._bx_t + slot_in * self._sx, self._bx_t + slot_out * self._sx
+            p.x_in, p.x_out = self._bx + slot_in * self._sx, self._bx + slot_out * self._sx
+            p.P_in, p.P_out = self._bP + slot_in * self._sP, self._bP + slot_out * self._sP
+            p.obs = self._bo + slot_out * self._so
+            p.metrics = self._bm + slot_out * self._sm
+            p.upd = upd_out if upd_out else self._bu + slot_out * self._su
+            p.stats = stats_out if stats_out else self._bs + slot_out * self._ss   # e.g. straight into a send buffer
+            p.aer_out = aer_out
+            p.stat_shards = self._shard_sets[shard_set].data_ptr() if shard_set >= 0 else 0
+            p.stat_shards_prev, p.stats_prev, p.launch_mask = 0, 0, 0
+            ent = (p, C.byref(p), int(p.stats))
+            if len(self._pcache) > 4096:
+                self._pcache.clear()
+            self._pcache[key] = ent
+        return ent
+
     def launch_step(self, slot_in, slot_out, time_offset, actions_ptr=None, stream=None, aer_out=0, stats_out=0, upd_out=0,
                     fast_stats=False, defer_fold=False, profile_slot=None):
         """enqueue the step; asynchronous, no host sync.  fast_stats: statistics by the step kernel's atomics (two
-        launches, no arg-max of sigma_pos).  defer_fold (with fast_stats, no payload): ONE launch -- this step's
+        launches, no arg-max of sigma_pos).  defer_fold (with fast_stats): ONE launch -- this step's
         statistics are folded by extra wavefronts of the NEXT deferred step, or by flush_stats()."""
-        p = self._p
-        p.time_offset = int(time_offset)
-        p.x_true_in, p.x_true_out = self._bx_t + slot_in * self._sx, self._bx_t + slot_out * self._sx
-        p.x_in, p.x_out = self._bx + slot_in * self._sx, self._bx + slot_out * self._sx
-        p.P_in, p.P_out = self._bP + slot_in * self._sP, self._bP + slot_out * self._sP
-        p.obs = self._bo + slot_out * self._so
-        p.metrics = self._bm + slot_out * self._sm
-        p.upd = upd_out if upd_out else self._bu + slot_out * self._su
-        p.actions = self.actions.data_ptr() if actions_ptr is None else actions_ptr
-        p.stats = stats_out if stats_out else self._bs + slot_out * self._ss   # e.g. straight into a send buffer
-        p.aer_out = aer_out
-        # two-launch path (no arg-max of sigma_pos): see include/ssa_hip.h ssa_step_params.stat_shards
         s = torch.cuda.current_stream().cuda_stream if stream is None else stream
         defer = bool(defer_fold and fast_stats)
         if not defer and self._fold_pending is not None:
             self.flush_stats(s)       # a deferred step is followed by an immediate one: fold it first (same stream, in order)
-        p.stat_shards = self._shard_sets[self._shard_cur].data_ptr() if fast_stats else 0
-        p.launch_mask = _lib.LAUNCH_DEFER_FOLD if defer else 0
+        p, pref, stats_ptr = self._step_params(slot_in, slot_out, aer_out, stats_out, upd_out, self._shard_cur if fast_stats else -1)
+        p.time_offset = int(time_offset)
+        p.actions = self._actions_ptr if actions_ptr is None else actions_ptr
         if defer and self._fold_pending is not None:
-            p.stat_shards_prev = self._shard_sets[self._fold_pending[0]].data_ptr()
+            p.launch_mask = _lib.LAUNCH_DEFER_FOLD
+            p.stat_shards_prev = self._shard_ptr[self._fold_pending[0]]
             p.stats_prev = self._fold_pending[1]
         else:
+            p.launch_mask = _lib.LAUNCH_DEFER_FOLD if defer else 0
             p.stat_shards_prev, p.stats_prev = 0, 0
         if profile_slot is None:
-            rc = self._lib.ssa_env_step_f64(self._cref, self._pref, s)
+            rc = self._lib.ssa_env_step_f64(self._cref, pref, s)
         else:   # the dominant launch bracketed by event pair `profile_slot` (read back with profile_ms)
-            rc = self._lib.ssa_env_step_profiled_f64(self._cref, self._pref, s, int(profile_slot))
-        p.launch_mask = 0
+            rc = self._lib.ssa_env_step_profiled_f64(self._cref, pref, s, int(profile_slot))
         if rc:
             raise _lib.SsaHipError("ssa_env_step_f64 failed with code %d" % rc)
         if defer:
-            self._fold_pending = (self._shard_cur, int(p.stats))
+            self._fold_pending = (self._shard_cur, stats_ptr)
             self._shard_cur ^= 1
 
     def launch_rollout(self, slot_in, time_offset, actions, stream=None):
