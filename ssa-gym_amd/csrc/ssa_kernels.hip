@@ -658,6 +658,14 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
 #endif
 
     if (TILE == 0) tile_issue(pf, p, lane, base, cnt);   // one tile per wavefront: plain load, no staging registers kept
+#ifndef SSA_NO_EARLY_ARGS
+    if (TILE == 0) {
+        // the epilogue's output pointers are fetched NOW: their scalar loads (kernarg segment) overlap the tile's HBM round
+        // trip instead of each adding a scalar-memory round trip to the store path of a latency-bound wavefront
+        asm volatile("" ::"s"(p.P_out), "s"(p.x_out), "s"(p.x_true_out), "s"(p.obs), "s"(p.metrics), "s"(p.stat_shards), "s"(p.upd),
+                     "s"(p.aer_out), "s"(p.n_obj));
+    }
+#endif
     if (TILE != 2) tile_commit(t, pf, lane);            // TILE 1: requested one tile ago (or by the kernel prologue)
     if (lane < 8) t.Z[lane] = 0.0;
     if (TILE != 2 && lane < 36) t.Q[lane] = C.Q[lane];   // (a rollout's later steps find it in place)
@@ -825,13 +833,13 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                     if (l != 13) sf[c] = xb[c] + sgn * t.UA[g * 36 + krow * 6 + c];
             }
             // H1/H2: measurement of every sigma point (lanes 0-12) and of the true state (lane 13)
-            double z[3];
+            double z[3], enu_vec[3];
             double el_mine;
             {
                 double Mm[9], aer[3];
 #pragma unroll
                 for (int i = 0; i < 9; ++i) Mm[i] = M[i];
-                hx_aer(sf, Mm, C.enu, C.obs_itrs, aer);
+                hx_aer_enu(sf, Mm, C.enu, C.obs_itrs, aer, enu_vec);
                 el_mine = aer[1];
                 if (C.obs_type == SSA_OBS_AER) { z[0] = aer[0]; z[1] = aer[1]; z[2] = aer[2]; }
                 else { z[0] = sf[0]; z[1] = sf[1]; z[2] = sf[2]; }
@@ -846,12 +854,11 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                 double zp[3];
                 const double wl = (l == 0) ? C.Wc0 : (is_pm ? C.Wi : 0.0);
                 if (C.obs_type == SSA_OBS_AER) {
-                    double uvw[3], um[3];
-                    aer2uvw(z, uvw);
+                    double um[3];   // mean_z_uvw (dynamics.py:343): aer2uvw of a sigma point is its local vector enu_vec
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        double u0 = row_bcast<0>(uvw[c]);
-                        double du = is_pm ? (uvw[c] - u0) : 0.0;
+                        double u0 = row_bcast<0>(enu_vec[c]);
+                        double du = is_pm ? (enu_vec[c] - u0) : 0.0;
                         um[c] = u0 + (C.sum_wm_m1 * u0 + C.Wi * row_allsum(du));
                     }
                     uvw2aer(um, zp);
@@ -875,7 +882,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
 #pragma unroll
                         for (int c = 0; c < 3; ++c) zin[c] = z[c];
                     }
-                    if (C.obs_type == SSA_OBS_AER) residual_z_aer(zin, zp, rz);
+                    if (C.obs_type == SSA_OBS_AER) residual_z_aer_wrapped(zin, zp, rz);
                     else {
 #pragma unroll
                         for (int c = 0; c < 3; ++c) rz[c] = zin[c] - zp[c];

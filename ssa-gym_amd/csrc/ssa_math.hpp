@@ -552,9 +552,12 @@ SSA_DEV int robust_chol6(const double* A, double* U)
 // ---------------------------------------------------------------------------
 // H1: hx_aer_erfa (dynamics.py:219) = ecef2aer(M x[:3]) (transformations.py:330-352).
 // enu = trans_uvw_ecef (row-major) for the observer.
-SSA_DEV void hx_aer(const double* x, const double* M, const double* enu, const double* obs, double* z)
+// Also hands back R, the observer-local cartesian vector az / el / range are formed from: aer2uvw(z) (transformations.py
+// :284-297: r cos el cos az, r cos el sin az, r sin el) IS that vector, so the update's mean_z_uvw takes it from here
+// instead of going through two more sincos per sigma point.
+SSA_DEV void hx_aer_enu(const double* x, const double* M, const double* enu, const double* obs, double* z, double* R)
 {
-    double xi[3], d[3], R[3];
+    double xi[3], d[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) xi[i] = M[i * 3] * x[0] + M[i * 3 + 1] * x[1] + M[i * 3 + 2] * x[2];
 #pragma unroll
@@ -567,6 +570,11 @@ SSA_DEV void hx_aer(const double* x, const double* M, const double* enu, const d
     z[0] = az;
     z[1] = asin(R[2] / rng);
     z[2] = rng;
+}
+SSA_DEV void hx_aer(const double* x, const double* M, const double* enu, const double* obs, double* z)
+{
+    double R[3];
+    hx_aer_enu(x, M, enu, obs, z, R);
 }
 SSA_DEV void aer2uvw(const double* aer, double* uvw)  // transformations.py:284
 {
@@ -591,6 +599,17 @@ SSA_DEV void residual_z_aer(const double* a, const double* b, double* c)  // dyn
     double d = a[0] - b[0], s, co;
     sincos(d, &s, &co);
     c[0] = atan2(s, co);
+    c[1] = a[1] - b[1];
+    c[2] = a[2] - b[2];
+}
+
+// the same residual for the fused update: atan2(sin d, cos d) is d wrapped into (-pi, pi]; formed directly (exact for
+// |d| < pi, where the sin / cos / atan2 route carries 1e-16 of absolute error) it saves a sincos and an atan2 on the
+// update's critical path
+SSA_DEV void residual_z_aer_wrapped(const double* a, const double* b, double* c)
+{
+    const double d = a[0] - b[0];
+    c[0] = fma(-rint(d * (1.0 / TWO_PI)), TWO_PI, d);
     c[1] = a[1] - b[1];
     c[2] = a[2] - b[2];
 }
