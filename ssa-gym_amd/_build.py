@@ -31,9 +31,11 @@ def build_library(force=False, verbose=False, extra_flags=()):
     # -disable-machine-licm: the step kernel is one long straight-line body inside a tile loop (plus Newton /
     # ladder loops); MachineLICM hoists its literals, argument scalars and LDS addresses out of those loops
     # and the register allocator then spills them (16 VGPR + 48 SGPR spills, 220 B scratch per lane with it;
-    # none without at 4 waves/SIMD) -- see DESIGN.md section 7
+    # none without at 4 waves/SIMD) -- see DESIGN.md section 6.  -amdgpu-kernarg-preload-count: the step kernel's leading pointer
+    # arguments arrive in SGPRs at wavefront launch (no scalar-memory round trip before the tile loads)
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-shared",
-           "-ffp-contract=fast", "-mllvm", "-disable-machine-licm", *extra_flags, "-o", LIB + ".tmp", SRC]
+           "-ffp-contract=fast", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-kernarg-preload-count=8",
+           *extra_flags, "-o", LIB + ".tmp", SRC]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -275,7 +275,7 @@ struct StepK {
 constexpr int OBJ_PER_WAVE = 4;
 constexpr double X_FAILED_POS = 1e20, X_FAILED_VEL = 1e12;  // ssa_tasker_simple_2.py:157-158
 
-// LDS working set of one wavefront (4 objects): 7 600 bytes, so that 20 wavefronts (5 per SIMD) share the CU's 160 KB.
+// LDS working set of one wavefront (4 objects): 7 984 bytes, so that 20 wavefronts (5 per SIMD) share the CU's 160 KB.
 // D holds the centred propagated sigma points d_i = sigma_i' - sigma_0' (i = 1..12) of the four objects as rows of 8
 // doubles [d_i[0..5], 1.0, 0.0]: the layout the matrix unit reads its operands from (below); the object blocks start at
 // {0, 100, 208, 308} doubles so that the 32 lanes of one ds_read_b64 half hit 32 different 8-byte bank slots.
@@ -290,6 +290,7 @@ struct alignas(16) Tiles {
     double Obs[OBJ_PER_WAVE * 12];
     double Met[OBJ_PER_WAVE * 4];
     double Z[8];                       // six zeros: the "factor row" of the lanes that add nothing (sigma_0, truth, idle)
+    double In[OBJ_PER_WAVE * 12];      // the update's inputs, prefetched: GCRS->ITRS matrix [9] | measurement noise [3]
     int St[OBJ_PER_WAVE];
 };
 SSA_DEV int dbase(int g) { return g * 96 + (g & 1) * 4 + (g >> 1) * 16; }   // 0, 100, 208, 308
@@ -305,26 +306,31 @@ SSA_DEV int dbase(int g) { return g * 96 + (g & 1) * 4 + (g >> 1) * 16; }   // 0
 struct TileRegs { double2 main, aux; };
 // one 16-byte lane of a tile load (plain: marking the inputs streaming was measured slower, 45.4 k vs 46.5 k)
 SSA_DEV double2 load16(const double* src) { return *reinterpret_cast<const double2*>(src); }
-SSA_DEV void tile_issue(TileRegs& r, const ssa_step_params& p, int lane, int64_t base, int cnt)
+SSA_DEV void tile_issue_from(TileRegs& r, const double* P_in, const double* x_in, const double* x_true_in, const int32_t* status,
+                            int lane, int64_t base, int cnt)
 {
     const double2 zero = make_double2(0.0, 0.0);
     r.main = zero;
     r.aux = zero;
     if (cnt <= 0) return;
-    const double* Pin = p.P_in + base * 36;
+    const double* Pin = P_in + base * 36;
     if (lane < cnt * 18) r.main = load16(Pin + 2 * lane);
     if (lane < 8) {
         if (64 + lane < cnt * 18) r.aux = load16(Pin + 2 * (64 + lane));
     } else if (lane >= 32 && lane < 44) {
         const int i = lane - 32;
-        if (i < cnt * 3) r.aux = load16(p.x_in + base * 6 + 2 * i);
+        if (i < cnt * 3) r.aux = load16(x_in + base * 6 + 2 * i);
     } else if (lane >= 48 && lane < 60) {
         const int i = lane - 48;
-        if (i < cnt * 3) r.aux = load16(p.x_true_in + base * 6 + 2 * i);
+        if (i < cnt * 3) r.aux = load16(x_true_in + base * 6 + 2 * i);
     } else if (lane >= 60) {
         const int i = lane - 60;
-        r.aux.x = __hiloint2double(0, (i < cnt) ? p.status[base + i] : SSA_ST_PREDICT_NAN);
+        r.aux.x = __hiloint2double(0, (i < cnt) ? status[base + i] : SSA_ST_PREDICT_NAN);
     }
+}
+SSA_DEV void tile_issue(TileRegs& r, const ssa_step_params& p, int lane, int64_t base, int cnt)
+{
+    tile_issue_from(r, p.P_in, p.x_in, p.x_true_in, p.status, lane, base, cnt);
 }
 SSA_DEV void tile_commit(Tiles& t, const TileRegs& r, int lane)
 {
@@ -648,6 +654,18 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     // the action / time index of this object's env, fetched early (used after the transform)
     const int act = valid ? p.actions[e] : -1;
     const int tix = valid ? p.env_time[e] + p.time_offset : 0;
+    // ---- the one update of this env (ssa_tasker_simple_2.py:292-315) runs in the row that owns the selected object.  Its
+    // wavefront is the longest-living one of the launch, so its inputs (this step's GCRS->ITRS matrix, the measurement noise)
+    // leave HBM now and wait in LDS, instead of costing two memory round trips when the update starts
+    const bool interval_ok = (C.update_interval <= 1) || (tix % C.update_interval == 0);
+    const bool my_update = valid && act >= 0 && (int64_t)act == j && interval_ok;
+    const int tmod = (p.n_time > 0) ? tix % p.n_time : 0;   // row of `trans` / `z_noise` (episodes wrap)
+    double upd_in = 0.0;
+    if (my_update && l < 12) {
+        const double* src = (l < 9) ? p.trans + (int64_t)tmod * 9 + l
+                                    : p.z_noise + (int64_t)e * p.zn_stride_env + (int64_t)tmod * p.zn_stride_time + (int64_t)act * p.zn_stride_obj + (l - 9);
+        upd_in = *src;
+    }
     SSA_TR(0);
 #ifdef SSA_TRACE
     if (lane == 0 && tile < 16384) {
@@ -657,7 +675,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     }
 #endif
 
-    if (TILE == 0) tile_issue(pf, p, lane, base, cnt);   // one tile per wavefront: plain load, no staging registers kept
+    // (TILE 0: the kernel issued the tile's loads from its preloaded pointer arguments before anything else)
 #ifndef SSA_NO_EARLY_ARGS
     if (TILE == 0) {
         // the epilogue's output pointers are fetched NOW: their scalar loads (kernarg segment) overlap the tile's HBM round
@@ -682,6 +700,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
 #else
     const int rung = robust_chol_row_lds(t, C.scale, g, l);
 #endif
+    if (my_update && l < 12) t.In[g * 12 + l] = upd_in;
     wave_lds_sync();
     SSA_TR(2);
     const bool chol_fail = (rung == 16);
@@ -806,17 +825,14 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     // ---- U5: the one update of this env (ssa_tasker_simple_2.py:292-315), in the row that owns the
     // selected object.  Cross-lane traffic is row-level (DPP / bpermute); the small matrices are staged
     // in the row's (now free) t.D area:  W[0..9) S | W[9..27) Pxz | W[27..36) inv(S) | W[36..54) K
-    const bool interval_ok = (C.update_interval <= 1) || (tix % C.update_interval == 0);
-    const bool my_update = valid && act >= 0 && (int64_t)act == j && interval_ok;
     if (my_update) {
-        const int tmod = (p.n_time > 0) ? tix % p.n_time : 0;   // row of `trans` / `z_noise` (episodes wrap)
         double* rec = p.upd ? p.upd + (int64_t)e * SSA_UPD_STRIDE : nullptr;
         double* W = &t.D[dbase(g)];
         bool taken = false, visible = false;
         // a filter that has failed (earlier, or in this step's predict) is skipped entirely (:293): no z_true, no record
         const bool attempted = (st_new == SSA_ST_OK);
         if (attempted) {
-            const double* M = p.trans + (int64_t)tmod * 9;
+            const double* M = &t.In[g * 12];
             // sigma points handed to update(): the propagated ones or, with
             // SSA_FLAG_RESAMPLE, the set drawn from the prior at the end of predict (factor rows in t.U)
             double sf[6], xb[6];
@@ -875,7 +891,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                 {
                     double zin[3];
                     if (l == 13) {
-                        const double* zn = p.z_noise + (int64_t)e * p.zn_stride_env + (int64_t)tmod * p.zn_stride_time + (int64_t)act * p.zn_stride_obj;
+                        const double* zn = &t.In[g * 12 + 9];
 #pragma unroll
                         for (int c = 0; c < 3; ++c) zin[c] = z[c] + zn[c];
                     } else {
@@ -1101,8 +1117,13 @@ __global__ void __launch_bounds__(64) reward_fold_kernel(unsigned long long* __r
 // MULTI = false is the one-tile-per-wavefront instance (every launch up to 20 480 objects): no loop, no staging
 // registers.
 typedef const __attribute__((address_space(4))) StepK* KernargPtr;
+// The four leading pointer arguments repeat k_arg.p.{P_in, x_in, x_true_in, status}: as plain scalar arguments they are
+// PRELOADED into SGPRs at wavefront launch (-amdgpu-kernarg-preload-count, _build.py), so the tile's loads -- the first link
+// of every wavefront's dependency chain -- leave without waiting for a scalar-memory round trip to the kernarg segment.
 template <int PROP, bool MULTI>
-__global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(const StepK k_arg, int ntiles, int nwork)
+__global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(const double* pre_P_in, const double* pre_x_in,
+                                                                       const double* pre_x_true_in, const int32_t* pre_status,
+                                                                       const StepK k_arg, int ntiles, int nwork)
 {
     __shared__ Tiles t;
     int lane = threadIdx.x;
@@ -1116,6 +1137,7 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(const Ste
     if (!MULTI) {
         const int64_t base = (int64_t)tile * OBJ_PER_WAVE;
         const int cnt = (int)((total - base) < OBJ_PER_WAVE ? (total - base) : OBJ_PER_WAVE);
+        tile_issue_from(pf, pre_P_in, pre_x_in, pre_x_true_in, pre_status, lane, base, cnt);
         process_wave<PROP, 0>(t, k_arg.c, k_arg.p, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, pf, 0, 0, tile);
         return;
     }
@@ -1886,13 +1908,13 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
     if (mask & 1u) {   // (ev0, ev1: dispatch timestamps of this kernel for ssa_env_step_profiled_f64, else null)
         const int nt = (int)ntiles;
         if (per_wave == 1) {
-            if (prop == SSA_PROP_FG) hipExtLaunchKernelGGL((step_fast_kernel<1, false>), grid, block, 0, s, ev0, ev1, 0, k, nt, nwork);
-            else if (prop == SSA_PROP_ELEMENTS) hipExtLaunchKernelGGL((step_fast_kernel<0, false>), grid, block, 0, s, ev0, ev1, 0, k, nt, nwork);
-            else hipExtLaunchKernelGGL((step_fast_kernel<2, false>), grid, block, 0, s, ev0, ev1, 0, k, nt, nwork);
+            if (prop == SSA_PROP_FG) hipExtLaunchKernelGGL((step_fast_kernel<1, false>), grid, block, 0, s, ev0, ev1, 0, p->P_in, p->x_in, p->x_true_in, p->status, k, nt, nwork);
+            else if (prop == SSA_PROP_ELEMENTS) hipExtLaunchKernelGGL((step_fast_kernel<0, false>), grid, block, 0, s, ev0, ev1, 0, p->P_in, p->x_in, p->x_true_in, p->status, k, nt, nwork);
+            else hipExtLaunchKernelGGL((step_fast_kernel<2, false>), grid, block, 0, s, ev0, ev1, 0, p->P_in, p->x_in, p->x_true_in, p->status, k, nt, nwork);
         } else {
-            if (prop == SSA_PROP_FG) hipExtLaunchKernelGGL((step_fast_kernel<1, true>), grid, block, 0, s, ev0, ev1, 0, k, nt, nwork);
-            else if (prop == SSA_PROP_ELEMENTS) hipExtLaunchKernelGGL((step_fast_kernel<0, true>), grid, block, 0, s, ev0, ev1, 0, k, nt, nwork);
-            else hipExtLaunchKernelGGL((step_fast_kernel<2, true>), grid, block, 0, s, ev0, ev1, 0, k, nt, nwork);
+            if (prop == SSA_PROP_FG) hipExtLaunchKernelGGL((step_fast_kernel<1, true>), grid, block, 0, s, ev0, ev1, 0, p->P_in, p->x_in, p->x_true_in, p->status, k, nt, nwork);
+            else if (prop == SSA_PROP_ELEMENTS) hipExtLaunchKernelGGL((step_fast_kernel<0, true>), grid, block, 0, s, ev0, ev1, 0, p->P_in, p->x_in, p->x_true_in, p->status, k, nt, nwork);
+            else hipExtLaunchKernelGGL((step_fast_kernel<2, true>), grid, block, 0, s, ev0, ev1, 0, p->P_in, p->x_in, p->x_true_in, p->status, k, nt, nwork);
         }
     }
     if (fast_stats) {   // (the aer_out payload, if any, was the step kernel's epilogue) a one-wave fold finishes the step
