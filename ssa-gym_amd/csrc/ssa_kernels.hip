@@ -275,7 +275,8 @@ struct StepK {
 constexpr int OBJ_PER_WAVE = 4;
 constexpr double X_FAILED_POS = 1e20, X_FAILED_VEL = 1e12;  // ssa_tasker_simple_2.py:157-158
 
-// LDS working set of one wavefront (4 objects): 7 984 bytes, so that 20 wavefronts (5 per SIMD) share the CU's 160 KB.
+// LDS working set of one wavefront (4 objects): 7 600 bytes -- it must stay <= 7 680: with 7 984 only 18 wavefronts fit a CU
+// (the allocation granule is larger than 512 bytes) and the 20 000-object step needs a second round (+2 us, measured).
 // D holds the centred propagated sigma points d_i = sigma_i' - sigma_0' (i = 1..12) of the four objects as rows of 8
 // doubles [d_i[0..5], 1.0, 0.0]: the layout the matrix unit reads its operands from (below); the object blocks start at
 // {0, 100, 208, 308} doubles so that the 32 lanes of one ds_read_b64 half hit 32 different 8-byte bank slots.
@@ -287,13 +288,13 @@ struct alignas(16) Tiles {
     double D[408];                     // centred propagated sigma points (see above); scratch of the update
     double M[OBJ_PER_WAVE * 12];       // s = Wi sum d_i | m' = mean - sigma_0'
     double Q[36];                      // process noise (read per covariance entry with a lane-dependent index)
-    double Obs[OBJ_PER_WAVE * 12];
+    double Obs[OBJ_PER_WAVE * 12];     // until the update has run: its prefetched inputs (GCRS->ITRS matrix [9] | measurement noise [3]) per object
     double Met[OBJ_PER_WAVE * 4];
     double Z[8];                       // six zeros: the "factor row" of the lanes that add nothing (sigma_0, truth, idle)
-    double In[OBJ_PER_WAVE * 12];      // the update's inputs, prefetched: GCRS->ITRS matrix [9] | measurement noise [3]
     int St[OBJ_PER_WAVE];
 };
 SSA_DEV int dbase(int g) { return g * 96 + (g & 1) * 4 + (g >> 1) * 16; }   // 0, 100, 208, 308
+static_assert(sizeof(Tiles) <= 7680, "Tiles must fit 20 wavefronts per CU (see above)");
 
 // Wave-contiguous tile I/O: the 4 objects of a wavefront are consecutive, so P / x / x_true / obs are
 // single contiguous spans (1152 / 192 / 192 / 384 B) moved as 16-byte lanes -- whole cache lines per
@@ -700,7 +701,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
 #else
     const int rung = robust_chol_row_lds(t, C.scale, g, l);
 #endif
-    if (my_update && l < 12) t.In[g * 12 + l] = upd_in;
+    if (my_update && l < 12) t.Obs[g * 12 + l] = upd_in;
     wave_lds_sync();
     SSA_TR(2);
     const bool chol_fail = (rung == 16);
@@ -832,7 +833,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         // a filter that has failed (earlier, or in this step's predict) is skipped entirely (:293): no z_true, no record
         const bool attempted = (st_new == SSA_ST_OK);
         if (attempted) {
-            const double* M = &t.In[g * 12];
+            const double* M = &t.Obs[g * 12];
             // sigma points handed to update(): the propagated ones or, with
             // SSA_FLAG_RESAMPLE, the set drawn from the prior at the end of predict (factor rows in t.U)
             double sf[6], xb[6];
@@ -891,7 +892,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                 {
                     double zin[3];
                     if (l == 13) {
-                        const double* zn = &t.In[g * 12 + 9];
+                        const double* zn = &t.Obs[g * 12 + 9];
 #pragma unroll
                         for (int c = 0; c < 3; ++c) zin[c] = z[c] + zn[c];
                     } else {
@@ -1160,7 +1161,7 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(const dou
         // instead of being carried around the loop in registers
         asm volatile("" : "+s"(kp));
         asm volatile("" : "+v"(lane));
-        const StepK& k = *(const StepK*)kp;
+        const StepK& k = *(const StepK*)((const char*)kp + 4 * sizeof(void*));   // behind the four preloaded pointer arguments
         const int64_t base = (int64_t)tile * OBJ_PER_WAVE;
         const int cnt = (int)((total - base) < OBJ_PER_WAVE ? (total - base) : OBJ_PER_WAVE);
         const int nt = tile + nwork;
