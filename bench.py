@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_OBJECT_STEP = 896   # r+w x_true 48, x 48, P 288 each way; obs 96; metrics 32
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-FP64_FLOP_PER_OBJECT_STEP = 9400  # profiles/*fp64_counters.json: (ADD + MUL + 2 FMA + TRANS) x 64 lanes / 4 objects per wavefront
+FP64_FLOP_PER_OBJECT_STEP = 6900  # profiles/r02_counters.json: (ADD 16 + MUL 75 + 2 FMA 130 + TRANS 10) x 64 lanes + 9 MFMA x 512, per 4 objects
 FP64_PEAK_TFLOPS = 78.6           # MI355X datasheet fp64 vector peak (an FMA micro-benchmark reaches 63.2 on these boxes)
 
 
@@ -440,7 +440,7 @@ def main():
                 "fp64_frac": round(fp64_tflops / FP64_PEAK_TFLOPS, 4),
                 "fp64": {"flop_per_object_step": FP64_FLOP_PER_OBJECT_STEP, "achieved_tflops": round(fp64_tflops, 2),
                          "peak_tflops": FP64_PEAK_TFLOPS,
-                         "note": "flop count from the SQ_INSTS_VALU_*_F64 counters of the fg kernel (profiles/); datasheet vector peak"},
+                         "note": "flop count from the SQ_INSTS_VALU_*_F64 / MFMA counters of the fg kernel (profiles/r02_counters.json); datasheet vector peak"},
                 "limiter": "per-wavefront dependency chain + VALU / LDS issue (HBM idles between the load and store bursts); "
                            "`bound` names the roofline north_star declares for the path, the kernel is not memory-bound",
                 "note": "whole 479-step episode of back-to-back per-step launches, HIP event pair bound to each dispatch"}
