@@ -298,6 +298,12 @@ def main():
     if args.dry_run:
         return dry_run(args)
 
+    # stdout carries exactly ONE line -- the JSON record.  Native libraries write there too (RCCL prints a version banner at
+    # communicator creation): from here on file descriptor 1 is stderr, and the record goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     import ssa_gym_amd
@@ -528,7 +534,8 @@ def main():
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(steps_per_s * world / cpu["value"], 1)
             out["speedup_vs_cpu_baseline_all_cores"] = round(steps_per_s * world / cpu_all["value"], 1)
-        print(json.dumps(out), flush=True)
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
     if use_dist:
         dist.barrier()
         if sharded is not None:

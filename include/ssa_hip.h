@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SSA_ABI_VERSION 13
+#define SSA_ABI_VERSION 14
 
 /* error codes */
 #define SSA_OK 0
@@ -148,6 +148,11 @@ typedef struct ssa_step_params {
                                   ssa_tasker_simple_2.py:834-840), may be NULL.  With stat_shards it is written by the step
                                   kernel's epilogue from the on-chip tiles (no extra launch, no second pass over x / P);
                                   without, by the post kernel: the 'aer' observation / the sharded all-gather payload. */
+    uint64_t *stat_shards_clear; /* [E][SSA_STAT_SHARDS][4] or NULL: a shard set this launch ZEROES (nothing reads or adds to it
+                                  during the launch).  Lets a consumer that takes the statistics as RAW shards -- the sharded
+                                  multi-GPU step sends its rank's shard words in the all-gather payload and every rank
+                                  folds all ranks' words itself -- alternate two payload buffers without a fold / clear
+                                  launch: step k accumulates into buffer k & 1 and clears buffer (k + 1) & 1. */
 } ssa_step_params;
 
 /* ---------------------------------------------------------------- fused hot path

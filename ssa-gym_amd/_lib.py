@@ -33,6 +33,7 @@ class ssa_step_params(C.Structure):
         ("zn_stride_env", C.c_int64), ("zn_stride_time", C.c_int64), ("zn_stride_obj", C.c_int64),
         ("n_time", C.c_int32), ("launch_mask", C.c_uint32), ("stats", c_dp), ("work", c_dp), ("stat_ws", c_dp),
         ("stat_shards", c_dp), ("stat_shards_prev", c_dp), ("stats_prev", c_dp), ("aer_out", c_dp),
+        ("stat_shards_clear", c_dp),
     ]
 
 
@@ -45,7 +46,7 @@ class ssa_rollout_params(C.Structure):
 
 
 # constants of include/ssa_hip.h
-ABI_VERSION = 13
+ABI_VERSION = 14
 ST_OK, ST_PREDICT_NAN, ST_PREDICT_LINALG, ST_UPDATE_NAN, ST_UPDATE_LINALG = range(5)
 OBS_AER, OBS_XYZ = 0, 1
 PROP_ELEMENTS, PROP_FG, PROP_J2_RK4 = 0, 1, 2

@@ -1128,6 +1128,10 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(const dou
 {
     __shared__ Tiles t;
     int lane = threadIdx.x;
+    if (blockIdx.x == 0 && k_arg.p.stat_shards_clear) {   // zero the shard set the NEXT step will accumulate into (raw-shard consumers)
+        unsigned long long* z = (unsigned long long*)k_arg.p.stat_shards_clear;
+        for (int i = threadIdx.x; i < k_arg.p.n_env * SSA_STAT_SHARDS * 4; i += 64) z[i] = 0ull;
+    }
     if ((int)blockIdx.x >= nwork) {   // deferred fold of the previous step's statistics: one extra wavefront per env
         fold_stat_shards((unsigned long long*)k_arg.p.stat_shards_prev, k_arg.p.stats_prev, (int)blockIdx.x - nwork, lane);
         return;
@@ -1920,7 +1924,7 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
     }
     if (fast_stats) {   // (the aer_out payload, if any, was the step kernel's epilogue) a one-wave fold finishes the step
                         // (2 launches), unless deferred (1 launch)
-        if ((mask & 6u) && !defer)
+        if ((mask & 6u) && !defer && p->stats)   // (stats NULL: the caller consumes the raw shard words, see stat_shards_clear)
             hipLaunchKernelGGL(reward_fold_kernel, dim3(p->n_env), dim3(64), 0, s, (unsigned long long*)p->stat_shards, p->stats);
         return launch_status();
     }

@@ -23,6 +23,8 @@ import torch
 import torch.distributed as dist
 
 STAT_STRIDE = 8
+STAT_SHARDS = 64                 # include/ssa_hip.h SSA_STAT_SHARDS: raw statistics words [64][4] uint64 per env
+RAW_WORDS = STAT_SHARDS * 4
 STAT_MAX_DPOS, STAT_CNT_LT_1E4, STAT_CNT_LT_1E7, STAT_ARGMAX_SPOS, STAT_N_FAILED, STAT_MAX_SPOS = range(6)
 
 
@@ -87,9 +89,16 @@ class ShardedStepper:
         self.plan, self.local, self.group = plan, local, group
         self._rccl = None
         dev = local.device
-        self.width = 4 * plan.m_pad + STAT_STRIDE
+        # payload of one rank: [ aer block 4 * m_pad | 8 folded statistics | 256 raw statistics words (uint64 bit patterns) ]
+        # A local stepper with `raw_shards` (the HIP engine) lets the step kernel accumulate straight into the raw words of
+        # the send buffer -- no fold launch -- and every rank folds all ranks' words on arrival; other steppers fill the 8
+        # folded statistics.  (The step kernel of step k also zeroes the raw words of the OTHER send buffer, whose last
+        # all-gather has completed in stream order; with the all-gather on a communication stream that is not guaranteed,
+        # so the overlapped mode keeps the folded form.)
+        self.width = 4 * plan.m_pad + STAT_STRIDE + RAW_WORDS
         self.send = [torch.zeros(self.width, dtype=torch.float64, device=dev) for _ in range(2)]
         self.recv = [torch.zeros(plan.world * self.width, dtype=torch.float64, device=dev) for _ in range(2)]
+        self._raw = [False, False]
         self.k = 0
         self._gpu = torch.device(dev).type == "cuda"
         if self._gpu:
@@ -118,7 +127,14 @@ class ShardedStepper:
             torch.cuda.current_stream().wait_event(self._done[b])   # payload of step k-2 has left
             self._pending[b] = False
         # kernels of this step write (az, el, range, trP) and the statistics straight into `send`
-        self.local.step(p.local_action(global_action), send[:4 * p.m_local], send[4 * p.m_pad:])
+        o_st = 4 * p.m_pad
+        raw = bool(getattr(self.local, "raw_shards", False)) and not overlap
+        if raw:
+            self.local.step(p.local_action(global_action), send[:4 * p.m_local], None,
+                            shards_out=send[o_st + STAT_STRIDE:], shards_clear=self.send[b ^ 1][o_st + STAT_STRIDE:])
+        else:
+            self.local.step(p.local_action(global_action), send[:4 * p.m_local], send[o_st:o_st + STAT_STRIDE])
+        self._raw[b] = raw
         if not use_dist:   # single process without a process group
             recv.copy_(send)
         elif overlap:
@@ -161,8 +177,17 @@ class ShardedStepper:
     def global_stats(self):
         """reduce the per-rank statistics exactly as the single-GPU kernel would have produced them."""
         p = self.plan
-        st = self._latest().view(p.world, self.width)[:, 4 * p.m_pad:].cpu().numpy()
+        rows = self._latest().view(p.world, self.width)[:, 4 * p.m_pad:].cpu().numpy()
+        st = rows[:, :STAT_STRIDE]
         out = np.zeros(STAT_STRIDE)
+        if self._raw[(self.k - 1) & 1]:      # raw shard words of every rank: fold them as reward_fold_kernel would
+            w = np.ascontiguousarray(rows[:, STAT_STRIDE:]).view(np.uint64).reshape(p.world * STAT_SHARDS, 4)
+            out[STAT_MAX_DPOS] = np.array([w[:, 0].max()], dtype=np.uint64).view(np.float64)[0]   # ordered bit patterns, NaN on top
+            out[STAT_CNT_LT_1E4] = float((w[:, 1] & np.uint64(0xffffffff)).sum())
+            out[STAT_CNT_LT_1E7] = float((w[:, 1] >> np.uint64(32)).sum())
+            out[STAT_N_FAILED] = float(w[:, 2].sum())
+            out[STAT_MAX_SPOS], out[STAT_ARGMAX_SPOS] = np.nan, -1.0
+            return out
         out[STAT_MAX_DPOS] = np.nan if np.isnan(st[:, STAT_MAX_DPOS]).any() else st[:, STAT_MAX_DPOS].max()
         out[STAT_CNT_LT_1E4] = st[:, STAT_CNT_LT_1E4].sum()
         out[STAT_CNT_LT_1E7] = st[:, STAT_CNT_LT_1E7].sum()
@@ -190,6 +215,7 @@ class HipLocalStepper:
         # last one).  For consumers that read the statistics in bulk; a closed loop reads them every step (no deferral).
         self.defer_fold = defer_fold
         self.device = engine.dev
+        self.raw_shards = bool(fast_stats)   # the step kernel can accumulate into caller-provided shard words (no fold launch)
         self.tick = 0
         self._act = torch.zeros(1, dtype=torch.int32)
         self._sched = None
@@ -203,23 +229,25 @@ class HipLocalStepper:
         """fold the statistics of the last deferred step."""
         self.engine.flush_stats()
 
-    def step(self, local_action, obs_out=None, stats_out=None, profile_slot=None):
+    def step(self, local_action, obs_out=None, stats_out=None, profile_slot=None, shards_out=None, shards_clear=None):
         """enqueue one env step; when given, the post kernel writes the shard's aer observation
         block and its reward statistics directly into `obs_out` / `stats_out` (the all-gather payload)."""
         e = self.engine
         self.tick += 1
         aer = obs_out.data_ptr() if obs_out is not None else 0
         st = stats_out.data_ptr() if stats_out is not None else 0
+        so = shards_out.data_ptr() if shards_out is not None else 0
+        sc = shards_clear.data_ptr() if shards_clear is not None else 0
         if self._sched is not None:
             k = (self.tick - 1 - self._sched_k0) % self._sched.numel()
             e.launch_step((self.tick - 1) % e.H, self.tick % e.H, self.tick, actions_ptr=self._sched.data_ptr() + 4 * k,
                           aer_out=aer, stats_out=st, fast_stats=self.fast_stats, defer_fold=self.defer_fold and stats_out is None,
-                          profile_slot=profile_slot)
+                          profile_slot=profile_slot, shards_out=so, shards_clear=sc)
             return
         self._act[0] = int(local_action)
         e.actions.copy_(self._act)
         e.launch_step((self.tick - 1) % e.H, self.tick % e.H, self.tick, aer_out=aer, stats_out=st, fast_stats=self.fast_stats,
-                      defer_fold=self.defer_fold and stats_out is None, profile_slot=profile_slot)
+                      defer_fold=self.defer_fold and stats_out is None, profile_slot=profile_slot, shards_out=so, shards_clear=sc)
 
     def rollout(self, n_steps):
         """advance n_steps of the pre-staged schedule in ONE launch (open-loop actions; HotPathEngine.launch_rollout)."""

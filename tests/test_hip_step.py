@@ -672,6 +672,15 @@ def test_direct_rccl_all_gather_equals_torch_distributed(hip):
             assert (sh._rccl is not None) == direct
             for k in range(3):
                 sh.step(7 * k + 1, overlap=(k == 2))
+                if k == 1:   # in-stream steps carry the RAW shard words (no fold launch); folded on arrival they must equal
+                    sh.wait()   # the numpy reductions of this step's metrics
+                    torch.cuda.synchronize()
+                    assert sh._raw[1] and sh._raw[0]
+                    st = sh.global_stats()
+                    dp = eng.metrics[local.tick % 2, 0, 0].cpu().numpy()
+                    assert st[hip.lib.STAT_MAX_DPOS] == dp.max() and st[hip.lib.STAT_CNT_LT_1E4] == (dp < 1e4).sum()
+                    assert st[hip.lib.STAT_CNT_LT_1E7] == (dp < 1e7).sum() and st[hip.lib.STAT_N_FAILED] == 0
+            assert not sh._raw[0]   # the overlapped step (k = 2, buffer 0) went through the fold
             sh.wait()
             torch.cuda.synchronize()
             got.append((sh.global_obs().cpu().numpy(), sh.global_stats(), sh.recv[0].cpu().numpy(), sh.recv[1].cpu().numpy()))
