@@ -38,6 +38,54 @@ SSA_DEV double rsqrt_nr(double v)
     return fma(y, e * fma(0.375, e, 0.5), y);
 }
 
+// a / b and sqrt(v) through the refined hardware estimates (<= 1-2 ulp: the reference's numpy / libm chain is correctly
+// rounded here, the same class; the IEEE sequences cost 14-25 instructions each and SSA_PROP_ELEMENTS has 13 + 8 of them
+// per sigma point)
+SSA_DEV double div_fast(double a, double b) { return a * rcp_nr(b); }
+SSA_DEV double sqrt_fast(double v) { return (v == 0.0) ? 0.0 : v * rsqrt_nr(v); }
+
+// sin and cos of a moderately sized angle (|x| < 64: every angle of the element chain): Cody-Waite reduction by pi/2 in two
+// parts and the fdlibm kernel polynomials on |r| <= pi/4; 1.5 ulp.  Larger arguments (whole-wave branch) go to libm.
+SSA_DEV void sincos_fast(double x, double& so, double& co)
+{
+    if (__all(fabs(x) < 64.0)) {
+        const double k = rint(x * 0.63661977236758134308);
+        double r = fma(-k, 1.57079632673412561417e+00, x);
+        r = fma(-k, 6.07710050650619224932e-11, r);
+        const double z = r * r;
+        double ps = 1.58969099521155010221e-10;
+        ps = fma(ps, z, -2.50507602534068634195e-08);
+        ps = fma(ps, z, 2.75573137070700676789e-06);
+        ps = fma(ps, z, -1.98412698298579493134e-04);
+        ps = fma(ps, z, 8.33333333332248946124e-03);
+        ps = fma(ps, z, -1.66666666666666324348e-01);
+        const double s = fma(z * r, ps, r);
+        double pc = -1.13596475577881948265e-11;
+        pc = fma(pc, z, 2.08757232129817482790e-09);
+        pc = fma(pc, z, -2.75573143513906633035e-07);
+        pc = fma(pc, z, 2.48015872894767294178e-05);
+        pc = fma(pc, z, -1.38888888888741095749e-03);
+        pc = fma(pc, z, 4.16666666666666019037e-02);
+        const double c = 1.0 - fma(-z * z, pc, 0.5 * z);
+        const int n = (int)k & 3;
+        const double a = (n & 1) ? c : s, b = (n & 1) ? s : c;   // quadrant
+        so = (n & 2) ? -a : a;
+        co = ((n + 1) & 2) ? -b : b;
+    } else {
+        sincos(x, &so, &co);
+    }
+}
+// (s, c) <- (sin, cos)(angle + d), |d| <= 0.02: truncation d^9/9! < 2e-21
+SSA_DEV void rot_small(double d, double& s, double& c)
+{
+    const double d2 = d * d;
+    const double sd = d * (1.0 - d2 * (1.0 / 6.0) * (1.0 - d2 * (1.0 / 20.0) * (1.0 - d2 * (1.0 / 42.0))));
+    const double cd = 1.0 - d2 * 0.5 * (1.0 - d2 * (1.0 / 12.0) * (1.0 - d2 * (1.0 / 30.0) * (1.0 - d2 * (1.0 / 56.0))));
+    const double s2 = s * cd + c * sd;
+    c = c * cd - s * sd;
+    s = s2;
+}
+
 // Python / numpy `a % (2 pi)` (result in [0, 2 pi)); exact remainder via one FMA.
 SSA_DEV double mod_2pi(double a)
 {
@@ -59,15 +107,20 @@ SSA_DEV double solve_kepler_E(double M, double ecc)
     double p0 = (ecc < 0.8) ? M : (M > 0.0 ? PI : (M < 0.0 ? -PI : 0.0));
     double res = __builtin_nan("");
     bool done = false;
+    double s, c;
+    sincos_fast(p0, s, c);
     for (int it = 0; it < 50; ++it) {
-        double s, c;
-        sincos(p0, &s, &c);
-        double fval = (p0 - ecc * s) - M;
-        double fder = 1.0 - ecc * c;
-        double p = p0 - fval / fder;
-        if (!done && fabs(p - p0) < NEWTON_TOL) { res = p; done = true; }
+        const double fval = (p0 - ecc * s) - M;
+        const double fder = 1.0 - ecc * c;
+        const double p = p0 - div_fast(fval, fder);
+        const double d = p - p0;
+        if (!done && fabs(d) < NEWTON_TOL) { res = p; done = true; }
         p0 = p;
         if (__all(done)) break;
+        // sin / cos of the new iterate: carried along by the angle-addition formulas while the Newton step is small
+        // (every step after the first on the catalogue), evaluated afresh otherwise
+        if (fabs(d) <= 0.02) rot_small(d, s, c);
+        else sincos_fast(p0, s, c);
     }
     return res;
 }
@@ -76,11 +129,11 @@ SSA_DEV double solve_kepler_E(double M, double ecc)
 SSA_DEV void coe2rv(double p, double ecc, double inc, double raan, double argp, double nu, double* out)
 {
     double sn, cn, sO, cO, si, ci, sw, cw;
-    sincos(nu, &sn, &cn);
-    sincos(raan, &sO, &cO);
-    sincos(inc, &si, &ci);
-    sincos(argp, &sw, &cw);
-    double fr = p / (1.0 + ecc * cn), fv = sqrt(MU / p);
+    sincos_fast(nu, sn, cn);
+    sincos_fast(raan, sO, cO);
+    sincos_fast(inc, si, ci);
+    sincos_fast(argp, sw, cw);
+    double fr = div_fast(p, 1.0 + ecc * cn), fv = sqrt_fast(div_fast(MU, p));
     double px = cn * fr, py = sn * fr, vx = -sn * fv, vy = (ecc + cn) * fv;
     double r00 = cO * cw - sO * ci * sw, r01 = -cO * sw - sO * ci * cw;
     double r10 = sO * cw + cO * ci * sw, r11 = -sO * sw + cO * ci * cw;
@@ -101,39 +154,45 @@ SSA_DEV bool rv2coe_elliptic(const double* r, const double* v, double* coe)
     const double tol = 1e-8;
     double h[3] = {r[1] * v[2] - r[2] * v[1], r[2] * v[0] - r[0] * v[2], r[0] * v[1] - r[1] * v[0]};
     double n[3] = {-h[1], h[0], 0.0};  // cross([0,0,1], h)
-    double rn = sqrt(dot3(r, r)), vv = dot3(v, v), rv = dot3(r, v);
-    double c1 = vv - MU / rn;
-    double e[3] = {(c1 * r[0] - rv * v[0]) / MU, (c1 * r[1] - rv * v[1]) / MU, (c1 * r[2] - rv * v[2]) / MU};
-    double ecc = sqrt(dot3(e, e));
-    double p = dot3(h, h) / MU;
-    double hn = sqrt(dot3(h, h));
-    double inc = acos(h[2] / hn);
+    double rn = sqrt_fast(dot3(r, r)), vv = dot3(v, v), rv = dot3(r, v);
+    const double inv_mu = 1.0 / MU;
+    double c1 = vv - div_fast(MU, rn);
+    double e[3] = {(c1 * r[0] - rv * v[0]) * inv_mu, (c1 * r[1] - rv * v[1]) * inv_mu, (c1 * r[2] - rv * v[2]) * inv_mu};
+    double ecc = sqrt_fast(dot3(e, e));
+    double p = dot3(h, h) * inv_mu;
+    double hn = sqrt_fast(dot3(h, h));
+    const double inv_hn = rcp_nr(hn);
+    double inc = acos(h[2] * inv_hn);
     bool circular = ecc < tol, equatorial = fabs(inc) < tol;
     double raan, argp, nu;
     if (equatorial && !circular) {
         raan = 0.0;
         argp = mod_2pi(atan2(e[1], e[0]));
         double t[3] = {e[1] * r[2] - e[2] * r[1], e[2] * r[0] - e[0] * r[2], e[0] * r[1] - e[1] * r[0]};
-        nu = atan2(dot3(h, t) / hn, dot3(r, e));
+        nu = atan2(dot3(h, t) * inv_hn, dot3(r, e));
     } else if (!equatorial && circular) {
         raan = mod_2pi(atan2(n[1], n[0]));
         argp = 0.0;
         double t[3] = {h[1] * n[2] - h[2] * n[1], h[2] * n[0] - h[0] * n[2], h[0] * n[1] - h[1] * n[0]};
-        nu = atan2(dot3(r, t) / hn, dot3(r, n));
+        nu = atan2(dot3(r, t) * inv_hn, dot3(r, n));
     } else if (equatorial && circular) {
         raan = 0.0;
         argp = 0.0;
         nu = mod_2pi(atan2(r[1], r[0]));
     } else {
-        double a = p / (1.0 - ecc * ecc);
+        double a = div_fast(p, 1.0 - ecc * ecc);
         if (!(a > 0.0)) return false;
-        double e_se = rv / sqrt(MU * a);
-        double e_ce = rn * vv / MU - 1.0;
+        double e_se = rv * rsqrt_nr(MU * a);
+        double e_ce = rn * vv * inv_mu - 1.0;
         double E = atan2(e_se, e_ce);
-        nu = 2.0 * atan(sqrt((1.0 + ecc) / (1.0 - ecc)) * tan(0.5 * E));
+        {
+            double sh, ch;
+            sincos_fast(0.5 * E, sh, ch);
+            nu = 2.0 * atan(sqrt_fast(div_fast(1.0 + ecc, 1.0 - ecc)) * div_fast(sh, ch));   // tan(E/2) = sin / cos
+        }
         raan = mod_2pi(atan2(n[1], n[0]));
         double t[3] = {h[1] * n[2] - h[2] * n[1], h[2] * n[0] - h[0] * n[2], h[0] * n[1] - h[1] * n[0]};
-        double px = dot3(r, n), py = dot3(r, t) / hn;
+        double px = dot3(r, n), py = dot3(r, t) * inv_hn;
         argp = mod_2pi(atan2(py, px) - nu);
     }
     nu = wrap_pi(nu);
@@ -180,15 +239,20 @@ SSA_DEV void kepler_elements(const double* x, double tof, double* out, double* d
         return;
     }
     double p = coe[0], ecc = coe[1], nu0 = coe[5];
-    double q = p / (1.0 + ecc);
+    double q = div_fast(p, 1.0 + ecc);
     double ome = 1.0 - ecc;
-    double E0 = 2.0 * atan(sqrt(ome / (1.0 + ecc)) * tan(0.5 * nu0));
-    double M0 = E0 - ecc * sin(E0);
-    double nmm = sqrt(MU * ome * ome * ome / (q * q * q));
-    double dt0 = M0 / nmm;
+    double sh, ch;
+    sincos_fast(0.5 * nu0, sh, ch);
+    double E0 = 2.0 * atan(sqrt_fast(div_fast(ome, 1.0 + ecc)) * div_fast(sh, ch));
+    double sE0, cE0;
+    sincos_fast(E0, sE0, cE0);
+    double M0 = E0 - ecc * sE0;
+    double nmm = sqrt_fast(div_fast(MU * ome * ome * ome, q * q * q));
+    double dt0 = div_fast(M0, nmm);
     double M = nmm * (dt0 + tof);
     double E = solve_kepler_E(wrap_pi(M), ecc);
-    double nu = 2.0 * atan(sqrt((1.0 + ecc) / ome) * tan(0.5 * E));
+    sincos_fast(0.5 * E, sh, ch);
+    double nu = 2.0 * atan(sqrt_fast(div_fast(1.0 + ecc, ome)) * div_fast(sh, ch));
     coe2rv(p, ecc, coe[2], coe[3], coe[4], nu, out);
     if (diag) {
         for (int i = 0; i < 6; ++i) diag[i] = coe[i];
@@ -421,15 +485,20 @@ SSA_DEV bool kepler_elements_fast(const double* x, double tof, double* out)
     double coe[6] = {1e7, 0.0, 0.0, 0.0, 0.0, 0.0};
     bool ok = rv2coe_elliptic(x, x + 3, coe);
     double p = coe[0], ecc = ok ? coe[1] : 0.0, nu0 = coe[5];
-    double q = p / (1.0 + ecc);
+    double q = div_fast(p, 1.0 + ecc);
     double ome = 1.0 - ecc;
-    double E0 = 2.0 * atan(sqrt(ome / (1.0 + ecc)) * tan(0.5 * nu0));
-    double M0 = E0 - ecc * sin(E0);
-    double nmm = sqrt(MU * ome * ome * ome / (q * q * q));
-    double dt0 = M0 / nmm;
+    double sh, ch;
+    sincos_fast(0.5 * nu0, sh, ch);
+    double E0 = 2.0 * atan(sqrt_fast(div_fast(ome, 1.0 + ecc)) * div_fast(sh, ch));
+    double sE0, cE0;
+    sincos_fast(E0, sE0, cE0);
+    double M0 = E0 - ecc * sE0;
+    double nmm = sqrt_fast(div_fast(MU * ome * ome * ome, q * q * q));
+    double dt0 = div_fast(M0, nmm);
     double M = nmm * (dt0 + tof);
     double E = solve_kepler_E(wrap_pi(M), ecc);
-    double nu = 2.0 * atan(sqrt((1.0 + ecc) / ome) * tan(0.5 * E));
+    sincos_fast(0.5 * E, sh, ch);
+    double nu = 2.0 * atan(sqrt_fast(div_fast(1.0 + ecc, ome)) * div_fast(sh, ch));
     coe2rv(p, ecc, coe[2], coe[3], coe[4], nu, out);
     return ok && (E == E);
 }

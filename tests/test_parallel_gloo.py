@@ -26,14 +26,28 @@ class OracleLocalStepper:
         self.tick = 0
         self.Wm, self.Wc, self.scale = orc.merwe_weights(1e-4, 2.0, -3)
 
-    def step(self, a, obs_out=None, stats_out=None):
+    raw_shards = False     # True: hand the statistics over as raw shard words, the way the HIP step kernel's atomics leave them
+
+    def step(self, a, obs_out=None, stats_out=None, shards_out=None, shards_clear=None):
         self.tick += 1
         ep = self.ep
         zn = ep["z_noise"][self.tick, self.lo + a] if a >= 0 else np.zeros(3)
         r = self.o.env_step(self.xt, self.x, self.P, self.status, 20.0, ep["Q"], ep["R"], self.Wm, self.Wc, self.scale, a,
                             self.c2t[self.tick], ep["obs_lla"], ep["obs_itrs"], -np.pi / 2, zn)
         self.xt, self.x, self.P, self.met = r["x_true"], r["x"], r["P"], r["metrics"]
-        if obs_out is not None:
+        if obs_out is not None and shards_out is not None:   # raw form: max delta_pos as ordered bits | packed counts | failures, spread
+            obs_out.copy_(torch.as_tensor(self.o.aer_obs(self.x, self.P, self.c2t[self.tick], self.ep["obs_lla"], self.ep["obs_itrs"])))
+            w = np.zeros((64, 4), dtype=np.uint64)               # over a few shards like the kernel's per-tile atomics
+            d = self.met[0]
+            for t0 in range(0, len(d), 4):
+                sh_ = (t0 // 4) % 64
+                tile = d[t0:t0 + 4]
+                w[sh_, 0] = max(w[sh_, 0], tile.view(np.uint64).max())
+                w[sh_, 1] += np.uint64((tile < 1e4).sum()) + (np.uint64((tile < 1e7).sum()) << np.uint64(32))
+                w[sh_, 2] += np.uint64((self.status[t0:t0 + 4] != 0).sum())
+            shards_out.copy_(torch.as_tensor(w.reshape(-1).view(np.float64)))
+            shards_clear.zero_()
+        elif obs_out is not None:
             self.pack_into(obs_out, stats_out)
 
     def pack_into(self, obs_out, stats_out):
@@ -44,7 +58,7 @@ class OracleLocalStepper:
                                       s.max(), 0, 0], dtype=torch.float64))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, raw=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -59,6 +73,7 @@ def _worker(rank, world, port, q):
     P = np.tile(ep["P0"], (m, 1, 1))
     sl = slice(plan.lo, plan.hi)
     local = OracleLocalStepper(xt[sl], x[sl], P[sl], ep, c2t, plan.lo)
+    local.raw_shards = raw
     sh = parallel.ShardedStepper(plan, local)
     outs = []
     for i in range(1, 6):
@@ -86,13 +101,16 @@ def test_shard_plan():
         assert all(p.local_action(-1) == -1 for p in plans)
 
 
-def test_sharded_env_matches_unsharded_world2():
+@pytest.mark.parametrize("raw", [False, True])
+def test_sharded_env_matches_unsharded_world2(raw):
+    """raw = True: the statistics cross the all-gather as raw shard words (what the HIP step kernel's atomics leave in the send
+    buffer: no fold launch) and every rank folds all ranks' words on arrival."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from ssa_gym_amd import parallel
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + (7 if raw else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, raw)) for r in range(2)]
     for p in procs:
         p.start()
     outs = q.get(timeout=120)
@@ -110,7 +128,11 @@ def test_sharded_env_matches_unsharded_world2():
         sh.step(a)
         obs, st = sh.global_obs().numpy(), sh.global_stats()
         assert np.array_equal(obs, outs[i][0])          # bit-identical observation vector
-        assert np.array_equal(st, outs[i][1])           # identical reward statistics (incl. global arg-max)
+        if raw:                                         # (the raw form carries no arg-max of sigma_pos, as on the GPU)
+            k = [parallel.STAT_MAX_DPOS, parallel.STAT_CNT_LT_1E4, parallel.STAT_CNT_LT_1E7, parallel.STAT_N_FAILED]
+            assert np.array_equal(st[k], outs[i][1][k]) and outs[i][1][parallel.STAT_ARGMAX_SPOS] == -1
+        else:
+            assert np.array_equal(st, outs[i][1])       # identical reward statistics (incl. global arg-max)
 
 
 def test_bench_self_launches_its_ranks_dry_run():
