@@ -156,7 +156,7 @@ class HotPathEngine:
             p.stat_shards_clear = 0
             if shards_out:      # raw-shard consumer (include/ssa_hip.h: stat_shards_clear): no fold, no `stats`
                 p.stat_shards, p.stats, p.stat_shards_clear = shards_out, 0, shards_clear
-            ent = (p, C.byref(p), int(p.stats))
+            ent = (p, C.byref(p), int(p.stats or 0))
             if len(self._pcache) > 4096:
                 self._pcache.clear()
             self._pcache[key] = ent
