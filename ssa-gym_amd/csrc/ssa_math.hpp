@@ -162,7 +162,7 @@ SSA_DEV bool rv2coe_elliptic(const double* r, const double* v, double* coe)
     double p = dot3(h, h) * inv_mu;
     double hn = sqrt_fast(dot3(h, h));
     const double inv_hn = rcp_nr(hn);
-    double inc = acos(h[2] * inv_hn);
+    double inc = acos(h[2] / hn);   // (IEEE division: for an equatorial orbit h_z / |h| must be exactly 1, not 1 + 1 ulp -> acos NaN)
     bool circular = ecc < tol, equatorial = fabs(inc) < tol;
     double raan, argp, nu;
     if (equatorial && !circular) {
