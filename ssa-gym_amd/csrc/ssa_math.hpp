@@ -160,8 +160,8 @@ SSA_DEV bool rv2coe_elliptic(const double* r, const double* v, double* coe)
     double e[3] = {(c1 * r[0] - rv * v[0]) * inv_mu, (c1 * r[1] - rv * v[1]) * inv_mu, (c1 * r[2] - rv * v[2]) * inv_mu};
     double ecc = sqrt_fast(dot3(e, e));
     double p = dot3(h, h) * inv_mu;
-    double hn = sqrt_fast(dot3(h, h));
-    const double inv_hn = rcp_nr(hn);
+    double hn = sqrt(dot3(h, h));   // correctly rounded, as is h_z / |h| below: the equatorial test |inc| < 1e-8 holds only
+    const double inv_hn = rcp_nr(hn);   // when that quotient is EXACTLY 1 (acos(1 - 1 ulp) = 1.5e-8), farnocchia.py:278
     double inc = acos(h[2] / hn);   // (IEEE division: for an equatorial orbit h_z / |h| must be exactly 1, not 1 + 1 ulp -> acos NaN)
     bool circular = ecc < tol, equatorial = fabs(inc) < tol;
     double raan, argp, nu;
