@@ -1079,6 +1079,14 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
             }
         }
         SSA_TR(9);
+        // raw-shard consumers (stat_shards_clear): the first tile's wavefront zeroes the shard set the NEXT step accumulates
+        // into -- at the very end, so that no wavefront waits for this pointer's kernarg line before its tile loads
+        if (tile == 0) {
+            if (p.stat_shards_clear) {
+                unsigned long long* z = (unsigned long long*)p.stat_shards_clear;
+                for (int i = lane; i < p.n_env * SSA_STAT_SHARDS * 4; i += 64) z[i] = 0ull;
+            }
+        }
     }
 }
 
@@ -1128,10 +1136,6 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(const dou
 {
     __shared__ Tiles t;
     int lane = threadIdx.x;
-    if (blockIdx.x == 0 && k_arg.p.stat_shards_clear) {   // zero the shard set the NEXT step will accumulate into (raw-shard consumers)
-        unsigned long long* z = (unsigned long long*)k_arg.p.stat_shards_clear;
-        for (int i = threadIdx.x; i < k_arg.p.n_env * SSA_STAT_SHARDS * 4; i += 64) z[i] = 0ull;
-    }
     if ((int)blockIdx.x >= nwork) {   // deferred fold of the previous step's statistics: one extra wavefront per env
         fold_stat_shards((unsigned long long*)k_arg.p.stat_shards_prev, k_arg.p.stats_prev, (int)blockIdx.x - nwork, lane);
         return;
