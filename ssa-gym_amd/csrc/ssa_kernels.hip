@@ -394,9 +394,9 @@ SSA_DEV void observe_rows(Tiles& t, int g, int l)
             double a0 = t.X[g * 6 + off] - t.T[g * 6 + off];
             double a1 = t.X[g * 6 + off + 1] - t.T[g * 6 + off + 1];
             double a2 = t.X[g * 6 + off + 2] - t.T[g * 6 + off + 2];
-            v = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
-        } else {
-            v = sqrt(t.P[g * 36 + 7 * off] + t.P[g * 36 + 7 * (off + 1)] + t.P[g * 36 + 7 * (off + 2)]);
+            v = sqrt_fast(a0 * a0 + a1 * a1 + a2 * a2);
+        } else {   // (a negative sum -- indefinite covariance -- gives NaN, as numpy's sqrt)
+            v = sqrt_fast(t.P[g * 36 + 7 * off] + t.P[g * 36 + 7 * (off + 1)] + t.P[g * 36 + 7 * (off + 2)]);
         }
         t.Met[g * 4 + l] = v;
     }
@@ -532,7 +532,9 @@ SSA_DEV void chol_step(const double (&a)[6], double (&uc)[6], int lc, bool& ok)
         v = fma(-uij, uc[i], v);                  // lane J: ajj -= U[i][J]^2 ; lane c > J: A[J][c] -= U[i][J] U[i][c]
     }
     const double y = row_bcast<J>(rsqrt_nr(v));   // 1 / sqrt(pivot) of lane J; NaN / inf when the pivot is <= 0 or NaN
-    ok = ok && (y > 0.0) && (y <= 1.79769313486231570e308);
+    // a bad pivot poisons everything downstream (row J becomes inf / NaN, every later pivot in its column picks up -inf or NaN),
+    // so the positivity test of the LAST pivot covers all six
+    if (J == 5) ok = ok && (y > 0.0) && (y <= 1.79769313486231570e308);
     uc[J] = (lc >= J) ? v * y : 0.0;              // lane J: ajj / sqrt(ajj) = the diagonal entry
 }
 // factorises the matrix at Pg (row-major 6x6 in LDS) in the calling row `grow`; the factor's column lc stays in uc[]
@@ -788,7 +790,9 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         }
     }
     wave_lds_sync();
+#if !(defined(SSA_ABLATE) && (SSA_ABLATE & 8))
     moment_sums_mfma(t, lane);
+#endif
     wave_lds_sync();
     SSA_TR(4);
     double xb_l = 0.0;   // lanes 0..5: component l of the prior mean
@@ -1008,7 +1012,9 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     }
     if (l == 0) t.St[g] = st_new;
     wave_lds_sync();
+#if !(defined(SSA_ABLATE) && (SSA_ABLATE & 16))
     observe_rows(t, g, l);
+#endif
     // O4 in the epilogue (atomics-statistics path): the (az, el, range, trace P) block of the NEW state -- the 'aer'
     // observation mode and the multi-GPU all-gather payload -- from the tiles, so that no second pass over x / P (the
     // former post kernel: 6.7 MB re-read per 20 000 objects plus a launch) is needed
@@ -1018,6 +1024,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     wave_lds_sync();
     SSA_TR(7);
     {
+#if !(defined(SSA_ABLATE) && (SSA_ABLATE & 32))
         store_tile<TILE != 1>(t, p, lane, base, cnt);
         SSA_TR(8);
         // O3 by sharded atomics: max delta_pos (as ordered bits: non-negative doubles and NaN order like unsigned
@@ -1079,6 +1086,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
             }
         }
         SSA_TR(9);
+#endif
         // raw-shard consumers (stat_shards_clear): the first tile's wavefront zeroes the shard set the NEXT step accumulates
         // into -- at the very end, so that no wavefront waits for this pointer's kernarg line before its tile loads
         if (tile == 0) {
