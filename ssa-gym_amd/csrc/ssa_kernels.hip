@@ -538,6 +538,7 @@ SSA_DEV void chol_step(const double (&a)[6], double (&uc)[6], int lc, bool& ok)
     uc[J] = (lc >= J) ? v * y : 0.0;              // lane J: ajj / sqrt(ajj) = the diagonal entry
 }
 // factorises the matrix at Pg (row-major 6x6 in LDS) in the calling row `grow`; the factor's column lc stays in uc[]
+template <bool PLAIN>   // PLAIN: the jitter-free first attempt (no diagonal select / add on the common path)
 SSA_DEV bool chol_row_regs(const double* Pg, double scale, double jit, int grow, int l, double (&uc)[6])
 {
     const int lc = l < 6 ? l : 5;   // lanes 6..15 shadow column 5 (their stores are masked)
@@ -549,7 +550,7 @@ SSA_DEV bool chol_row_regs(const double* Pg, double scale, double jit, int grow,
     for (int j = 0; j < 6; ++j) {
         const double pv = Pg[j * 6 + lc];
         ok = ok && (fabs(pv) <= 1.79769313486231570e308);
-        a[j] = scale * pv + ((lc == j) ? jit : 0.0);
+        a[j] = PLAIN ? scale * pv : scale * pv + ((lc == j) ? jit : 0.0);
     }
     ok = ((__ballot(!ok) >> (grow * 16)) & 0xFFFFull) == 0;
     chol_step<0>(a, uc, lc, ok);
@@ -581,7 +582,7 @@ SSA_DEV int robust_chol_row_lds(Tiles& t, double scale, int g, int l)
     double uc[6];
     int rung = 16;
     {
-        const bool ok = chol_row_regs(&t.P[g * 36], scale, 0.0, g, l, uc);
+        const bool ok = chol_row_regs<true>(&t.P[g * 36], scale, 0.0, g, l, uc);
         if (ok) {
             chol_store_rows(&t.UA[g * 36], uc, l);
             rung = -1;
@@ -602,7 +603,7 @@ SSA_DEV int robust_chol_row_lds(Tiles& t, double scale, int g, int l)
             int found = 16;
             if (__ballot(!finite) == 0ull) {
                 for (int pass = 0; pass < 4; ++pass) {
-                    const bool okr = chol_row_regs(Pg, scale, JITTER[pass * 4 + g], g, l, uc);   // row g tries rung 4 pass + g
+                    const bool okr = chol_row_regs<false>(Pg, scale, JITTER[pass * 4 + g], g, l, uc);   // row g tries rung 4 pass + g
                     const unsigned long long won = __ballot(okr);
                     if (won != 0ull) {
                         const int win = (won & 0xFFFFull) ? 0 : ((won >> 16) & 0xFFFFull) ? 1 : ((won >> 32) & 0xFFFFull) ? 2 : 3;
@@ -1134,13 +1135,13 @@ __global__ void __launch_bounds__(64) reward_fold_kernel(unsigned long long* __r
 // MULTI = false is the one-tile-per-wavefront instance (every launch up to 20 480 objects): no loop, no staging
 // registers.
 typedef const __attribute__((address_space(4))) StepK* KernargPtr;
-// The four leading pointer arguments repeat k_arg.p.{P_in, x_in, x_true_in, status}: as plain scalar arguments they are
-// PRELOADED into SGPRs at wavefront launch (-amdgpu-kernarg-preload-count, _build.py), so the tile's loads -- the first link
+// The leading arguments -- the two tile counts and the pointers k_arg.p.{P_in, x_in, x_true_in, status} repeated -- are plain
+// scalars: they are PRELOADED into SGPRs at wavefront launch (-amdgpu-kernarg-preload-count, _build.py), so the tile's loads -- the first link
 // of every wavefront's dependency chain -- leave without waiting for a scalar-memory round trip to the kernarg segment.
 template <int PROP, bool MULTI>
-__global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(const double* pre_P_in, const double* pre_x_in,
-                                                                       const double* pre_x_true_in, const int32_t* pre_status,
-                                                                       const StepK k_arg, int ntiles, int nwork)
+__global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(int ntiles, int nwork, const double* pre_P_in,
+                                                                       const double* pre_x_in, const double* pre_x_true_in,
+                                                                       const int32_t* pre_status, const StepK k_arg)
 {
     __shared__ Tiles t;
     int lane = threadIdx.x;
@@ -1177,7 +1178,7 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(const dou
         // instead of being carried around the loop in registers
         asm volatile("" : "+s"(kp));
         asm volatile("" : "+v"(lane));
-        const StepK& k = *(const StepK*)((const char*)kp + 4 * sizeof(void*));   // behind the four preloaded pointer arguments
+        const StepK& k = *(const StepK*)((const char*)kp + 2 * sizeof(int) + 4 * sizeof(void*));   // behind the preloaded scalar arguments
         const int64_t base = (int64_t)tile * OBJ_PER_WAVE;
         const int cnt = (int)((total - base) < OBJ_PER_WAVE ? (total - base) : OBJ_PER_WAVE);
         const int nt = tile + nwork;
@@ -1925,13 +1926,13 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
     if (mask & 1u) {   // (ev0, ev1: dispatch timestamps of this kernel for ssa_env_step_profiled_f64, else null)
         const int nt = (int)ntiles;
         if (per_wave == 1) {
-            if (prop == SSA_PROP_FG) hipExtLaunchKernelGGL((step_fast_kernel<1, false>), grid, block, 0, s, ev0, ev1, 0, p->P_in, p->x_in, p->x_true_in, p->status, k, nt, nwork);
-            else if (prop == SSA_PROP_ELEMENTS) hipExtLaunchKernelGGL((step_fast_kernel<0, false>), grid, block, 0, s, ev0, ev1, 0, p->P_in, p->x_in, p->x_true_in, p->status, k, nt, nwork);
-            else hipExtLaunchKernelGGL((step_fast_kernel<2, false>), grid, block, 0, s, ev0, ev1, 0, p->P_in, p->x_in, p->x_true_in, p->status, k, nt, nwork);
+            if (prop == SSA_PROP_FG) hipExtLaunchKernelGGL((step_fast_kernel<1, false>), grid, block, 0, s, ev0, ev1, 0, nt, nwork, p->P_in, p->x_in, p->x_true_in, p->status, k);
+            else if (prop == SSA_PROP_ELEMENTS) hipExtLaunchKernelGGL((step_fast_kernel<0, false>), grid, block, 0, s, ev0, ev1, 0, nt, nwork, p->P_in, p->x_in, p->x_true_in, p->status, k);
+            else hipExtLaunchKernelGGL((step_fast_kernel<2, false>), grid, block, 0, s, ev0, ev1, 0, nt, nwork, p->P_in, p->x_in, p->x_true_in, p->status, k);
         } else {
-            if (prop == SSA_PROP_FG) hipExtLaunchKernelGGL((step_fast_kernel<1, true>), grid, block, 0, s, ev0, ev1, 0, p->P_in, p->x_in, p->x_true_in, p->status, k, nt, nwork);
-            else if (prop == SSA_PROP_ELEMENTS) hipExtLaunchKernelGGL((step_fast_kernel<0, true>), grid, block, 0, s, ev0, ev1, 0, p->P_in, p->x_in, p->x_true_in, p->status, k, nt, nwork);
-            else hipExtLaunchKernelGGL((step_fast_kernel<2, true>), grid, block, 0, s, ev0, ev1, 0, p->P_in, p->x_in, p->x_true_in, p->status, k, nt, nwork);
+            if (prop == SSA_PROP_FG) hipExtLaunchKernelGGL((step_fast_kernel<1, true>), grid, block, 0, s, ev0, ev1, 0, nt, nwork, p->P_in, p->x_in, p->x_true_in, p->status, k);
+            else if (prop == SSA_PROP_ELEMENTS) hipExtLaunchKernelGGL((step_fast_kernel<0, true>), grid, block, 0, s, ev0, ev1, 0, nt, nwork, p->P_in, p->x_in, p->x_true_in, p->status, k);
+            else hipExtLaunchKernelGGL((step_fast_kernel<2, true>), grid, block, 0, s, ev0, ev1, 0, nt, nwork, p->P_in, p->x_in, p->x_true_in, p->status, k);
         }
     }
     if (fast_stats) {   // (the aer_out payload, if any, was the step kernel's epilogue) a one-wave fold finishes the step

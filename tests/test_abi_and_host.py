@@ -187,12 +187,12 @@ def test_step_kernels_keep_their_register_budget(tmp_path):
         kern[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1)) for k in
                       ("vgpr_count", "sgpr_count", "private_segment_fixed_size", "vgpr_spill_count", "group_segment_fixed_size")}
     # the grid-stride instance re-derives its argument block from the kernarg segment pointer: the by-value StepK must sit
-    # right behind the four preloaded pointer arguments (a wrong offset there is a wild-pointer GPU fault, not a wrong number)
+    # right behind the six preloaded scalar arguments (offset 40) (a wrong offset there is a wild-pointer GPU fault, not a wrong number)
     for blk in notes.split("- .agpr_count:")[1:]:
         if "step_fast_kernel" in re.search(r"\.name:\s+(\S+)", blk).group(1):
             offs = [int(v) for v in re.findall(r"\.offset:\s+(\d+)\s+\.size:\s+\d+\s+\.value_kind:\s+by_value", blk)]
             kinds = re.findall(r"\.value_kind:\s+(\w+)", blk)
-            assert kinds[:4] == ["global_buffer"] * 4 and 32 in offs, (kinds[:6], offs)
+            assert kinds[:6] == ["by_value"] * 2 + ["global_buffer"] * 4 and 40 in offs, (kinds[:7], offs)
     hot = [k for k in kern if "step_fast_kernel" in k or "rollout_kernel" in k]
     assert len(hot) == 9, hot                      # 3 propagators x {one tile, multi tile} + 3 rollout instances
     for k in hot:
