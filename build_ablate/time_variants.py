@@ -16,7 +16,7 @@ for path in sorted(glob.glob(os.path.join(ROOT,'build_ablate','*.so'))):
     _lib.ABI_VERSION=probe.ssa_abi_version()
     lib=_lib.load()
     _lib.SIGNATURES=sig
-    for prop in os.environ.get('PROPS','fg,elements').split(','):
+    for prop in os.environ.get('PROPS','fg').split(','):
         consts=host.make_consts(pb["Q"], pb["R"], 1e-4, 2.0, -3, 20.0, -np.pi/2, pb["obs_lla"], obs_type='aer', propagator=prop)
         z=torch.zeros((1,480,m,3),dtype=torch.float64,device='cuda')
         eng=engine.HotPathEngine(consts,m,1,pb["trans"],z,history=2)

@@ -111,6 +111,10 @@ def load():
         raise SsaHipError(
             "libssa_hip.so is not built (%s). The ssa-gym hot path has no CPU fallback: run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc)." % path)
+    # One HIP/HSA runtime per process: torch (which owns the device memory and streams handed to this library) ships its own
+    # libamdhip64 / libhsa-runtime64.  Loaded after torch, libssa_hip.so binds to those; loaded first it would pull in
+    # /opt/rocm's copies and the second runtime to open the device finds none (hipErrorNoDevice on the first launch).
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

@@ -10,6 +10,7 @@
 // with block-contiguous (fully coalesced) global loads and stores; the 13-point mean is a
 // DPP row reduction; the covariance outer products run from LDS.
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
@@ -1859,7 +1860,13 @@ static GeoK make_geo(const ssa_consts* c)
     g.sum_wm_m1 = c->sum_wm_m1;
     return g;
 }
-static inline int launch_status() { return hipGetLastError() == hipSuccess ? SSA_OK : SSA_E_LAUNCH; }
+static inline int launch_status()
+{
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return SSA_OK;
+    fprintf(stderr, "libssa_hip: kernel launch failed: %s (%s)\n", hipGetErrorName(e), hipGetErrorString(e));   // fail loudly
+    return SSA_E_LAUNCH;
+}
 static inline unsigned nblk(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
 }  // namespace ssa
