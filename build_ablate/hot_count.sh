@@ -20,9 +20,9 @@ if a in m: m=m.replace(a,"if (false) {")
 open(p,'w').write(m)
 PY
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=fast -mllvm -disable-machine-licm -mllvm -amdgpu-kernarg-preload-count=8 -gline-tables-only -S --cuda-device-only ${EXTRA} -o $W/hot.s $W/ssa-gym_amd/csrc/ssa_kernels.hip 2>/dev/null
-python3 /root/repo/build_ablate/isa_by_line.py $W/hot.s '_ZN3ssa16step_fast_kernelILi1ELb0EEEvPKdS2_S2_PKiNS_5StepKEii' --ops > $W/lines.txt
+python3 /root/repo/build_ablate/isa_by_line.py $W/hot.s '_ZN3ssa16step_fast_kernelILi1ELb0EEEviiPKdS2_S2_PKiNS_5StepKE' --ops > $W/lines.txt
 tail -2 $W/lines.txt | head -1
 cp $W/lines.txt /tmp/isa/hot_lines_latest.txt
 grep -A3 "step_fast_kernelILi1ELb0EEEvNS_5StepKEii$" $W/hot.s | head -0
-awk '/\.name: *_ZN3ssa16step_fast_kernelILi1ELb0EEEvPKd/{f=1} f&&/vgpr_count|sgpr_count|private_segment_fixed|vgpr_spill/{print} f&&/wavefront_size/{exit}' $W/hot.s
+awk '/\.name: *_ZN3ssa16step_fast_kernelILi1ELb0EEEvii/{f=1} f&&/vgpr_count|sgpr_count|private_segment_fixed|vgpr_spill/{print} f&&/wavefront_size/{exit}' $W/hot.s
 rm -rf $W

@@ -636,6 +636,30 @@ SSA_DEV void aer_obs_row(const double* x, const double* P, const ssa_step_params
     for (int c = 0; c < 4; ++c) p.aer_out[obj * 4 + c] = (fabs(v[c]) <= 1.79769313486231570e308) ? v[c] : 0.001;
 }
 
+// The same block in the step kernel's epilogue, from the tiles, on lanes 0..3 of the object's row: lane c produces component
+// c.  Azimuth (lane 0) and elevation (lane 1) are both ONE atan2 -- az = atan2(n, e), el = atan2(u, hypot(e, n)) -- so the
+// two lanes walk the same instruction stream once (hx_aer evaluates them one after the other), lane 2 keeps the range,
+// lane 3 trace(P); one 8-byte store per lane, 32 contiguous bytes per object.
+SSA_DEV void aer_obs_tile(const Tiles& t, const ssa_step_params& p, const ssa_consts& C, int g, int l, int e, int64_t obj)
+{
+    const int tix = p.env_time[e] + p.time_offset;
+    const double* M = p.trans + (int64_t)((p.n_time > 0) ? tix % p.n_time : 0) * 9;
+    const double* x = &t.X[g * 6];
+    const double* P = &t.P[g * 36];
+    double d[3], R[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d[i] = M[i * 3] * x[0] + M[i * 3 + 1] * x[1] + M[i * 3 + 2] * x[2] - C.obs_itrs[i];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R[j] = C.enu[j] * d[0] + C.enu[3 + j] * d[1] + C.enu[6 + j] * d[2];
+    const double h2 = R[0] * R[0] + R[1] * R[1];
+    const double rt = sqrt_fast((l == 1) ? h2 : d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);   // lane 1: hypot(e, n); others: the range
+    double a = atan2_fast((l == 1) ? R[2] : R[1], (l == 1) ? rt : R[0]);
+    if (l == 0 && a < 0.0) a += TWO_PI;
+    const double tr = P[0] + P[7] + P[14] + P[21] + P[28] + P[35];
+    const double v = (l < 2) ? a : (l == 2) ? rt : tr;
+    p.aer_out[obj * 4 + l] = (fabs(v) <= 1.79769313486231570e308) ? v : 0.001;
+}
+
 #ifdef SSA_TRACE   // diagnostic build only (build_ablate/wave_timeline.py): per-wave phase timestamps, 100 MHz wall clock
 __device__ unsigned long long g_trace[16384 * 16];
 #define SSA_TR(k) do { if (lane == 0 && tile < 16384) g_trace[tile * 16 + (k)] = wall_clock64(); } while (0)
@@ -1021,7 +1045,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     // observation mode and the multi-GPU all-gather payload -- from the tiles, so that no second pass over x / P (the
     // former post kernel: 6.7 MB re-read per 20 000 objects plus a launch) is needed
     if (p.aer_out && p.stat_shards) {
-        if (l == 0 && valid) aer_obs_row(&t.X[g * 6], &t.P[g * 36], p, C, e, obj);
+        if (l < 4 && valid) aer_obs_tile(t, p, C, g, l, e, obj);
     }
     wave_lds_sync();
     SSA_TR(7);

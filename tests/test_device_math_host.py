@@ -102,3 +102,28 @@ def test_fast_sincos_and_reciprocals(hm):
     r, q = np.empty_like(v), np.empty_like(v)
     hm.hm_recip(_p(v), C.c_long(len(v)), _p(r), _p(q))
     assert np.abs(r * v - 1).max() < 4.5e-16 and np.abs(q * q * v - 1).max() < 9e-16     # from a 1e-8 estimate: third order
+
+
+def test_fast_atan2(hm):
+    """atan2_fast (azimuth, and elevation as atan2(u, hypot(e, n))): error < 1.5 ulp (6e-16 at pi) over every octant, the fold points
+    and the axes; atan2(0, 0) = 0 and the sign conventions of libm (azimuth wraps to [0, 2 pi) from those)."""
+    rs = np.random.RandomState(2)
+    ang = rs.uniform(-np.pi, np.pi, 300000)
+    rad = 10.0 ** rs.uniform(-3, 8, len(ang))
+    y = np.concatenate([rad * np.sin(ang), [0.0, 0.0, 0.0, 1.0, -1.0, 1.0, 1.0, -1.0, np.tan(np.pi / 8), 1e-300, 3.0]])
+    x = np.concatenate([rad * np.cos(ang), [0.0, 1.0, -1.0, 0.0, 0.0, 1.0, -1.0, -1.0, 1.0, 1.0, 1e300]])
+    r = np.empty_like(x)
+    hm.hm_atan2_fast(_p(y), _p(x), C.c_long(len(x)), _p(r))
+    ref = np.arctan2(y.astype(np.longdouble), x.astype(np.longdouble))
+    err = np.abs((r - ref).astype(np.float64))
+    assert err.max() < 6e-16 and (err / np.spacing(np.maximum(np.abs(r), 0.5))).max() < 1.5, (err.max(), np.argmax(err))
+    small = np.abs(ref) < 0.3
+    assert (err[small] / np.maximum(np.abs(ref[small]).astype(np.float64), 1e-300)).max() < 5e-16   # relative where the angle is small
+    assert r[-11] == 0.0 and r[-10] == 0.0 and r[-9] == np.pi and r[-8] == np.pi / 2 and r[-7] == -np.pi / 2
+    # elevation: asin(u / r) == atan2(u, hypot(e, n))
+    e, n, u = rs.normal(size=(3, 100000)) * 1e6
+    el = np.empty_like(u)
+    hm.hm_atan2_fast(_p(u), _p(np.hypot(e, n)), C.c_long(len(u)), _p(el))
+    el_, nl, ul = (v.astype(np.longdouble) for v in (e, n, u))
+    ref = np.arcsin(ul / np.sqrt(el_ * el_ + nl * nl + ul * ul))      # (in fp64 asin(u / r) itself loses digits towards the zenith)
+    assert np.abs((el - ref).astype(np.float64)).max() < 4e-16
