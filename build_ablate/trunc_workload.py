@@ -1,0 +1,22 @@
+"""PMC workload for the truncation builds (build_ablate/build_trunc.sh): 50 launches of the one-tile FG step kernel, every one from the
+SAME healthy input state (slot 0 -> slot 1; a truncated wave writes nothing, so the state must not ping-pong)."""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.argv = ['bench.py']
+import bench
+from ssa_gym_amd import _lib, _build, host, engine
+if os.environ.get('LIB'):
+    _build.LIB = os.environ['LIB']
+m = int(os.environ.get('M', '20000'))
+pb = bench.build_problem(m, seed=100)
+consts = host.make_consts(pb["Q"], pb["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, pb["obs_lla"], obs_type='aer', propagator=os.environ.get('PROP', 'fg'))
+z = torch.zeros((1, 480, m, 3), dtype=torch.float64, device='cuda')
+eng = engine.HotPathEngine(consts, m, 1, pb["trans"], z, history=2)
+eng.load_state(0, pb["x_true"], pb["x"], np.broadcast_to(pb["P0"], (m, 6, 6)))
+act = int(os.environ.get('ACTION', '-1'))
+for k in range(50):
+    eng.set_actions([act])
+    eng.launch_step(0, 1, 1)
+torch.cuda.synchronize()

@@ -285,7 +285,7 @@ struct alignas(16) Tiles {
     double P[OBJ_PER_WAVE * 36];       // P_in, later P_out
     double X[OBJ_PER_WAVE * 6];        // x_in, then sigma_0', then x_out
     double T[OBJ_PER_WAVE * 6];        // x_true_in, later x_true_out
-    double UA[OBJ_PER_WAVE * 48];      // Cholesky factor rows [4][36]; later the moment sums A[4][6][8] of the transform
+    double UA[OBJ_PER_WAVE * 36];      // Cholesky factor rows [4][36] (the transform's moment sums stay in registers)
     double D[408];                     // centred propagated sigma points (see above); scratch of the update
     double M[OBJ_PER_WAVE * 12];       // s = Wi sum d_i | m' = mean - sigma_0'
     double Q[36];                      // process noise (read per covariance entry with a lane-dependent index)
@@ -317,17 +317,17 @@ SSA_DEV void tile_issue_from(TileRegs& r, const double* P_in, const double* x_in
     if (cnt <= 0) return;
     const double* Pin = P_in + base * 36;
     if (lane < cnt * 18) r.main = load16(Pin + 2 * lane);
-    if (lane < 8) {
-        if (64 + lane < cnt * 18) r.aux = load16(Pin + 2 * (64 + lane));
-    } else if (lane >= 32 && lane < 44) {
-        const int i = lane - 32;
-        if (i < cnt * 3) r.aux = load16(x_in + base * 6 + 2 * i);
-    } else if (lane >= 48 && lane < 60) {
-        const int i = lane - 48;
-        if (i < cnt * 3) r.aux = load16(x_true_in + base * 6 + 2 * i);
-    } else if (lane >= 60) {
-        const int i = lane - 60;
-        r.aux.x = __hiloint2double(0, (i < cnt) ? status[base + i] : SSA_ST_PREDICT_NAN);
+    // the rest of the tile -- lanes [0, 8): the tail of P, [32, 44): x, [48, 60): x_true -- is ONE 16-byte load per lane whose
+    // source is selected by lane range (a tree of nested lane-range branches cost 80 scalar instructions and their branch
+    // latencies in front of the loads); a ragged tile (cnt < 4) shortens every range through `lim`
+    const bool sX = lane >= 32, sT = lane >= 48;
+    const int i = lane - (sT ? 48 : sX ? 32 : 0);
+    const int lim = sX ? cnt * 3 : cnt * 18 - 64;
+    const double* src = sT ? x_true_in + base * 6 : sX ? x_in + base * 6 : Pin + 128;
+    if (i < lim) r.aux = load16(src + 2 * i);
+    if (lane >= 60) {
+        const int k = lane - 60;
+        r.aux.x = __hiloint2double(0, (k < cnt) ? status[base + k] : SSA_ST_PREDICT_NAN);
     }
 }
 SSA_DEV void tile_issue(TileRegs& r, const ssa_step_params& p, int lane, int64_t base, int cnt)
@@ -337,10 +337,11 @@ SSA_DEV void tile_issue(TileRegs& r, const ssa_step_params& p, int lane, int64_t
 SSA_DEV void tile_commit(Tiles& t, const TileRegs& r, int lane)
 {
     reinterpret_cast<double2*>(t.P)[lane] = r.main;
-    if (lane < 8) reinterpret_cast<double2*>(t.P)[64 + lane] = r.aux;
-    else if (lane >= 32 && lane < 44) reinterpret_cast<double2*>(t.X)[lane - 32] = r.aux;
-    else if (lane >= 48 && lane < 60) reinterpret_cast<double2*>(t.T)[lane - 48] = r.aux;
-    else if (lane >= 60) t.St[lane - 60] = __double2loint(r.aux.x);
+    const bool sX = lane >= 32, sT = lane >= 48;
+    const int i = lane - (sT ? 48 : sX ? 32 : 0);
+    double* dst = sT ? t.T : sX ? t.X : t.P + 128;
+    if (i < (sX ? 12 : 8)) reinterpret_cast<double2*>(dst)[i] = r.aux;
+    if (lane >= 60) t.St[lane - 60] = __double2loint(r.aux.x);
 }
 typedef double v2d __attribute__((ext_vector_type(2)));
 // one 16-byte lane of a tile store.  NT (non-temporal): for launches of up to 20 480 objects and for rollouts the
@@ -360,26 +361,30 @@ SSA_DEV void store16(double* dst, const double* src)
 template <bool NT>
 SSA_DEV void store_tile(const Tiles& t, const ssa_step_params& p, int lane, int64_t base, int cnt)
 {
-    for (int i = lane; i < 72; i += 64)
-        if (i < cnt * 18) store16<NT>(p.P_out + base * 36 + 2 * i, t.P + 2 * i);
-    if (lane < 12) {
-        if (lane < cnt * 3) store16<NT>(p.x_out + base * 6 + 2 * lane, t.X + 2 * lane);
-    } else if (lane >= 16 && lane < 28) {
-        const int i = lane - 16;
-        if (i < cnt * 3) store16<NT>(p.x_true_out + base * 6 + 2 * i, t.T + 2 * i);
-    } else if (lane >= 32 && lane < 36) {
-        const int i = lane - 32;
+    if (lane < cnt * 18) store16<NT>(p.P_out + base * 36 + 2 * lane, t.P + 2 * lane);
+    {   // lanes [0, 12): x | [16, 28): x_true | [32, 40): the tail of P | [40, 64): obs -- one 16-byte store per lane, destination and
+        // LDS source selected by lane range (see tile_issue_from)
+        const bool sT = lane >= 16, sP = lane >= 32, sO = lane >= 40;
+        const int i = lane - (sO ? 40 : sP ? 32 : sT ? 16 : 0);
+        const int lim = sO ? cnt * 6 : sP ? cnt * 18 - 64 : cnt * 3;
+        double* dst = sO ? p.obs + base * 12 : sP ? p.P_out + base * 36 + 128 : sT ? p.x_true_out + base * 6 : p.x_out + base * 6;
+        const double* src = sO ? t.Obs : sP ? t.P + 128 : sT ? t.T : t.X;
+        if (i < lim) store16<NT>(dst + 2 * i, src + 2 * i);
+    }
+    if (lane >= 12 && lane < 16) {
+        const int i = lane - 12;
         if (i < cnt) p.status[base + i] = t.St[i];
-    } else if (lane >= 40 && lane < 64) {
-        const int i = lane - 40;
-        if (i < cnt * 6) store16<NT>(p.obs + base * 12 + 2 * i, t.Obs + 2 * i);
     }
     if (lane < 16) {   // metrics [E][4][m]: four 32-byte runs per tile
         const int kk = lane >> 2, jj = lane & 3;
         if (jj < cnt) {
             const int64_t obj = base + jj;
-            const int64_t e = (p.n_env > 1) ? (int64_t)((uint32_t)obj / (uint32_t)p.n_obj) : 0, j = obj - e * p.n_obj;
-            p.metrics[(e * 4 + kk) * p.n_obj + j] = t.Met[jj * 4 + kk];
+            if (p.n_env == 1) {   // (scalar row stride, one 64-bit multiply-add per lane)
+                p.metrics[(int64_t)kk * p.n_obj + obj] = t.Met[jj * 4 + kk];
+            } else {
+                const int64_t e = (int64_t)((uint32_t)obj / (uint32_t)p.n_obj), j = obj - e * p.n_obj;
+                p.metrics[(e * 4 + kk) * p.n_obj + j] = t.Met[jj * 4 + kk];
+            }
         }
     }
 }
@@ -410,8 +415,10 @@ SSA_DEV void observe_rows(Tiles& t, int g, int l)
 // (result) index lane bits 5:4, its i / j index lane bits 1:0 (measured, build_ablate/probe): block b = object b, three
 // k-chunks of four sigma points, 4x4 tiles (0,0), (0,1), (1,1) of the symmetric 8x8 result = 9 instructions of 16 cycles
 // on the otherwise idle matrix pipe, operands by six conflict-free ds_read_b64.  Lane (hi, mid, lo) ends up with
-// A^(mid)[hi][lo], A^(mid)[hi][4 + lo], A^(mid)[4 + hi][4 + lo] and stores them to t.UA.
-SSA_DEV void moment_sums_mfma(Tiles& t, int lane)
+// A^(mid)[hi][lo], A^(mid)[hi][4 + lo], A^(mid)[4 + hi][4 + lo] and KEEPS them in registers: covariance_finish() below turns
+// them into the entries of P in the same lanes.  Only the column of sums A[a][6] goes to LDS (t.M[mid][a]: the mean needs it).
+struct Moments { double c00, c01, c11; };
+SSA_DEV Moments moment_sums_mfma(Tiles& t, int lane)
 {
     const int hi = lane >> 4, mid = (lane >> 2) & 3, lo = lane & 3;
     const double* src = &t.D[dbase(mid) + hi * 8 + lo];
@@ -421,32 +428,53 @@ SSA_DEV void moment_sums_mfma(Tiles& t, int lane)
         a0[kc] = src[kc * 32];
         a1[kc] = src[kc * 32 + 4];
     }
-    double c00 = 0.0, c01 = 0.0, c11 = 0.0;
+    Moments mo = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int kc = 0; kc < 3; ++kc) {
-        c00 = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[kc], a0[kc], c00, 0, 0, 0);
-        c01 = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[kc], a1[kc], c01, 0, 0, 0);
-        c11 = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[kc], a1[kc], c11, 0, 0, 0);
+        mo.c00 = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[kc], a0[kc], mo.c00, 0, 0, 0);
+        mo.c01 = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[kc], a1[kc], mo.c01, 0, 0, 0);
+        mo.c11 = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[kc], a1[kc], mo.c11, 0, 0, 0);
     }
-    double* A = &t.UA[mid * 48];
-    A[hi * 8 + lo] = c00;
-    A[hi * 8 + 4 + lo] = c01;
-    if (hi < 2) A[(4 + hi) * 8 + 4 + lo] = c11;
+    if (lo == 2) {                                   // column 6 of the blocks (0,1) and (1,1): the sums over the sigma points
+        t.M[mid * 12 + hi] = mo.c01;
+        if (hi < 2) t.M[mid * 12 + 4 + hi] = mo.c11;
+    }
+    return mo;
 }
 
 // U3 (second half): P = sum Wc_i y_i y_i^T + Q with y_i = sigma_i' - x, expanded around sigma_0':
-//   P = Wi A - m' s^T - s m'^T + sum(Wc) m' m'^T + Q       (A from moment_sums_mfma; s, m' in t.M)
-SSA_DEV void covariance_rows(Tiles& t, const ssa_consts& C, int g, int l)
+//   P = Wi A - m' s^T - s m'^T + sum(Wc) m' m'^T + Q       (A in the registers moment_sums_mfma left; s, m' in t.M)
+// in the matrix unit's result layout: lane (hi, mid, lo) finishes object mid's entries (hi, lo), (hi, 4 + lo), (4 + hi, 4 + lo)
+// -- all 64 lanes, no index arithmetic beyond the lane's bit fields, no second LDS copy of A (the earlier version ran the
+// 21 upper-triangle entries over the object's 16 lanes in two passes, half of its instructions index arithmetic).  A is
+// bit-symmetric (same products, same order) but the expression below is not under a <-> b, so only lanes with a <= b
+// write, to both [a][b] and [b][a]: P leaves exactly symmetric.
+SSA_DEV double covariance_entry(const ssa_consts& C, double acc, double sa_, double ma, double sb_, double mb, double q)
 {
-    for (int idx = l; idx < 21; idx += 16) {
-        const int a = (idx >= 6) + (idx >= 11) + (idx >= 15) + (idx >= 18) + (idx >= 20);   // row of the upper triangle
-        const int b = idx - (a * 6 - ((a * (a - 1)) >> 1)) + a;
-        const double acc = t.UA[g * 48 + a * 8 + b];
-        const double sa_ = t.M[g * 12 + a], sb_ = t.M[g * 12 + b];
-        const double ma = t.M[g * 12 + 6 + a], mb = t.M[g * 12 + 6 + b];
-        double Pab = C.Wi * acc - ma * sb_ - sa_ * mb + C.sum_wc * ma * mb + t.Q[a * 6 + b];
-        t.P[g * 36 + a * 6 + b] = Pab;
-        t.P[g * 36 + b * 6 + a] = Pab;
+    return C.Wi * acc - ma * sb_ - sa_ * mb + C.sum_wc * ma * mb + q;
+}
+SSA_DEV void covariance_finish(Tiles& t, const ssa_consts& C, int lane, const Moments& mo)
+{
+    const int hi = lane >> 4, mid = (lane >> 2) & 3, lo = lane & 3;
+    const int hi1 = hi & 1, lo1 = lo & 1;            // (rows / columns 4, 5: the lanes beyond them compute on valid addresses and do not write)
+    const double* M = &t.M[mid * 12];
+    double* P = &t.P[mid * 36];
+    const double s_a = M[hi], m_a = M[6 + hi], s_b = M[lo], m_b = M[6 + lo];
+    const double s_a4 = M[4 + hi1], m_a4 = M[10 + hi1], s_b4 = M[4 + lo1], m_b4 = M[10 + lo1];
+    const double p00 = covariance_entry(C, mo.c00, s_a, m_a, s_b, m_b, t.Q[hi * 6 + lo]);
+    const double p01 = covariance_entry(C, mo.c01, s_a, m_a, s_b4, m_b4, t.Q[hi * 6 + 4 + lo1]);
+    const double p11 = covariance_entry(C, mo.c11, s_a4, m_a4, s_b4, m_b4, t.Q[(4 + hi1) * 6 + 4 + lo1]);
+    if (hi <= lo) {
+        P[hi * 6 + lo] = p00;
+        P[lo * 6 + hi] = p00;
+    }
+    if (lo < 2) {
+        P[hi * 6 + 4 + lo] = p01;
+        P[(4 + lo) * 6 + hi] = p01;
+        if (hi <= lo) {                              // (hi, lo) in {(0,0), (0,1), (1,1)}
+            P[(4 + hi) * 6 + 4 + lo] = p11;
+            P[(4 + lo) * 6 + 4 + hi] = p11;
+        }
     }
 }
 
@@ -621,6 +649,13 @@ SSA_DEV int robust_chol_row_lds(Tiles& t, double scale, int g, int l)
     return rung;
 }
 
+// tix % n_time, the division (a ~25-instruction sequence on the vector unit) only when the index has actually wrapped
+SSA_DEV int time_row(int tix, int n_time)
+{
+    if (n_time <= 0) return 0;
+    return ((unsigned)tix < (unsigned)n_time) ? tix : tix % n_time;
+}
+
 // O4 for one object (ssa_tasker_simple_2.py:834-840): [hx(x_filter[:3]), trace(P)], NaN/inf -> 0.001
 SSA_DEV void aer_obs_row(const double* x, const double* P, const ssa_step_params& p, const ssa_consts& C, int e, int64_t obj)
 {
@@ -643,7 +678,7 @@ SSA_DEV void aer_obs_row(const double* x, const double* P, const ssa_step_params
 SSA_DEV void aer_obs_tile(const Tiles& t, const ssa_step_params& p, const ssa_consts& C, int g, int l, int e, int64_t obj)
 {
     const int tix = p.env_time[e] + p.time_offset;
-    const double* M = p.trans + (int64_t)((p.n_time > 0) ? tix % p.n_time : 0) * 9;
+    const double* M = p.trans + (int64_t)time_row(tix, p.n_time) * 9;
     const double* x = &t.X[g * 6];
     const double* P = &t.P[g * 36];
     double d[3], R[3];
@@ -663,6 +698,8 @@ SSA_DEV void aer_obs_tile(const Tiles& t, const ssa_step_params& p, const ssa_co
 #ifdef SSA_TRACE   // diagnostic build only (build_ablate/wave_timeline.py): per-wave phase timestamps, 100 MHz wall clock
 __device__ unsigned long long g_trace[16384 * 16];
 #define SSA_TR(k) do { if (lane == 0 && tile < 16384) g_trace[tile * 16 + (k)] = wall_clock64(); } while (0)
+#elif defined(SSA_TRUNC)   // diagnostic build only (build_ablate/trunc_counters.sh): the wave ends at marker SSA_TRUNC, so that the
+#define SSA_TR(k) do { if ((k) == SSA_TRUNC) return; } while (0)   // PMC instruction counts of successive builds difference into stages
 #else
 #define SSA_TR(k) do { } while (0)
 #endif
@@ -688,9 +725,10 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     // leave HBM now and wait in LDS, instead of costing two memory round trips when the update starts
     const bool interval_ok = (C.update_interval <= 1) || (tix % C.update_interval == 0);
     const bool my_update = valid && act >= 0 && (int64_t)act == j && interval_ok;
-    const int tmod = (p.n_time > 0) ? tix % p.n_time : 0;   // row of `trans` / `z_noise` (episodes wrap)
+    int tmod = 0;                                           // row of `trans` / `z_noise` (episodes wrap)
     double upd_in = 0.0;
     if (my_update && l < 12) {
+        tmod = time_row(tix, p.n_time);
         const double* src = (l < 9) ? p.trans + (int64_t)tmod * 9 + l
                                     : p.z_noise + (int64_t)e * p.zn_stride_env + (int64_t)tmod * p.zn_stride_time + (int64_t)act * p.zn_stride_obj + (l - 9);
         upd_in = *src;
@@ -766,9 +804,11 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         if (PROP != 0) {
             // SSA_PROP_FG / J2: the solvers cover every conic; they decline only NaN / degenerate input or a
             // non-converging iteration, which IS a NaN result (farnocchia.py:353) -> 'predict returned nan'
-            if (!kep_ok) {
+            if (__any(!kep_ok)) {   // (whole-wave branch: twelve selects on the common path otherwise)
+                if (!kep_ok) {
 #pragma unroll
-                for (int c = 0; c < 6; ++c) o[c] = __builtin_nan("");
+                    for (int c = 0; c < 6; ++c) o[c] = __builtin_nan("");
+                }
             }
         } else if (__any(!kep_ok)) {
             // SSA_PROP_ELEMENTS outside the strong-elliptic regime (or NaN input): the complete restatement of
@@ -816,15 +856,16 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         }
     }
     wave_lds_sync();
+    Moments mo = {0.0, 0.0, 0.0};
 #if !(defined(SSA_ABLATE) && (SSA_ABLATE & 8))
-    moment_sums_mfma(t, lane);
+    mo = moment_sums_mfma(t, lane);
 #endif
     wave_lds_sync();
     SSA_TR(4);
     double xb_l = 0.0;   // lanes 0..5: component l of the prior mean
     if (l < 6) {
         const double s0 = t.X[g * 6 + l];
-        const double ssum = C.Wi * t.UA[g * 48 + l * 8 + 6];
+        const double ssum = C.Wi * t.M[g * 12 + l];
         const double mp = C.sum_wm_m1 * s0 + ssum;
         xb_l = s0 + mp;
         t.M[g * 12 + l] = ssum;
@@ -834,7 +875,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     const bool nan_x = ((__ballot(l < 6 && xb_l != xb_l) >> (g * 16)) & 0xFFFFull) != 0;
     wave_lds_sync();
 #if !(defined(SSA_ABLATE) && (SSA_ABLATE & 4))
-    covariance_rows(t, C, g, l);
+    covariance_finish(t, C, lane, mo);
 #endif
     wave_lds_sync();
     SSA_TR(5);
