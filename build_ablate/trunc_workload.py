@@ -16,7 +16,14 @@ z = torch.zeros((1, 480, m, 3), dtype=torch.float64, device='cuda')
 eng = engine.HotPathEngine(consts, m, 1, pb["trans"], z, history=2)
 eng.load_state(0, pb["x_true"], pb["x"], np.broadcast_to(pb["P0"], (m, 6, 6)))
 act = int(os.environ.get('ACTION', '-1'))
-for k in range(50):
-    eng.set_actions([act])
-    eng.launch_step(0, 1, 1)
+if os.environ.get('FAST', '1') == '1':     # the bench's path: statistics by sharded atomics + the aer block in the kernel's epilogue
+    from ssa_gym_amd import parallel
+    eng.load_state(1, pb["x_true"], pb["x"], np.broadcast_to(pb["P0"], (m, 6, 6)))   # (a truncated wave writes nothing: both slots stay healthy)
+    local = parallel.HipLocalStepper(eng, consts, fast_stats=True)
+    for k in range(50):
+        local.step(act)
+else:
+    for k in range(50):
+        eng.set_actions([act])
+        eng.launch_step(0, 1, 1)
 torch.cuda.synchronize()

@@ -675,9 +675,8 @@ SSA_DEV void aer_obs_row(const double* x, const double* P, const ssa_step_params
 // c.  Azimuth (lane 0) and elevation (lane 1) are both ONE atan2 -- az = atan2(n, e), el = atan2(u, hypot(e, n)) -- so the
 // two lanes walk the same instruction stream once (hx_aer evaluates them one after the other), lane 2 keeps the range,
 // lane 3 trace(P); one 8-byte store per lane, 32 contiguous bytes per object.
-SSA_DEV void aer_obs_tile(const Tiles& t, const ssa_step_params& p, const ssa_consts& C, int g, int l, int e, int64_t obj)
+SSA_DEV void aer_obs_tile_at(const Tiles& t, const ssa_step_params& p, const ssa_consts& C, int g, int l, int64_t obj, int tix)
 {
-    const int tix = p.env_time[e] + p.time_offset;
     const double* M = p.trans + (int64_t)time_row(tix, p.n_time) * 9;
     const double* x = &t.X[g * 6];
     const double* P = &t.P[g * 36];
@@ -693,6 +692,12 @@ SSA_DEV void aer_obs_tile(const Tiles& t, const ssa_step_params& p, const ssa_co
     const double tr = P[0] + P[7] + P[14] + P[21] + P[28] + P[35];
     const double v = (l < 2) ? a : (l == 2) ? rt : tr;
     p.aer_out[obj * 4 + l] = (fabs(v) <= 1.79769313486231570e308) ? v : 0.001;
+}
+SSA_DEV void aer_obs_tile(const Tiles& t, const ssa_step_params& p, const ssa_consts& C, int g, int l, int e, int64_t obj)
+{
+    // one env: the time index is wave-uniform, so the GCRS->ITRS matrix arrives by scalar loads (nine per-lane loads otherwise)
+    if (p.n_env > 1) aer_obs_tile_at(t, p, C, g, l, obj, p.env_time[e] + p.time_offset);
+    else aer_obs_tile_at(t, p, C, g, l, obj, p.env_time[0] + p.time_offset);
 }
 
 #ifdef SSA_TRACE   // diagnostic build only (build_ablate/wave_timeline.py): per-wave phase timestamps, 100 MHz wall clock
@@ -718,8 +723,16 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     const int e = (valid && p.n_env > 1) ? (int)((uint32_t)obj / (uint32_t)p.n_obj) : 0;
     const int64_t j = valid ? obj - (int64_t)e * p.n_obj : 0;
     // the action / time index of this object's env, fetched early (used after the transform)
-    const int act = valid ? p.actions[e] : -1;
-    const int tix = valid ? p.env_time[e] + p.time_offset : 0;
+    // (one env: wave-uniform scalar loads; per-lane loads with their 64-bit address arithmetic only for vectorised envs)
+    int act, tix;
+    if (p.n_env > 1) {
+        act = valid ? p.actions[e] : -1;
+        tix = valid ? p.env_time[e] + p.time_offset : 0;
+    } else {
+        const int a0 = p.actions[0], t0 = p.env_time[0];
+        act = valid ? a0 : -1;
+        tix = valid ? t0 + p.time_offset : 0;
+    }
     // ---- the one update of this env (ssa_tasker_simple_2.py:292-315) runs in the row that owns the selected object.  Its
     // wavefront is the longest-living one of the launch, so its inputs (this step's GCRS->ITRS matrix, the measurement noise)
     // leave HBM now and wait in LDS, instead of costing two memory round trips when the update starts
@@ -805,6 +818,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
             // SSA_PROP_FG / J2: the solvers cover every conic; they decline only NaN / degenerate input or a
             // non-converging iteration, which IS a NaN result (farnocchia.py:353) -> 'predict returned nan'
             if (__any(!kep_ok)) {   // (whole-wave branch: twelve selects on the common path otherwise)
+                asm volatile("");   // (keeps the optimiser from flattening the branch back into those selects)
                 if (!kep_ok) {
 #pragma unroll
                     for (int c = 0; c < 6; ++c) o[c] = __builtin_nan("");
@@ -1103,17 +1117,14 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
             const double dp = t.Met[g * 4 + 0];
             const bool rv = g < cnt;
             unsigned long long mx = rv ? ((unsigned long long)__double_as_longlong(dp) & 0x7fffffffffffffffull) : 0ull;
-            unsigned long long cn = rv ? ((unsigned long long)(dp < 1e4) + ((unsigned long long)(dp < 1e7) << 32)) : 0ull;
-            int nfl = (rv && t.St[g] != 0) ? 1 : 0;
+            // counts of the row, one 32-bit word while they cross rows: [< 1e4] | [< 1e7] << 8 | [failed] << 16  (each <= 4 per tile)
+            unsigned cw = rv ? ((unsigned)(dp < 1e4) | ((unsigned)(dp < 1e7) << 8) | ((unsigned)(t.St[g] != 0) << 16)) : 0u;
 #define SSA_XROW(CTRL, ROWMASK)                                                                                          \
             {                                                                                                            \
                 const unsigned long long m2 = ((unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(0, (int)(mx >> 32), CTRL, ROWMASK, 0xF, false) << 32) | \
                                               (unsigned)__builtin_amdgcn_update_dpp(0, (int)(mx & 0xffffffffull), CTRL, ROWMASK, 0xF, false);                 \
-                const unsigned long long c2 = ((unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(0, (int)(cn >> 32), CTRL, ROWMASK, 0xF, false) << 32) | \
-                                              (unsigned)__builtin_amdgcn_update_dpp(0, (int)(cn & 0xffffffffull), CTRL, ROWMASK, 0xF, false);                 \
-                nfl += __builtin_amdgcn_update_dpp(0, nfl, CTRL, ROWMASK, 0xF, false);                                   \
+                cw += (unsigned)__builtin_amdgcn_update_dpp(0, (int)cw, CTRL, ROWMASK, 0xF, false);                      \
                 mx = m2 > mx ? m2 : mx;                                                                                  \
-                cn += c2;                                                                                                \
             }
             SSA_XROW(0x142, 0xA)   // row_bcast:15
             SSA_XROW(0x143, 0xC)   // row_bcast:31
@@ -1121,8 +1132,9 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
             if (lane == 63) {
                 const int64_t e_tile = (p.n_env > 1) ? (int64_t)((uint32_t)base / (uint32_t)p.n_obj) : 0;
                 unsigned long long* sh = (unsigned long long*)p.stat_shards + ((e_tile * SSA_STAT_SHARDS) + (tile & (SSA_STAT_SHARDS - 1))) * 4;
+                const unsigned nfl = cw >> 16;
                 atomicMax(sh, mx);
-                atomicAdd(sh + 1, cn);
+                atomicAdd(sh + 1, (unsigned long long)(cw & 0xffu) | ((unsigned long long)((cw >> 8) & 0xffu) << 32));
                 if (nfl) atomicAdd(sh + 2, (unsigned long long)nfl);
             }
         } else if (p.stat_shards && lane == 0) {   // a tile that straddles envs: one group of atomics per env

@@ -374,7 +374,33 @@ SSA_DEV void stumpff_small(double z, double& c2, double& c3)
     c3 = fma(-c3, z, 1.0 / 120.0);
     c3 = fma(-c3, z, 1.0 / 6.0);
 }
+// the same series cut after z^3 for |z| < 2e-3 (truncation z^4 / 10! : 1e-17 relative) -- every sigma point of a 20 s step of the
+// catalogue (z ~ (n dt)^2 < 1e-3): six FMAs instead of fourteen per evaluation
+SSA_DEV void stumpff_tiny(double z, double& c2, double& c3)
+{
+    c2 = fma(-fma(-fma(-1.0 / 40320.0, z, 1.0 / 720.0), z, 1.0 / 24.0), z, 0.5);
+    c3 = fma(-fma(-fma(-1.0 / 362880.0, z, 1.0 / 5040.0), z, 1.0 / 120.0), z, 1.0 / 6.0);
+}
+template <bool TINY>
+SSA_DEV void stumpff_sel(double z, double& c2, double& c3)
+{
+    if (TINY) stumpff_tiny(z, c2, c3);
+    else stumpff_small(z, c2, c3);
+}
+template <bool TINY>
+SSA_DEV bool kepler_uv_fast_t(const double* x, double tof, double* out, bool& handled);
 SSA_DEV bool kepler_uv_fast(const double* x, double tof, double* out, bool& handled)
+{
+    // whole-wave choice of the series length from the first-order estimate z ~ alpha (sqrt(mu) tof / r0)^2 (bound 1.5e-3: the
+    // converged z stays below the 2e-3 the short series is good for; a NaN lane takes either)
+    const double rr = dot3(x, x), vv = dot3(x + 3, x + 3);
+    const double ir = rsqrt_nr(rr);
+    const double z0 = (2.0 * ir - vv * (1.0 / MU)) * (MU * tof * tof) * (ir * ir);
+    if (__all(!(fabs(z0) >= 1.5e-3))) return kepler_uv_fast_t<true>(x, tof, out, handled);
+    return kepler_uv_fast_t<false>(x, tof, out, handled);
+}
+template <bool TINY>
+SSA_DEV bool kepler_uv_fast_t(const double* x, double tof, double* out, bool& handled)
 {
     const double* r = x;
     const double* v = x + 3;
@@ -399,7 +425,7 @@ SSA_DEV bool kepler_uv_fast(const double* x, double tof, double* out, bool& hand
     for (int it = 0; it < 6; ++it) {
         chi2 = chi * chi;
         z = alpha * chi2;
-        stumpff_small(z, c2, c3);
+        stumpff_sel<TINY>(z, c2, c3);
         const double w3 = 1.0 - z * c3, w2 = 1.0 - z * c2;
         const double F = fma(r0, chi, chi2 * fma(k3 * chi, c3, sig * c2)) - T;
         const double rad = fma(chi2, c2, fma(sig * chi, w3, r0 * w2));
@@ -417,7 +443,7 @@ SSA_DEV bool kepler_uv_fast(const double* x, double tof, double* out, bool& hand
     }
     chi2 = chi * chi;
     z = alpha * chi2;
-    stumpff_small(z, c2, c3);
+    stumpff_sel<TINY>(z, c2, c3);
     const double rad = fma(chi2, c2, fma(sig * chi, 1.0 - z * c3, r0 * (1.0 - z * c2)));
     const double inv_rad = rcp_nr(rad);
     const double f = 1.0 - chi2 * c2 * inv_r0;
