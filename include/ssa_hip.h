@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SSA_ABI_VERSION 14
+#define SSA_ABI_VERSION 15
 
 /* error codes */
 #define SSA_OK 0
@@ -76,7 +76,9 @@ extern "C" {
 #define SSA_UPD_ACTION 56   /* the action this record belongs to (as double), -1 = no update attempted */
 
 /* layout of the per-env reward statistics written by ssa_reward_stats_f64 (doubles) */
-#define SSA_STAT_SHARDS 64  /* accumulator shards per env of the atomics-based statistics path */
+#define SSA_STAT_SHARDS 128 /* accumulator shards per env of the atomics-based statistics path */
+#define SSA_STAT_SHARD_WORDS 16 /* uint64 words between shards: every shard owns a 128-byte line (words 0..2 used); with 64 shards
+                                  packed four words apart, 5000 wavefronts x 2 atomics met on 16 lines: +2 us per 20 000-object step */
 #define SSA_STAT_STRIDE 8
 #define SSA_STAT_MAX_DPOS 0   /* np.max(delta_pos[i])  (NaN-propagating)        (:325-343) */
 #define SSA_STAT_CNT_LT_1E4 1 /* count(delta_pos < 1e4)  } results.py:432        */
@@ -132,7 +134,7 @@ typedef struct ssa_step_params {
     double *stats;             /* [E][SSA_STAT_STRIDE] reward statistics of this step (O3), may be NULL */
     int32_t *work;             /* unused since ABI 12 (the exception queue is gone); may be NULL */
     void *stat_ws;             /* ssa_reward_stats_workspace_bytes(): per-block statistics partials */
-    uint64_t *stat_shards;     /* [E][SSA_STAT_SHARDS][4] zero-initialised device words, or NULL.  When given the
+    uint64_t *stat_shards;     /* [E][SSA_STAT_SHARDS][SSA_STAT_SHARD_WORDS] zero-initialised device words, or NULL.  When given the
                                   step kernel accumulates max delta_pos / trinary counts / failures itself with sharded
                                   atomics (and writes aer_out, if asked, in its epilogue); a one-wave fold kernel writes
                                   `stats` and clears the words: two launches per step instead of three.  arg-max
@@ -148,7 +150,7 @@ typedef struct ssa_step_params {
                                   ssa_tasker_simple_2.py:834-840), may be NULL.  With stat_shards it is written by the step
                                   kernel's epilogue from the on-chip tiles (no extra launch, no second pass over x / P);
                                   without, by the post kernel: the 'aer' observation / the sharded all-gather payload. */
-    uint64_t *stat_shards_clear; /* [E][SSA_STAT_SHARDS][4] or NULL: a shard set this launch ZEROES (nothing reads or adds to it
+    uint64_t *stat_shards_clear; /* [E][SSA_STAT_SHARDS][SSA_STAT_SHARD_WORDS] or NULL: a shard set this launch ZEROES (nothing reads or adds to it
                                   during the launch).  Lets a consumer that takes the statistics as RAW shards -- the sharded
                                   multi-GPU step sends its rank's shard words in the all-gather payload and every rank
                                   folds all ranks' words itself -- alternate two payload buffers without a fold / clear
@@ -194,7 +196,7 @@ typedef struct ssa_rollout_params {
     double *upd_ring;          /* [H][E][SSA_UPD_STRIDE] or NULL */
     double *stats_ring;        /* [H][E][SSA_STAT_STRIDE]; only the last H steps' statistics survive, as in any ring */
     const int32_t *actions;    /* [K][E] */
-    uint64_t *stat_shards;     /* [K][E][SSA_STAT_SHARDS][4] zero-initialised; cleared again by the fold */
+    uint64_t *stat_shards;     /* [K][E][SSA_STAT_SHARDS][SSA_STAT_SHARD_WORDS] zero-initialised; cleared again by the fold */
 } ssa_rollout_params;
 int ssa_env_rollout_f64(const ssa_consts *c_host, const ssa_step_params *first, const ssa_rollout_params *r, void *stream);
 

@@ -46,13 +46,14 @@ class ssa_rollout_params(C.Structure):
 
 
 # constants of include/ssa_hip.h
-ABI_VERSION = 14
+ABI_VERSION = 15
 ST_OK, ST_PREDICT_NAN, ST_PREDICT_LINALG, ST_UPDATE_NAN, ST_UPDATE_LINALG = range(5)
 OBS_AER, OBS_XYZ = 0, 1
 PROP_ELEMENTS, PROP_FG, PROP_J2_RK4 = 0, 1, 2
 FLAG_RESAMPLE = 1
 UPD_STRIDE, UPD_OBS_TAKEN, UPD_Z_TRUE, UPD_Y, UPD_S, UPD_SIGMAS_H, UPD_VISIBLE, UPD_ACTION = 64, 0, 1, 4, 7, 16, 55, 56
-STAT_SHARDS = 64
+STAT_SHARDS = 128
+STAT_SHARD_WORDS = 16
 PROFILE_SLOTS = 1024
 LAUNCH_DEFER_FOLD = 8
 AGENT_NAIVE_GREEDY, AGENT_VISIBLE_GREEDY, AGENT_SHANNON, AGENT_POS_ERROR, AGENT_VEL_ERROR = range(5)

@@ -1131,11 +1131,13 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
 #undef SSA_XROW
             if (lane == 63) {
                 const int64_t e_tile = (p.n_env > 1) ? (int64_t)((uint32_t)base / (uint32_t)p.n_obj) : 0;
-                unsigned long long* sh = (unsigned long long*)p.stat_shards + ((e_tile * SSA_STAT_SHARDS) + (tile & (SSA_STAT_SHARDS - 1))) * 4;
+                unsigned long long* sh = (unsigned long long*)p.stat_shards + ((e_tile * SSA_STAT_SHARDS) + (tile & (SSA_STAT_SHARDS - 1))) * SSA_STAT_SHARD_WORDS;
                 const unsigned nfl = cw >> 16;
+#ifndef SSA_NO_ATOMICS   // (diagnostic builds only)
                 atomicMax(sh, mx);
                 atomicAdd(sh + 1, (unsigned long long)(cw & 0xffu) | ((unsigned long long)((cw >> 8) & 0xffu) << 32));
                 if (nfl) atomicAdd(sh + 2, (unsigned long long)nfl);
+#endif
             }
         } else if (p.stat_shards && lane == 0) {   // a tile that straddles envs: one group of atomics per env
             int64_t e_cur = -1;
@@ -1148,7 +1150,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                 ++j_run;
                 if (eg != e_cur) {
                     if (e_cur >= 0) {
-                        unsigned long long* sh = (unsigned long long*)p.stat_shards + ((e_cur * SSA_STAT_SHARDS) + (tile & (SSA_STAT_SHARDS - 1))) * 4;
+                        unsigned long long* sh = (unsigned long long*)p.stat_shards + ((e_cur * SSA_STAT_SHARDS) + (tile & (SSA_STAT_SHARDS - 1))) * SSA_STAT_SHARD_WORDS;
                         atomicMax(sh, mx);
                         atomicAdd(sh + 1, cnts);
                         if (nf) atomicAdd(sh + 2, nf);
@@ -1171,7 +1173,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         if (tile == 0) {
             if (p.stat_shards_clear) {
                 unsigned long long* z = (unsigned long long*)p.stat_shards_clear;
-                for (int i = lane; i < p.n_env * SSA_STAT_SHARDS * 4; i += 64) z[i] = 0ull;
+                for (int i = lane; i < p.n_env * SSA_STAT_SHARDS * 4; i += 64) z[(i >> 2) * SSA_STAT_SHARD_WORDS + (i & 3)] = 0ull;   // (the used words)
             }
         }
     }
@@ -1180,9 +1182,16 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
 // folds the SSA_STAT_SHARDS accumulators of the atomics path of env e into stats and clears them (one wavefront)
 SSA_DEV void fold_stat_shards(unsigned long long* __restrict__ shards, double* __restrict__ stats, int e, int lane)
 {
-    unsigned long long* sh = shards + ((int64_t)e * SSA_STAT_SHARDS + lane) * 4;
+    static_assert(SSA_STAT_SHARDS == 128, "two shards per lane");
+    unsigned long long* sh = shards + ((int64_t)e * SSA_STAT_SHARDS + lane) * SSA_STAT_SHARD_WORDS;
+    unsigned long long* sh2 = sh + 64 * SSA_STAT_SHARD_WORDS;
     unsigned long long mx = sh[0], cn = sh[1], nf = sh[2];
+    const unsigned long long mb = sh2[0], cb = sh2[1], nb = sh2[2];
     sh[0] = 0ull; sh[1] = 0ull; sh[2] = 0ull;
+    sh2[0] = 0ull; sh2[1] = 0ull; sh2[2] = 0ull;
+    mx = mb > mx ? mb : mx;
+    cn += cb;
+    nf += nb;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         unsigned long long m2 = __shfl_down(mx, off, 64), c2 = __shfl_down(cn, off, 64), n2 = __shfl_down(nf, off, 64);
@@ -1334,7 +1343,7 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) rollout_kernel(const RollK
             // writer, in order)
             pk.upd = (r.upd_ring && kk >= K - H) ? r.upd_ring + so * su : nullptr;
             pk.actions = r.actions + (int64_t)kk * E;
-            pk.stat_shards = r.stat_shards + (int64_t)kk * E * SSA_STAT_SHARDS * 4;
+            pk.stat_shards = r.stat_shards + (int64_t)kk * E * SSA_STAT_SHARDS * SSA_STAT_SHARD_WORDS;
             pk.aer_out = nullptr;
             process_wave<PROP, 2>(t, k.c, pk, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, pf, 0, 0, tile);
             wave_lds_sync();
@@ -1349,7 +1358,7 @@ __global__ void __launch_bounds__(64) rollout_fold_kernel(unsigned long long* __
     const int kk = blockIdx.x, e = blockIdx.y;
     const int so = (slot_out + kk) % history;
     double* dst = (kk >= n_steps - history) ? stats_ring + (int64_t)so * n_env * SSA_STAT_STRIDE : nullptr;
-    fold_stat_shards(shards + (int64_t)kk * n_env * SSA_STAT_SHARDS * 4, dst, e, threadIdx.x);
+    fold_stat_shards(shards + (int64_t)kk * n_env * SSA_STAT_SHARDS * SSA_STAT_SHARD_WORDS, dst, e, threadIdx.x);
 }
 
 // Post kernel, grid (nparts, n_env) x 256 threads, launched when a payload or the exact statistics are wanted:

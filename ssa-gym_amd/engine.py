@@ -75,7 +75,7 @@ class HotPathEngine:
         self.work = torch.zeros(self._lib.ssa_env_step_work_bytes(self.m, self.E) // 4, dtype=torch.int32, device=d)
         self._p.work, self._p.stat_ws, self._p.launch_mask = self.work.data_ptr(), self._stats_ws.data_ptr(), 0
         # statistics accumulators of the atomics path; two sets, alternated when the fold is deferred
-        self._shard_sets = torch.zeros((2, self.E, _lib.STAT_SHARDS, 4), dtype=torch.int64, device=d)
+        self._shard_sets = torch.zeros((2, self.E, _lib.STAT_SHARDS, _lib.STAT_SHARD_WORDS), dtype=torch.int64, device=d)
         self.stat_shards = self._shard_sets[0]
         self._shard_cur = 0
         self._fold_pending = None      # (shard set index, stats destination) of a step whose fold was deferred
@@ -205,7 +205,7 @@ class HotPathEngine:
         self.flush_stats(s)
         K = int(actions.shape[0])
         if getattr(self, "_roll_shards", None) is None or self._roll_shards.shape[0] < K:
-            self._roll_shards = torch.zeros((K, self.E, _lib.STAT_SHARDS, 4), dtype=torch.int64, device=self.dev)
+            self._roll_shards = torch.zeros((K, self.E, _lib.STAT_SHARDS, _lib.STAT_SHARD_WORDS), dtype=torch.int64, device=self.dev)
         r = _lib.ssa_rollout_params()
         r.n_steps, r.history, r.slot_out = K, self.H, (int(slot_in) + 1) % self.H
         r.x_true_ring, r.x_ring, r.P_ring = self._bx_t, self._bx, self._bP

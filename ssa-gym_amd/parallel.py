@@ -23,8 +23,8 @@ import torch
 import torch.distributed as dist
 
 STAT_STRIDE = 8
-STAT_SHARDS = 64                 # include/ssa_hip.h SSA_STAT_SHARDS: raw statistics words [64][4] uint64 per env
-RAW_WORDS = STAT_SHARDS * 4
+STAT_SHARDS, STAT_SHARD_WORDS = 128, 16   # include/ssa_hip.h: raw statistics shards [128][16] uint64 per env (one 128-byte line each, words 0..2 used)
+RAW_WORDS = STAT_SHARDS * STAT_SHARD_WORDS
 STAT_MAX_DPOS, STAT_CNT_LT_1E4, STAT_CNT_LT_1E7, STAT_ARGMAX_SPOS, STAT_N_FAILED, STAT_MAX_SPOS = range(6)
 
 
@@ -181,7 +181,7 @@ class ShardedStepper:
         st = rows[:, :STAT_STRIDE]
         out = np.zeros(STAT_STRIDE)
         if self._raw[(self.k - 1) & 1]:      # raw shard words of every rank: fold them as reward_fold_kernel would
-            w = np.ascontiguousarray(rows[:, STAT_STRIDE:]).view(np.uint64).reshape(p.world * STAT_SHARDS, 4)
+            w = np.ascontiguousarray(rows[:, STAT_STRIDE:]).view(np.uint64).reshape(p.world * STAT_SHARDS, STAT_SHARD_WORDS)[:, :4]
             out[STAT_MAX_DPOS] = np.array([w[:, 0].max()], dtype=np.uint64).view(np.float64)[0]   # ordered bit patterns, NaN on top
             out[STAT_CNT_LT_1E4] = float((w[:, 1] & np.uint64(0xffffffff)).sum())
             out[STAT_CNT_LT_1E7] = float((w[:, 1] >> np.uint64(32)).sum())

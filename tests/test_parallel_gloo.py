@@ -37,10 +37,10 @@ class OracleLocalStepper:
         self.xt, self.x, self.P, self.met = r["x_true"], r["x"], r["P"], r["metrics"]
         if obs_out is not None and shards_out is not None:   # raw form: max delta_pos as ordered bits | packed counts | failures, spread
             obs_out.copy_(torch.as_tensor(self.o.aer_obs(self.x, self.P, self.c2t[self.tick], self.ep["obs_lla"], self.ep["obs_itrs"])))
-            w = np.zeros((64, 4), dtype=np.uint64)               # over a few shards like the kernel's per-tile atomics
+            w = np.zeros((128, 16), dtype=np.uint64)             # over a few shards (one 128-byte line each) like the kernel's per-tile atomics
             d = self.met[0]
             for t0 in range(0, len(d), 4):
-                sh_ = (t0 // 4) % 64
+                sh_ = (t0 // 4) % 128
                 tile = d[t0:t0 + 4]
                 w[sh_, 0] = max(w[sh_, 0], tile.view(np.uint64).max())
                 w[sh_, 1] += np.uint64((tile < 1e4).sum()) + (np.uint64((tile < 1e7).sum()) << np.uint64(32))
