@@ -5,6 +5,11 @@ sys.argv=['bench.py']
 import bench
 from ssa_gym_amd import _lib, _build, host, engine, parallel
 m=int(os.environ.get('M','20000'))
+FAST=os.environ.get('FAST','0')=='1'   # the bench's path: statistics by sharded atomics, folded by an extra wavefront of the next launch
+_sh=torch.zeros((2,1,128,16),dtype=torch.int64,device='cuda')
+def fast(p,k):
+    if FAST:
+        p.stat_shards=_sh[k&1].data_ptr(); p.stat_shards_prev=_sh[(k+1)&1].data_ptr(); p.stats_prev=p.stats; p.launch_mask=8
 pb=bench.build_problem(m, seed=100)
 res={}
 ROUNDS=int(os.environ.get('ROUNDS','3'))   # interleaved rounds over all builds: box / clock drift hits every build alike
@@ -24,7 +29,7 @@ for rnd in range(ROUNDS):
           eng=engine.HotPathEngine(consts,m,1,pb["trans"],z,history=2)
           eng.load_state(0,pb["x_true"],pb["x"],np.broadcast_to(pb["P0"],(m,6,6)))
           snap=eng.snapshot(0)
-          sched=torch.full((64,),-1,dtype=torch.int32,device='cuda'); sched[::2]=5
+          sched=torch.full((64,),-1,dtype=torch.int32,device='cuda'); sched[:]=torch.arange(64,dtype=torch.int32,device="cuda")*313 % m
           p=eng._p; s=torch.cuda.current_stream().cuda_stream
           best=1e9
           for rep in range(5):
@@ -36,7 +41,7 @@ for rnd in range(ROUNDS):
                   p.x_true_in,p.x_true_out=eng._bx_t+sin*eng._sx,eng._bx_t+sout*eng._sx
                   p.x_in,p.x_out=eng._bx+sin*eng._sx,eng._bx+sout*eng._sx
                   p.P_in,p.P_out=eng._bP+sin*eng._sP,eng._bP+sout*eng._sP
-                  p.obs=eng._bo; p.metrics=eng._bm; p.upd=eng._bu; p.stats=eng._bs; p.launch_mask=int(os.environ.get('MASK','1'))
+                  p.obs=eng._bo; p.metrics=eng._bm; p.upd=eng._bu; p.stats=eng._bs; p.launch_mask=int(os.environ.get('MASK','1')); fast(p,k)
                   p.actions=sched.data_ptr()+4*(k%64)
                   lib.ssa_env_step_f64(eng._cref,eng._pref,s)
               e1.record(); torch.cuda.synchronize(); best=min(best,e0.elapsed_time(e1)/100)
@@ -48,7 +53,7 @@ for rnd in range(ROUNDS):
                   p.x_true_in,p.x_true_out=eng._bx_t+sin*eng._sx,eng._bx_t+sout*eng._sx
                   p.x_in,p.x_out=eng._bx+sin*eng._sx,eng._bx+sout*eng._sx
                   p.P_in,p.P_out=eng._bP+sin*eng._sP,eng._bP+sout*eng._sP
-                  p.obs=eng._bo; p.metrics=eng._bm; p.upd=eng._bu; p.stats=eng._bs; p.launch_mask=int(os.environ.get('MASK','1'))
+                  p.obs=eng._bo; p.metrics=eng._bm; p.upd=eng._bu; p.stats=eng._bs; p.launch_mask=int(os.environ.get('MASK','1')); fast(p,k)
                   p.actions=sched.data_ptr()+4*(k%64)
                   lib.ssa_env_step_f64(eng._cref,eng._pref,s)
           run(0,330); torch.cuda.synchronize()

@@ -72,3 +72,11 @@ print("distinct CUs: %d ; waves per CU min/mean/max: %d / %.2f / %d" % (len(ucu)
 grid = np.linspace(0, en.max(), 60)
 conc = [(int(((st <= g) & (en > g)).sum())) for g in grid]
 print("resident waves over time:", conc)
+
+upd = np.nonzero(tr[:, 10])[0]
+if len(upd):
+    print("update wavefront(s): start, end [us] and the update's phases [us]: hx | z mean | residual + S, Pxz sums | inv + K | x, P | records")
+    for w_ in upd[:4]:
+        seq = [tr[w_, 5], tr[w_, 10], tr[w_, 11], tr[w_, 12], tr[w_, 13], tr[w_, 14], tr[w_, 6]]
+        print("   tile %d  start %.2f end %.2f   predict stages %s   update %s" % (w_, st[w_], en[w_], (np.diff(t[w_, :6]) / 1e3).round(2),
+              (np.diff(np.array(seq, dtype=np.float64)) * 10.0 / 1e3).round(2)))

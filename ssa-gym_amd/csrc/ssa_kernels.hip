@@ -738,6 +738,9 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     // leave HBM now and wait in LDS, instead of costing two memory round trips when the update starts
     const bool interval_ok = (C.update_interval <= 1) || (tix % C.update_interval == 0);
     const bool my_update = valid && act >= 0 && (int64_t)act == j && interval_ok;
+    // ... and it issues ahead of its SIMD's other wavefronts from here on: at equal priority its predict runs at a fifth of the
+    // SIMD and the update then starts when everybody else is finishing (the kernel's tail)
+    if (__any(my_update)) __builtin_amdgcn_s_setprio(3);
     int tmod = 0;                                           // row of `trans` / `z_noise` (episodes wrap)
     double upd_in = 0.0;
     if (my_update && l < 12) {
@@ -946,6 +949,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                 if (C.obs_type == SSA_OBS_AER) { z[0] = aer[0]; z[1] = aer[1]; z[2] = aer[2]; }
                 else { z[0] = sf[0]; z[1] = sf[1]; z[2] = sf[2]; }
             }
+            SSA_TR(10);
             visible = row_bcast<13>(el_mine) >= C.obs_limit;  // object_visible(): elevation of the TRUE state (:418-425)
             if (rec && l == 13) {
 #pragma unroll
@@ -972,6 +976,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                         zp[c] = u0 + (C.sum_wm_m1 * u0 + C.Wi * row_allsum(du));
                     }
                 }
+                SSA_TR(11);
                 // H4: residuals; lane 13 forms the innovation of the noisy measurement
                 double rz[3];
                 {
@@ -1014,6 +1019,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                     }
                 }
                 wave_lds_sync();
+                SSA_TR(12);
                 bool inv_ok;
                 {
                     double S[9], SI[9];
@@ -1036,6 +1042,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                         W[36 + idx] = W[9 + a * 3] * W[27 + b] + W[9 + a * 3 + 1] * W[30 + b] + W[9 + a * 3 + 2] * W[33 + b];
                     }
                     wave_lds_sync();
+                    SSA_TR(13);
                     // x += K y  (lanes 0..5); P -= K S K^T (36 entries over the row's lanes)
                     double xn = 0.0;
                     if (l < 6) xn = t.X[g * 6 + l] + (W[36 + l * 3] * y[0] + W[36 + l * 3 + 1] * y[1] + W[36 + l * 3 + 2] * y[2]);
@@ -1051,6 +1058,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                         t.P[g * 36 + idx] = t.P[g * 36 + idx] - corr;
                     }
                     if (l < 6) t.X[g * 6 + l] = xn;
+                    SSA_TR(14);
                     if (nan_u) st_new = SSA_ST_UPDATE_NAN;
                     if (rec) {
                         if (l < 3) rec[SSA_UPD_Y + l] = y[l == 0 ? 0 : (l == 1 ? 1 : 2)];
