@@ -1,2 +1,4 @@
 mkdir -p gpurun_out
-FAST=1 PROPS=fg timeout -k 10 400 python build_ablate/time_variants.py > gpurun_out/r2z_variants.txt 2>&1 ; cat gpurun_out/r2z_variants.txt
+cp ssa-gym_amd/libssa_hip.so /tmp/keep.so; cp build_ablate/libs/trace.so ssa-gym_amd/libssa_hip.so
+STEPS=380 timeout -k 10 200 python build_ablate/wave_timeline.py > gpurun_out/r2z_tl_late.txt 2>&1; grep -v "resident\|XCC\|distinct" gpurun_out/r2z_tl_late.txt | tail -40
+cp /tmp/keep.so ssa-gym_amd/libssa_hip.so

@@ -4,6 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/trunc
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+if [ -n "$LATE" ]; then export STATE=/tmp/late_state.npz; GEN=$LATE LIB=$R/ssa-gym_amd/libssa_hip.so python3 $R/build_ablate/trunc_workload.py; export TICK0=$LATE; fi
 for v in t1 t2 t3 t4 t5 t6 t7 t8 t9 full; do
   if [ $v = full ]; then export LIB=$R/ssa-gym_amd/libssa_hip.so; else export LIB=$R/build_ablate/trunc/$v.so; fi
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES --kernel-trace --output-format csv -d $OUT/${v}_a -- python3 $R/build_ablate/trunc_workload.py > $OUT/${v}_a.log 2>&1 || echo "pass a failed for $v"

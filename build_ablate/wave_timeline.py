@@ -21,7 +21,7 @@ z = torch.zeros((1, 480, m, 3), dtype=torch.float64, device='cuda')
 eng = engine.HotPathEngine(consts, m, 1, pb["trans"], z, history=2)
 eng.load_state(0, pb["x_true"], pb["x"], np.broadcast_to(pb["P0"], (m, 6, 6)))
 local = parallel.HipLocalStepper(eng, consts, fast_stats=True)
-local.load_schedule(np.arange(400) % m)
+local.load_schedule(np.arange(4000) % m)
 for k in range(int(os.environ.get("STEPS", 100))):
     local.step(-1)
 local.flush()

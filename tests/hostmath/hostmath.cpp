@@ -26,5 +26,6 @@ void hm_uv_general(const double* x, long n, double dt, double* out, int* ok)
 int hm_robust_chol6(const double* A21, double* U21) { return ssa::robust_chol6(A21, U21); }
 void hm_sincos_fast(const double* x, long n, double* s, double* c) { for (long i = 0; i < n; ++i) ssa::sincos_fast(x[i], s[i], c[i]); }
 void hm_atan2_fast(const double* y, const double* x, long n, double* r) { for (long i = 0; i < n; ++i) r[i] = ssa::atan2_fast(y[i], x[i]); }
+void hm_exp_fast(const double* x, long n, double* r) { for (long i = 0; i < n; ++i) r[i] = ssa::exp_fast(x[i]); }
 void hm_recip(const double* x, long n, double* r, double* rs) { for (long i = 0; i < n; ++i) { r[i] = ssa::rcp_nr(x[i]); rs[i] = ssa::rsqrt_nr(x[i]); } }
 }

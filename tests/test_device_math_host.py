@@ -127,3 +127,13 @@ def test_fast_atan2(hm):
     el_, nl, ul = (v.astype(np.longdouble) for v in (e, n, u))
     ref = np.arcsin(ul / np.sqrt(el_ * el_ + nl * nl + ul * ul))      # (in fp64 asin(u / r) itself loses digits towards the zenith)
     assert np.abs((el - ref).astype(np.float64)).max() < 4e-16
+
+
+def test_fast_exp(hm):
+    """exp_fast on [0, 700) (the hyperbolic Stumpff functions of the general solver): < 2 ulp."""
+    rs = np.random.RandomState(3)
+    x = np.concatenate([rs.uniform(0.0, 700.0, 200000), rs.uniform(0.0, 2.0, 50000), [0.0, 0.5, np.log(2.0) / 2, 699.999]])
+    r = np.empty_like(x)
+    hm.hm_exp_fast(_p(x), C.c_long(len(x)), _p(r))
+    ref = np.exp(x.astype(np.longdouble))
+    assert (np.abs((r - ref) / ref).astype(np.float64)).max() < 4.5e-16
