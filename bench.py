@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_OBJECT_STEP = 896   # r+w x_true 48, x 48, P 288 each way; obs 96; metrics 32
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-FP64_FLOP_PER_OBJECT_STEP = 6900  # profiles/r02_counters.json: (ADD 16 + MUL 75 + 2 FMA 130 + TRANS 10) x 64 lanes + 9 MFMA x 512, per 4 objects
+FP64_FLOP_PER_OBJECT_STEP = 6400  # profiles/r02_counters.json: (ADD 18 + MUL 89 + 2 FMA 106 + TRANS 10) x 64 lanes + 9 MFMA x 512, per 4 objects
 FP64_PEAK_TFLOPS = 78.6           # MI355X datasheet fp64 vector peak (an FMA micro-benchmark reaches 63.2 on these boxes)
 
 

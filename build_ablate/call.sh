@@ -1,4 +1,2 @@
 mkdir -p gpurun_out
-cp ssa-gym_amd/libssa_hip.so /tmp/keep.so; cp build_ablate/libs/trace.so ssa-gym_amd/libssa_hip.so
-STEPS=380 timeout -k 10 200 python build_ablate/wave_timeline.py > gpurun_out/r2z_tl_late.txt 2>&1; grep -v "resident\|XCC\|distinct" gpurun_out/r2z_tl_late.txt | tail -40
-cp /tmp/keep.so ssa-gym_amd/libssa_hip.so
+timeout -k 10 1000 bash profiles/collect.sh r02 > gpurun_out/r2z_collect.log 2>&1; echo "collect rc $?"; tail -30 gpurun_out/r2z_collect.log
