@@ -914,12 +914,22 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     // ---- U5: the one update of this env (ssa_tasker_simple_2.py:292-315), in the row that owns the
     // selected object.  Cross-lane traffic is row-level (DPP / bpermute); the small matrices are staged
     // in the row's (now free) t.D area:  W[0..9) S | W[9..27) Pxz | W[27..36) inv(S) | W[36..54) K
+    // Phase 1 (row-local, lanes of the selected object's row): measurement of the sigma points, predicted measurement,
+    // residuals; the rows [sigma - x | rz | Wc rz] go to the staging matrix.  Phase 2 (whole wavefront, below): the two
+    // weighted moment matrices on the matrix unit, inverse, gain, state and covariance over all 64 lanes.
+    bool upd_go = false, taken = false, visible = false, attempted = false;
+    double z[3] = {0.0, 0.0, 0.0}, y_row[3] = {0.0, 0.0, 0.0};   // (y_row: lane 13 of the row keeps the innovation)
+    double* rec = nullptr;
+    // staging matrix of the row's update: [13][9], row i = [sigma_i - x | rz_i].  The four rows' matrices (468 doubles) lie in the
+    // transform's scratch, free by now: the factor tile and the head of t.D (contiguous members of Tiles)
+    double* const STG = &t.UA[g * 117];
+    double* const W = &t.D[330];        // small matrices: W[0..9) S | W[9..27) Pxz | W[36..54) K | W[54..57) y
+    static_assert(offsetof(Tiles, D) == offsetof(Tiles, UA) + sizeof(double) * OBJ_PER_WAVE * 36, "UA and D contiguous");
+    static_assert(4 * 117 <= OBJ_PER_WAVE * 36 + 330 && 330 + 57 <= 408, "update staging fits");
     if (my_update) {
-        double* rec = p.upd ? p.upd + (int64_t)e * SSA_UPD_STRIDE : nullptr;
-        double* W = &t.D[dbase(g)];
-        bool taken = false, visible = false;
+        rec = p.upd ? p.upd + (int64_t)e * SSA_UPD_STRIDE : nullptr;
         // a filter that has failed (earlier, or in this step's predict) is skipped entirely (:293): no z_true, no record
-        const bool attempted = (st_new == SSA_ST_OK);
+        attempted = (st_new == SSA_ST_OK);
         if (attempted) {
             const double* M = &t.Obs[g * 12];
             // sigma points handed to update(): the propagated ones or, with
@@ -937,8 +947,14 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                 for (int c = 0; c < 6; ++c)
                     if (l != 13) sf[c] = xb[c] + sgn * t.UA[g * 36 + krow * 6 + c];
             }
+            // (the left half of the staging row leaves now -- harmless if the object turns out not to be visible -- so that the
+            // prior mean does not have to live across the measurement function)
+            if (l <= 12) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) STG[l * 9 + c] = sf[c] - xb[c];
+            }
             // H1/H2: measurement of every sigma point (lanes 0-12) and of the true state (lane 13)
-            double z[3], enu_vec[3];
+            double enu_vec[3];
             double el_mine;
             {
                 double Mm[9], aer[3];
@@ -995,73 +1011,98 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                         for (int c = 0; c < 3; ++c) rz[c] = zin[c] - zp[c];
                     }
                 }
-                double y[3];
+                upd_go = true;
+                if (l <= 12) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) y[c] = row_bcast<13>(rz[c]);
-                // S = sum Wc rz rz^T + R ; Pxz = sum Wc (sigma_f - x)(rz)^T   -> LDS
+                    for (int c = 0; c < 3; ++c) STG[l * 9 + 6 + c] = rz[c];
+                }
+                if (l == 13) {   // the innovation
 #pragma unroll
-                for (int a = 0; a < 3; ++a)
+                    for (int c = 0; c < 3; ++c) y_row[c] = rz[c];
+                }
+            }
+        }
+    }
+    // ---- Phase 2: whole wavefront, one selected object at a time
+    {
+        unsigned long long pend = __ballot(upd_go);
+        while (pend) {   // (several selected objects in one wavefront -- vectorised envs of fewer than four objects -- take turns)
+            const int gu = (__ffsll((long long)pend) - 1) >> 4;
+            pend &= ~(0xFFFFull << (gu * 16));
+            if (g == gu && l == 13) {
 #pragma unroll
-                    for (int b = a; b < 3; ++b) {
-                        double v = row_allsum(wl * (rz[a] * rz[b]));
-                        if (l == 0) {
-                            W[a * 3 + b] = v + C.R[a * 3 + b];
-                            W[b * 3 + a] = v + C.R[b * 3 + a];
-                        }
-                    }
+                for (int c = 0; c < 3; ++c) W[54 + c] = y_row[c];
+            }
+            wave_lds_sync();
+            // G = [sigma - x | rz]^T (Wc rz)  (9 x 3): rows 0..5 = Pxz, rows 6..8 = S - R.  One v_mfma_f64_4x4x4 per chunk of four
+            // sigma points; its blocks (lane bits 3:2) take the row tiles 0-3, 4-7 and 8 of the left operand;
+            // k = lane bits 5:4, i / j = lane bits 1:0 (see moment_sums_mfma)
+            {
+                const int kk = lane >> 4, blk = (lane >> 2) & 3, ij = lane & 3;
+                const double* SG = &t.UA[gu * 117];
+                const int acol = (blk < 2) ? 4 * blk + ij : 8;     // (block 2: row 8 in every lane, rows 9..11 of G are not used; block 3 idles on it)
+                double acc = 0.0;
 #pragma unroll
-                for (int a = 0; a < 6; ++a) {
-                    const double dxa = sf[a] - xb[a];
+                for (int cch = 0; cch < 4; ++cch) {
+                    const int k = (cch < 3) ? 4 * cch + kk : 12;   // sigma point; the last chunk holds point 12 and three empty slots
+                    const double* row = &SG[k * 9];
+                    double av = row[acol];
+                    double bv = row[6 + (ij < 3 ? ij : 2)] * ((cch == 0 && kk == 0) ? C.Wc0 : C.Wi);
+                    if (cch == 3 && kk != 0) { av = 0.0; bv = 0.0; }
+                    acc = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, acc, 0, 0, 0);
+                }
+                // result lane (i = lane bits 5:4, blk, j = lane bits 1:0) holds G[4 blk + i][j]
+                const int ri = 4 * blk + kk;
+                if (ij < 3 && ri < 6) W[9 + ri * 3 + ij] = acc;
+                if (ij < 3 && ri >= 6 && ri < 9 && ri - 6 <= ij) {   // S symmetric by construction: the upper triangle, mirrored
+                    const int a = ri - 6;
+                    W[a * 3 + ij] = acc + C.R[a * 3 + ij];
+                    W[ij * 3 + a] = acc + C.R[ij * 3 + a];
+                }
+            }
+            wave_lds_sync();
+            SSA_TR(12);
+            bool inv_ok;
+            double SI[9];
+            {
+                double S[9];
 #pragma unroll
-                    for (int b = 0; b < 3; ++b) {
-                        double v = row_allsum(wl * (dxa * rz[b]));
-                        if (l == 0) W[9 + a * 3 + b] = v;
-                    }
+                for (int c = 0; c < 9; ++c) S[c] = W[c];
+                inv_ok = inv3(S, SI);          // (every lane: the inverse stays in registers)
+            }
+            bool nan_u = false;
+            if (inv_ok) {
+                // K = Pxz inv(S): 18 entries, one per lane
+                if (lane < 18) {
+                    const int a = lane / 3, b = lane - 3 * a;
+                    W[36 + lane] = W[9 + a * 3] * SI[b] + W[9 + a * 3 + 1] * SI[3 + b] + W[9 + a * 3 + 2] * SI[6 + b];
                 }
                 wave_lds_sync();
-                SSA_TR(12);
-                bool inv_ok;
-                {
-                    double S[9], SI[9];
+                SSA_TR(13);
+                // x += K y  (lanes 0..5); P -= K S K^T (36 entries, one per lane)
+                double xn = 0.0;
+                if (lane < 6) xn = t.X[gu * 6 + lane] + (W[36 + lane * 3] * W[54] + W[36 + lane * 3 + 1] * W[55] + W[36 + lane * 3 + 2] * W[56]);
+                nan_u = __ballot(lane < 6 && xn != xn) != 0;
+                if (lane < 36) {
+                    const int a = lane / 6, b = lane - 6 * a;
+                    double corr = 0.0;
 #pragma unroll
-                    for (int c = 0; c < 9; ++c) S[c] = W[c];
-                    inv_ok = inv3(S, SI);
-                    if (l == 0) {
-#pragma unroll
-                        for (int c = 0; c < 9; ++c) W[27 + c] = SI[c];
+                    for (int u = 0; u < 3; ++u) {
+                        const double sk = W[u * 3] * W[36 + b * 3] + W[u * 3 + 1] * W[36 + b * 3 + 1] + W[u * 3 + 2] * W[36 + b * 3 + 2];  // (S K^T)[u][b]
+                        corr = fma(W[36 + a * 3 + u], sk, corr);
                     }
+                    t.P[gu * 36 + lane] = t.P[gu * 36 + lane] - corr;
                 }
-                wave_lds_sync();
-                if (!inv_ok) {
-                    st_new = SSA_ST_UPDATE_LINALG;
-                } else {
+                if (lane < 6) t.X[gu * 6 + lane] = xn;
+                SSA_TR(14);
+            }
+            if (g == gu) {
+                if (!inv_ok) st_new = SSA_ST_UPDATE_LINALG;
+                else {
                     taken = true;
-                    // K = Pxz inv(S): 18 entries over the row's lanes
-                    for (int idx = l; idx < 18; idx += 16) {
-                        const int a = idx / 3, b = idx - 3 * a;
-                        W[36 + idx] = W[9 + a * 3] * W[27 + b] + W[9 + a * 3 + 1] * W[30 + b] + W[9 + a * 3 + 2] * W[33 + b];
-                    }
-                    wave_lds_sync();
-                    SSA_TR(13);
-                    // x += K y  (lanes 0..5); P -= K S K^T (36 entries over the row's lanes)
-                    double xn = 0.0;
-                    if (l < 6) xn = t.X[g * 6 + l] + (W[36 + l * 3] * y[0] + W[36 + l * 3 + 1] * y[1] + W[36 + l * 3 + 2] * y[2]);
-                    const bool nan_u = ((__ballot(l < 6 && xn != xn) >> (g * 16)) & 0xFFFFull) != 0;
-                    for (int idx = l; idx < 36; idx += 16) {
-                        const int a = idx / 6, b = idx - 6 * a;
-                        double corr = 0.0;
-#pragma unroll
-                        for (int u = 0; u < 3; ++u) {
-                            const double sk = W[u * 3] * W[36 + b * 3] + W[u * 3 + 1] * W[36 + b * 3 + 1] + W[u * 3 + 2] * W[36 + b * 3 + 2];  // (S K^T)[u][b]
-                            corr = fma(W[36 + a * 3 + u], sk, corr);
-                        }
-                        t.P[g * 36 + idx] = t.P[g * 36 + idx] - corr;
-                    }
-                    if (l < 6) t.X[g * 6 + l] = xn;
-                    SSA_TR(14);
                     if (nan_u) st_new = SSA_ST_UPDATE_NAN;
                     if (rec) {
-                        if (l < 3) rec[SSA_UPD_Y + l] = y[l == 0 ? 0 : (l == 1 ? 1 : 2)];
+                        if (l < 3) rec[SSA_UPD_Y + l] = W[54 + l];
                         if (l < 9) rec[SSA_UPD_S + l] = W[l];
                         if (is_sigma) {
 #pragma unroll
@@ -1070,12 +1111,13 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                     }
                 }
             }
+            wave_lds_sync();   // (the next selected object reuses W)
         }
-        if (rec && l == 0) {
-            rec[SSA_UPD_OBS_TAKEN] = taken ? 1.0 : 0.0;
-            rec[SSA_UPD_VISIBLE] = visible ? 1.0 : 0.0;
-            rec[SSA_UPD_ACTION] = attempted ? (double)act : -1.0;
-        }
+    }
+    if (my_update && rec && l == 0) {
+        rec[SSA_UPD_OBS_TAKEN] = taken ? 1.0 : 0.0;
+        rec[SSA_UPD_VISIBLE] = visible ? 1.0 : 0.0;
+        rec[SSA_UPD_ACTION] = attempted ? (double)act : -1.0;
     }
     // envs whose action selects nobody still get a cleared record (written by object 0's row)
     if (valid && p.upd && j == 0 && l == 0 && !(act >= 0 && interval_ok && (int64_t)act < p.n_obj)) {
