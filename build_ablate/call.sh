@@ -1,7 +1,2 @@
 mkdir -p gpurun_out
-timeout -k 10 500 python -m pytest tests -m gpu -x -q > gpurun_out/r2z_pytest.log 2>&1; echo "pytest rc $?"; tail -3 gpurun_out/r2z_pytest.log
-FAST=1 PROPS=fg timeout -k 10 400 python build_ablate/time_variants.py > gpurun_out/r2z_variants.txt 2>&1 ; cat gpurun_out/r2z_variants.txt
-FAST=1 M=2000 PROPS=fg timeout -k 10 400 python build_ablate/time_variants.py > gpurun_out/r2z_variants2k.txt 2>&1 ; cat gpurun_out/r2z_variants2k.txt
-cp ssa-gym_amd/libssa_hip.so /tmp/keep.so; cp build_ablate/libs/trace.so ssa-gym_amd/libssa_hip.so
-M=64 timeout -k 10 200 python build_ablate/wave_timeline.py > gpurun_out/r2z_tl64.txt 2>&1; tail -4 gpurun_out/r2z_tl64.txt
-cp /tmp/keep.so ssa-gym_amd/libssa_hip.so
+timeout -k 10 500 python -m pytest tests -m gpu -x -q -k "multi_tile_wavefronts" > gpurun_out/r2z_pytest.log 2>&1; echo "pytest rc $?"; tail -12 gpurun_out/r2z_pytest.log

@@ -2058,7 +2058,11 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
     if (total >= ((int64_t)1 << 31)) return SSA_E_INVALID;
     // tiles per wavefront T = ceil(tiles / resident wavefront slots); G = ceil(tiles / T) wavefronts
     const int64_t ntiles = (total + OBJ_PER_WAVE - 1) / OBJ_PER_WAVE;
+#ifdef SSA_SLOTS_DIV   // (diagnostic: fewer, longer wavefronts)
+    const int64_t slots = (int64_t)device_cu_count() * 4 * SSA_STEP_WAVES / SSA_SLOTS_DIV;
+#else
     const int64_t slots = (int64_t)device_cu_count() * 4 * SSA_STEP_WAVES;
+#endif
     const int64_t per_wave = (ntiles + slots - 1) / slots;
     const int nwork = (int)((ntiles + per_wave - 1) / per_wave);
     const bool fast_stats = p->stat_shards != nullptr;   // statistics by the common-path kernel's atomics

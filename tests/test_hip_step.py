@@ -492,7 +492,8 @@ def test_two_launch_statistics_path_matches_exact_path(hip, E, m, payload):
     assert np.isnan(s0[0, L.STAT_MAX_DPOS]) and s0[0, L.STAT_N_FAILED] >= 1 and s0[E - 1, L.STAT_N_FAILED] >= 1
 
 
-@pytest.mark.parametrize("E,m,fast", [(1, 61443, False), (1, 61443, True), (8, 7001, True), (3, 20001, False)])
+@pytest.mark.parametrize("E,m,fast", [(1, 61443, False), (1, 61443, True), (8, 7001, True), (3, 20001, False),
+                                      (9, 1, True), (7, 2, False), (5, 3, True)])   # (tiny envs: several selected objects -- several updates -- in ONE wavefront)
 def test_multi_tile_wavefronts_equal_single_tile_results(hip, E, m, fast):
     """Above 20 480 objects a wavefront advances several tiles (grid-stride, next tile's loads in flight).
     An object's result must not depend on the batch it travels in: every env of a large batch is compared
