@@ -289,6 +289,9 @@ def main():
                     help="steps per launch of the additional open-loop rollout measurement (0 = skip); never `value`")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU rehearsal of the N-rank launch path (gloo, no GPU, no step arithmetic); never a measurement")
+    ap.add_argument("--payload", default="trace", choices=["trace", "aer"],
+                    help="sharded runs: what the per-step all-gather carries per object -- trace P (BASELINE config 4: \"all-gather of per-object "
+                         "covariance-trace obs\") or the four-column (az, el, range, trace P) block of the 'aer' observation mode")
     ap.add_argument("--no-legs", action="store_true", help="skip the additional N=1 legs (j2, elements, resample, gym_api, closed_loop)")
     args = ap.parse_args()
 
@@ -347,7 +350,8 @@ def main():
     total_steps = W + K
     glob_actions = np.arange(total_steps) % plan.m_total
     local.load_schedule([plan.local_action(int(a)) for a in glob_actions])
-    sharded = parallel.ShardedStepper(plan, local) if use_dist else None
+    obs_cols = 1 if args.payload == "trace" else 4
+    sharded = parallel.ShardedStepper(plan, local, obs_cols=obs_cols) if use_dist else None
 
     # episodes of the reference's default length (env_config['steps'] = 480: step indices 1..479), then a
     # reset from the device-resident initial state -- a predict-only UKF at alpha = 1e-4 is numerically
@@ -514,7 +518,7 @@ def main():
                                    "UKF predict (13 sigma points) + 1 az-el-range update/step%s" %
                                    (m, world, {"fg": "two-body Farnocchia (fg)", "elements": "two-body Farnocchia (elements)",
                                                "j2": "two-body + J2 RK4 propagator (EXTENSION, no reference counterpart; 4 sub-steps)"}[args.propagator],
-                                    ", sharded env with RCCL all-gather of (az,el,range,trP) obs + reward stats" if use_dist else ""),
+                                    (", sharded env with one RCCL all-gather per step of %s + reward statistics" % ("per-object trace P (BASELINE config 4)" if obs_cols == 1 else "the (az,el,range,trP) observation block")) if use_dist else ""),
                        "objects_per_gpu": m, "objects_total": m * world, "alpha": 1e-4, "dt_s": 20.0,
                        "propagator": args.propagator, "parallelism": "object-shard x%d" % world,
                        "allgather": (("comm-stream (overlapped with the next step)" if state["overlap"] else "in-stream")
@@ -523,6 +527,7 @@ def main():
                                           if sharded._rccl is not None else "torch.distributed.all_gather_into_tensor")
                                          if sharded is not None else None),
                        "allgather_warmup_probe": allgather_probe,
+                       "allgather_bytes_per_rank": (sharded.width * 8 if sharded is not None else None),
                        "rccl_ranks": (sharded._rccl.count() if (sharded is not None and sharded._rccl is not None)
                                       else (dist.get_world_size() if use_dist else None)),
                        "ukf_variant": "keep propagated sigma points for update() (default; PARITY-UNPINNED, see `resample`)"},

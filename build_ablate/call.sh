@@ -1,2 +1,2 @@
 mkdir -p gpurun_out
-timeout -k 10 300 python build_ablate/closed_loop_parts.py > gpurun_out/r2z_cl.txt 2>&1; cat gpurun_out/r2z_cl.txt
+timeout -k 10 500 python -m pytest tests -m gpu -x -q > gpurun_out/r2z_pytest.log 2>&1; echo "pytest rc $?"; tail -3 gpurun_out/r2z_pytest.log

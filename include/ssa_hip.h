@@ -155,6 +155,10 @@ typedef struct ssa_step_params {
                                   multi-GPU step sends its rank's shard words in the all-gather payload and every rank
                                   folds all ranks' words itself -- alternate two payload buffers without a fold / clear
                                   launch: step k accumulates into buffer k & 1 and clears buffer (k + 1) & 1. */
+    int32_t aer_cols;          /* columns of aer_out per object: 0 or 4 = (az, el, range, trace P); 1 = trace P only, [E*m] --
+                                  the "per-object covariance-trace observation" of the sharded 160 000-object configuration:
+                                  a quarter of the all-gather payload and no inverse trigonometry in the epilogue */
+    int32_t reserved1;
 } ssa_step_params;
 
 /* ---------------------------------------------------------------- fused hot path

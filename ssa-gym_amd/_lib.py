@@ -33,7 +33,7 @@ class ssa_step_params(C.Structure):
         ("zn_stride_env", C.c_int64), ("zn_stride_time", C.c_int64), ("zn_stride_obj", C.c_int64),
         ("n_time", C.c_int32), ("launch_mask", C.c_uint32), ("stats", c_dp), ("work", c_dp), ("stat_ws", c_dp),
         ("stat_shards", c_dp), ("stat_shards_prev", c_dp), ("stats_prev", c_dp), ("aer_out", c_dp),
-        ("stat_shards_clear", c_dp),
+        ("stat_shards_clear", c_dp), ("aer_cols", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 

@@ -659,6 +659,11 @@ SSA_DEV int time_row(int tix, int n_time)
 // O4 for one object (ssa_tasker_simple_2.py:834-840): [hx(x_filter[:3]), trace(P)], NaN/inf -> 0.001
 SSA_DEV void aer_obs_row(const double* x, const double* P, const ssa_step_params& p, const ssa_consts& C, int e, int64_t obj)
 {
+    if (p.aer_cols == 1) {   // trace P only
+        const double tr1 = P[0] + P[7] + P[14] + P[21] + P[28] + P[35];
+        p.aer_out[obj] = (fabs(tr1) <= 1.79769313486231570e308) ? tr1 : 0.001;
+        return;
+    }
     const int tix = p.env_time[e] + p.time_offset;
     const double* M = p.trans + (int64_t)((p.n_time > 0) ? tix % p.n_time : 0) * 9;
     double Mm[9], xx[3] = {x[0], x[1], x[2]}, z[3];
@@ -695,6 +700,14 @@ SSA_DEV void aer_obs_tile_at(const Tiles& t, const ssa_step_params& p, const ssa
 }
 SSA_DEV void aer_obs_tile(const Tiles& t, const ssa_step_params& p, const ssa_consts& C, int g, int l, int e, int64_t obj)
 {
+    if (p.aer_cols == 1) {   // trace P only: lane 0 of the row
+        if (l == 0) {
+            const double* P = &t.P[g * 36];
+            const double tr = P[0] + P[7] + P[14] + P[21] + P[28] + P[35];
+            p.aer_out[obj] = (fabs(tr) <= 1.79769313486231570e308) ? tr : 0.001;
+        }
+        return;
+    }
     // one env: the time index is wave-uniform, so the GCRS->ITRS matrix arrives by scalar loads (nine per-lane loads otherwise)
     if (p.n_env > 1) aer_obs_tile_at(t, p, C, g, l, obj, p.env_time[e] + p.time_offset);
     else aer_obs_tile_at(t, p, C, g, l, obj, p.env_time[0] + p.time_offset);
@@ -1120,7 +1133,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         rec[SSA_UPD_ACTION] = attempted ? (double)act : -1.0;
     }
     // envs whose action selects nobody still get a cleared record (written by object 0's row)
-    if (valid && p.upd && j == 0 && l == 0 && !(act >= 0 && interval_ok && (int64_t)act < p.n_obj)) {
+    if (valid && p.upd && obj == (int64_t)e * p.n_obj && l == 0 && !(act >= 0 && interval_ok && (int64_t)act < p.n_obj)) {   // (not `j`: it would live across the whole kernel)
         double* rec = p.upd + (int64_t)e * SSA_UPD_STRIDE;
         rec[SSA_UPD_OBS_TAKEN] = 0.0;
         rec[SSA_UPD_VISIBLE] = 0.0;
@@ -2051,6 +2064,7 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
         !p->obs || !p->metrics || !p->trans || !p->env_time || !p->actions || !p->z_noise || !p->stat_ws)
         return SSA_E_INVALID;
     if (c->obs_type != SSA_OBS_AER && c->obs_type != SSA_OBS_XYZ) return SSA_E_INVALID;
+    if (p->aer_cols != 0 && p->aer_cols != 1 && p->aer_cols != 4) return SSA_E_INVALID;
     StepK k;
     k.c = *c;
     k.p = *p;

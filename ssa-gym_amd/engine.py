@@ -134,11 +134,11 @@ class HotPathEngine:
         self.status.zero_()
 
     # ------------------------------------------------------------------ one step
-    def _step_params(self, slot_in, slot_out, aer_out, stats_out, upd_out, shard_set, shards_out=0, shards_clear=0):
+    def _step_params(self, slot_in, slot_out, aer_out, stats_out, upd_out, shard_set, shards_out=0, shards_clear=0, aer_cols=4):
         """parameter block of a step between two history slots: everything but the time index, the action pointer and the
         deferred-fold hand-over is fixed per (slot pair, outputs, shard set), so the blocks are built once and cached -- a
         step then costs a handful of field stores on the host instead of twenty"""
-        key = (slot_in, slot_out, aer_out, stats_out, upd_out, shard_set, shards_out, shards_clear)
+        key = (slot_in, slot_out, aer_out, stats_out, upd_out, shard_set, shards_out, shards_clear, aer_cols)
         ent = self._pcache.get(key)
         if ent is None:
             p = _lib.ssa_step_params()
@@ -154,6 +154,7 @@ class HotPathEngine:
             p.stat_shards = self._shard_sets[shard_set].data_ptr() if shard_set >= 0 else 0
             p.stat_shards_prev, p.stats_prev, p.launch_mask = 0, 0, 0
             p.stat_shards_clear = 0
+            p.aer_cols = int(aer_cols)
             if shards_out:      # raw-shard consumer (include/ssa_hip.h: stat_shards_clear): no fold, no `stats`
                 p.stat_shards, p.stats, p.stat_shards_clear = shards_out, 0, shards_clear
             ent = (p, C.byref(p), int(p.stats or 0))
@@ -163,7 +164,7 @@ class HotPathEngine:
         return ent
 
     def launch_step(self, slot_in, slot_out, time_offset, actions_ptr=None, stream=None, aer_out=0, stats_out=0, upd_out=0,
-                    fast_stats=False, defer_fold=False, profile_slot=None, shards_out=0, shards_clear=0):
+                    fast_stats=False, defer_fold=False, profile_slot=None, shards_out=0, shards_clear=0, aer_cols=4):
         """enqueue the step; asynchronous, no host sync.  fast_stats: statistics by the step kernel's atomics (two
         launches, no arg-max of sigma_pos).  defer_fold (with fast_stats): ONE launch -- this step's
         statistics are folded by extra wavefronts of the NEXT deferred step, or by flush_stats()."""
@@ -174,7 +175,7 @@ class HotPathEngine:
         if not defer and self._fold_pending is not None:
             self.flush_stats(s)       # a deferred step is followed by an immediate one: fold it first (same stream, in order)
         p, pref, stats_ptr = self._step_params(slot_in, slot_out, aer_out, stats_out, upd_out, self._shard_cur if fast_stats else -1,
-                                               shards_out, shards_clear)
+                                               shards_out, shards_clear, aer_cols)
         p.time_offset = int(time_offset)
         p.actions = self._actions_ptr if actions_ptr is None else actions_ptr
         if defer and self._fold_pending is not None:

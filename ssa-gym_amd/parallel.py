@@ -6,7 +6,8 @@ exchange is the per-step reassembly of the global observation vector plus the re
 reductions.  Both travel in ONE all-gather per step (RCCL over xGMI through
 torch.distributed's "nccl" backend; "gloo" in the CPU tests): each rank contributes
 
-    [ aer_obs (4 doubles per local object: az, el, range, trace P -- ssa_tasker_simple_2.py:834) |
+    [ aer_obs (4 doubles per local object: az, el, range, trace P -- ssa_tasker_simple_2.py:834; or, with
+      obs_cols = 1, trace P alone: the "per-object covariance-trace observation" of BASELINE config 4) |
       8 reward statistics (include/ssa_hip.h SSA_STAT_*) ]
 
 and every rank then holds the whole (4 * m_total) observation vector and reduces the statistics
@@ -85,8 +86,9 @@ class ShardedStepper:
     xGMI while the compute stream already runs the kernels of step k+1; the compute stream only waits
     (on an event, not on the host) before it overwrites a payload buffer two steps later."""
 
-    def __init__(self, plan, local, group=None, direct_rccl=True):
-        self.plan, self.local, self.group = plan, local, group
+    def __init__(self, plan, local, group=None, direct_rccl=True, obs_cols=4):
+        assert obs_cols in (1, 4)
+        self.plan, self.local, self.group, self.cols = plan, local, group, int(obs_cols)
         self._rccl = None
         dev = local.device
         # payload of one rank: [ aer block 4 * m_pad | 8 folded statistics | 256 raw statistics words (uint64 bit patterns) ]
@@ -95,7 +97,7 @@ class ShardedStepper:
         # folded statistics.  (The step kernel of step k also zeroes the raw words of the OTHER send buffer, whose last
         # all-gather has completed in stream order; with the all-gather on a communication stream that is not guaranteed,
         # so the overlapped mode keeps the folded form.)
-        self.width = 4 * plan.m_pad + STAT_STRIDE + RAW_WORDS
+        self.width = self.cols * plan.m_pad + STAT_STRIDE + RAW_WORDS
         self.send = [torch.zeros(self.width, dtype=torch.float64, device=dev) for _ in range(2)]
         self.recv = [torch.zeros(plan.world * self.width, dtype=torch.float64, device=dev) for _ in range(2)]
         self._raw = [False, False]
@@ -127,13 +129,14 @@ class ShardedStepper:
             torch.cuda.current_stream().wait_event(self._done[b])   # payload of step k-2 has left
             self._pending[b] = False
         # kernels of this step write (az, el, range, trP) and the statistics straight into `send`
-        o_st = 4 * p.m_pad
+        o_st = self.cols * p.m_pad
+        kw = {} if self.cols == 4 else {"obs_cols": self.cols}
         raw = bool(getattr(self.local, "raw_shards", False)) and not overlap
         if raw:
-            self.local.step(p.local_action(global_action), send[:4 * p.m_local], None,
-                            shards_out=send[o_st + STAT_STRIDE:], shards_clear=self.send[b ^ 1][o_st + STAT_STRIDE:])
+            self.local.step(p.local_action(global_action), send[:self.cols * p.m_local], None,
+                            shards_out=send[o_st + STAT_STRIDE:], shards_clear=self.send[b ^ 1][o_st + STAT_STRIDE:], **kw)
         else:
-            self.local.step(p.local_action(global_action), send[:4 * p.m_local], send[o_st:o_st + STAT_STRIDE])
+            self.local.step(p.local_action(global_action), send[:self.cols * p.m_local], send[o_st:o_st + STAT_STRIDE], **kw)
         self._raw[b] = raw
         if not use_dist:   # single process without a process group
             recv.copy_(send)
@@ -172,12 +175,12 @@ class ShardedStepper:
     def global_obs(self):
         p = self.plan
         rows = self._latest().view(p.world, self.width)
-        return torch.cat([rows[r, :4 * p.sizes[r]] for r in range(p.world)])
+        return torch.cat([rows[r, :self.cols * p.sizes[r]] for r in range(p.world)])
 
     def global_stats(self):
         """reduce the per-rank statistics exactly as the single-GPU kernel would have produced them."""
         p = self.plan
-        rows = self._latest().view(p.world, self.width)[:, 4 * p.m_pad:].cpu().numpy()
+        rows = self._latest().view(p.world, self.width)[:, self.cols * p.m_pad:].cpu().numpy()
         st = rows[:, :STAT_STRIDE]
         out = np.zeros(STAT_STRIDE)
         if self._raw[(self.k - 1) & 1]:      # raw shard words of every rank: fold them as reward_fold_kernel would
@@ -229,7 +232,7 @@ class HipLocalStepper:
         """fold the statistics of the last deferred step."""
         self.engine.flush_stats()
 
-    def step(self, local_action, obs_out=None, stats_out=None, profile_slot=None, shards_out=None, shards_clear=None):
+    def step(self, local_action, obs_out=None, stats_out=None, profile_slot=None, shards_out=None, shards_clear=None, obs_cols=4):
         """enqueue one env step; when given, the post kernel writes the shard's aer observation
         block and its reward statistics directly into `obs_out` / `stats_out` (the all-gather payload)."""
         e = self.engine
@@ -242,12 +245,13 @@ class HipLocalStepper:
             k = (self.tick - 1 - self._sched_k0) % self._sched.numel()
             e.launch_step((self.tick - 1) % e.H, self.tick % e.H, self.tick, actions_ptr=self._sched.data_ptr() + 4 * k,
                           aer_out=aer, stats_out=st, fast_stats=self.fast_stats, defer_fold=self.defer_fold and stats_out is None,
-                          profile_slot=profile_slot, shards_out=so, shards_clear=sc)
+                          profile_slot=profile_slot, shards_out=so, shards_clear=sc, aer_cols=obs_cols)
             return
         self._act[0] = int(local_action)
         e.actions.copy_(self._act)
         e.launch_step((self.tick - 1) % e.H, self.tick % e.H, self.tick, aer_out=aer, stats_out=st, fast_stats=self.fast_stats,
-                      defer_fold=self.defer_fold and stats_out is None, profile_slot=profile_slot, shards_out=so, shards_clear=sc)
+                      defer_fold=self.defer_fold and stats_out is None, profile_slot=profile_slot, shards_out=so, shards_clear=sc,
+                      aer_cols=obs_cols)
 
     def rollout(self, n_steps):
         """advance n_steps of the pre-staged schedule in ONE launch (open-loop actions; HotPathEngine.launch_rollout)."""

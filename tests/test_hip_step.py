@@ -492,6 +492,29 @@ def test_two_launch_statistics_path_matches_exact_path(hip, E, m, payload):
     assert np.isnan(s0[0, L.STAT_MAX_DPOS]) and s0[0, L.STAT_N_FAILED] >= 1 and s0[E - 1, L.STAT_N_FAILED] >= 1
 
 
+@pytest.mark.parametrize("fast", [False, True])
+def test_trace_only_payload_is_column_3_of_the_aer_block(hip, fast):
+    """ssa_step_params.aer_cols = 1 (the per-object covariance-trace observation of the sharded 160 000-object configuration):
+    the payload is [E*m] trace P -- bit for bit the fourth column of the four-column block, from the epilogue of the step
+    kernel (fast) and from the post kernel alike; any other column count is refused."""
+    E, m = 2, 1003
+    xt, x, P, g = make_batch(E * m, seed=43)
+    P[7] = np.nan * np.eye(6)                      # a failed filter: its covariance becomes the sentinel diagonal (trace 3e20)
+    consts = hip.host.make_consts(g["Q"], g["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, g["obs_lla"])
+    res = {}
+    for cols in (4, 1):
+        eng = hip.engine.HotPathEngine(consts, m, E, c2t(), np.zeros((E, 480, m, 3)), history=2)
+        eng.load_state(0, xt, x, P)
+        eng.set_actions([5, 11])
+        out = hip.torch.full((E * m * cols,), -7.0, dtype=hip.torch.float64, device="cuda")
+        eng.launch_step(0, 1, 4, fast_stats=fast, aer_out=out.data_ptr(), aer_cols=cols)
+        hip.torch.cuda.synchronize()
+        res[cols] = out.cpu().numpy()
+    assert np.array_equal(res[1], res[4].reshape(-1, 4)[:, 3]) and res[1][7] > 1e20 and (res[1] > 0).all()
+    with pytest.raises(hip.lib.SsaHipError):
+        eng.launch_step(1, 0, 5, fast_stats=fast, aer_out=out.data_ptr(), aer_cols=3)
+
+
 @pytest.mark.parametrize("E,m,fast", [(1, 61443, False), (1, 61443, True), (8, 7001, True), (3, 20001, False),
                                       (9, 1, True), (7, 2, False), (5, 3, True)])   # (tiny envs: several selected objects -- several updates -- in ONE wavefront)
 def test_multi_tile_wavefronts_equal_single_tile_results(hip, E, m, fast):

@@ -28,15 +28,16 @@ class OracleLocalStepper:
 
     raw_shards = False     # True: hand the statistics over as raw shard words, the way the HIP step kernel's atomics leave them
 
-    def step(self, a, obs_out=None, stats_out=None, shards_out=None, shards_clear=None):
+    def step(self, a, obs_out=None, stats_out=None, shards_out=None, shards_clear=None, obs_cols=4):
         self.tick += 1
+        self.cols = obs_cols
         ep = self.ep
         zn = ep["z_noise"][self.tick, self.lo + a] if a >= 0 else np.zeros(3)
         r = self.o.env_step(self.xt, self.x, self.P, self.status, 20.0, ep["Q"], ep["R"], self.Wm, self.Wc, self.scale, a,
                             self.c2t[self.tick], ep["obs_lla"], ep["obs_itrs"], -np.pi / 2, zn)
         self.xt, self.x, self.P, self.met = r["x_true"], r["x"], r["P"], r["metrics"]
         if obs_out is not None and shards_out is not None:   # raw form: max delta_pos as ordered bits | packed counts | failures, spread
-            obs_out.copy_(torch.as_tensor(self.o.aer_obs(self.x, self.P, self.c2t[self.tick], self.ep["obs_lla"], self.ep["obs_itrs"])))
+            obs_out.copy_(torch.as_tensor(self._obs()))
             w = np.zeros((128, 16), dtype=np.uint64)             # over a few shards (one 128-byte line each) like the kernel's per-tile atomics
             d = self.met[0]
             for t0 in range(0, len(d), 4):
@@ -50,15 +51,19 @@ class OracleLocalStepper:
         elif obs_out is not None:
             self.pack_into(obs_out, stats_out)
 
+    def _obs(self):
+        a = self.o.aer_obs(self.x, self.P, self.c2t[self.tick], self.ep["obs_lla"], self.ep["obs_itrs"])
+        return a if getattr(self, "cols", 4) == 4 else np.ascontiguousarray(a.reshape(-1, 4)[:, 3])   # (trace P alone)
+
     def pack_into(self, obs_out, stats_out):
         ep = self.ep
-        obs_out.copy_(torch.as_tensor(self.o.aer_obs(self.x, self.P, self.c2t[self.tick], ep["obs_lla"], ep["obs_itrs"])))
+        obs_out.copy_(torch.as_tensor(self._obs()))
         d, s = self.met[0], self.met[2]
         stats_out.copy_(torch.tensor([d.max(), (d < 1e4).sum(), (d < 1e7).sum(), np.argmax(s), (self.status != 0).sum(),
                                       s.max(), 0, 0], dtype=torch.float64))
 
 
-def _worker(rank, world, port, q, raw=False):
+def _worker(rank, world, port, q, raw=False, cols=4):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -74,7 +79,7 @@ def _worker(rank, world, port, q, raw=False):
     sl = slice(plan.lo, plan.hi)
     local = OracleLocalStepper(xt[sl], x[sl], P[sl], ep, c2t, plan.lo)
     local.raw_shards = raw
-    sh = parallel.ShardedStepper(plan, local)
+    sh = parallel.ShardedStepper(plan, local, obs_cols=cols)
     outs = []
     for i in range(1, 6):
         a = [3, 12, 18, 0, 9][i - 1]
@@ -101,16 +106,16 @@ def test_shard_plan():
         assert all(p.local_action(-1) == -1 for p in plans)
 
 
-@pytest.mark.parametrize("raw", [False, True])
-def test_sharded_env_matches_unsharded_world2(raw):
+@pytest.mark.parametrize("raw,cols", [(False, 4), (True, 4), (True, 1)])
+def test_sharded_env_matches_unsharded_world2(raw, cols):
     """raw = True: the statistics cross the all-gather as raw shard words (what the HIP step kernel's atomics leave in the send
     buffer: no fold launch) and every rank folds all ranks' words on arrival."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from ssa_gym_amd import parallel
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + (7 if raw else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, raw)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + (7 if raw else 0) + (13 if cols == 1 else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, raw, cols)) for r in range(2)]
     for p in procs:
         p.start()
     outs = q.get(timeout=120)
@@ -123,11 +128,11 @@ def test_sharded_env_matches_unsharded_world2(raw):
     m = 19
     plan1 = parallel.ShardPlan(m, 1, 0)
     local = OracleLocalStepper(ep["x_true0"][:m], ep["x0"][:m], np.tile(ep["P0"], (m, 1, 1)), ep, c2t, 0)
-    sh = parallel.ShardedStepper(plan1, local)
+    sh = parallel.ShardedStepper(plan1, local, obs_cols=cols)
     for i, a in enumerate([3, 12, 18, 0, 9]):
         sh.step(a)
         obs, st = sh.global_obs().numpy(), sh.global_stats()
-        assert np.array_equal(obs, outs[i][0])          # bit-identical observation vector
+        assert np.array_equal(obs, outs[i][0]) and obs.shape == (cols * m,)   # bit-identical observation vector (cols = 1: trace P per object)
         if raw:                                         # (the raw form carries no arg-max of sigma_pos, as on the GPU)
             k = [parallel.STAT_MAX_DPOS, parallel.STAT_CNT_LT_1E4, parallel.STAT_CNT_LT_1E7, parallel.STAT_N_FAILED]
             assert np.array_equal(st[k], outs[i][1][k]) and outs[i][1][parallel.STAT_ARGMAX_SPOS] == -1
