@@ -102,6 +102,15 @@ class ShardedStepper:
         self.recv = [torch.zeros(plan.world * self.width, dtype=torch.float64, device=dev) for _ in range(2)]
         self._raw = [False, False]
         self.k = 0
+        # the slices of the payload buffers the local stepper writes into, built once (a tensor slice costs the host 1-2 us:
+        # at 13 us of GPU work per step the per-step host path decides whether the collective can hide behind the compute)
+        o_st = self.cols * plan.m_pad
+        self._v_obs = [s[:self.cols * plan.m_local] for s in self.send]
+        self._v_stats = [s[o_st:o_st + STAT_STRIDE] for s in self.send]
+        self._v_shards = [s[o_st + STAT_STRIDE:] for s in self.send]
+        self._kw = {} if self.cols == 4 else {"obs_cols": self.cols}
+        self._use_dist = dist.is_available() and dist.is_initialized()
+        self._local_raw = bool(getattr(local, "raw_shards", False))
         self._gpu = torch.device(dev).type == "cuda"
         if self._gpu:
             self.comm = torch.cuda.Stream(device=dev)
@@ -123,32 +132,36 @@ class ShardedStepper:
         p = self.plan
         b = self.k & 1
         send, recv = self.send[b], self.recv[b]
-        use_dist = dist.is_available() and dist.is_initialized()
+        use_dist = self._use_dist
         overlap = overlap and self._gpu and use_dist
+        cur = torch.cuda.current_stream() if self._gpu else None
         if overlap and self._pending[b]:
-            torch.cuda.current_stream().wait_event(self._done[b])   # payload of step k-2 has left
+            cur.wait_event(self._done[b])   # payload of step k-2 has left
             self._pending[b] = False
-        # kernels of this step write (az, el, range, trP) and the statistics straight into `send`
-        o_st = self.cols * p.m_pad
-        kw = {} if self.cols == 4 else {"obs_cols": self.cols}
-        raw = bool(getattr(self.local, "raw_shards", False)) and not overlap
+        # kernels of this step write the observation block and the statistics straight into `send`
+        raw = self._local_raw and not overlap
+        kw = dict(self._kw, stream=cur.cuda_stream) if self._gpu else self._kw   # (the stream handle, looked up once per step)
         if raw:
-            self.local.step(p.local_action(global_action), send[:self.cols * p.m_local], None,
-                            shards_out=send[o_st + STAT_STRIDE:], shards_clear=self.send[b ^ 1][o_st + STAT_STRIDE:], **kw)
+            self.local.step(p.local_action(global_action), self._v_obs[b], None,
+                            shards_out=self._v_shards[b], shards_clear=self._v_shards[b ^ 1], **kw)
         else:
-            self.local.step(p.local_action(global_action), send[:self.cols * p.m_local], send[o_st:o_st + STAT_STRIDE], **kw)
+            self.local.step(p.local_action(global_action), self._v_obs[b], self._v_stats[b], **kw)
         self._raw[b] = raw
         if not use_dist:   # single process without a process group
             recv.copy_(send)
         elif overlap:
-            self._ready[b].record(torch.cuda.current_stream())
+            self._ready[b].record(cur)
             self.comm.wait_event(self._ready[b])
-            with torch.cuda.stream(self.comm):
+            if self._rccl is not None:     # (enqueued into the communication stream by handle: no current-stream switch on the host)
                 self._all_gather(recv, send, self.comm)
                 self._done[b].record(self.comm)
+            else:
+                with torch.cuda.stream(self.comm):
+                    self._all_gather(recv, send, self.comm)
+                    self._done[b].record(self.comm)
             self._pending[b] = True
         elif self._gpu:
-            self._all_gather(recv, send, torch.cuda.current_stream())
+            self._all_gather(recv, send, cur)
         else:
             dist.all_gather_into_tensor(recv, send, group=self.group)
         self.k += 1
@@ -232,7 +245,8 @@ class HipLocalStepper:
         """fold the statistics of the last deferred step."""
         self.engine.flush_stats()
 
-    def step(self, local_action, obs_out=None, stats_out=None, profile_slot=None, shards_out=None, shards_clear=None, obs_cols=4):
+    def step(self, local_action, obs_out=None, stats_out=None, profile_slot=None, shards_out=None, shards_clear=None, obs_cols=4,
+             stream=None):
         """enqueue one env step; when given, the post kernel writes the shard's aer observation
         block and its reward statistics directly into `obs_out` / `stats_out` (the all-gather payload)."""
         e = self.engine
@@ -245,13 +259,13 @@ class HipLocalStepper:
             k = (self.tick - 1 - self._sched_k0) % self._sched.numel()
             e.launch_step((self.tick - 1) % e.H, self.tick % e.H, self.tick, actions_ptr=self._sched.data_ptr() + 4 * k,
                           aer_out=aer, stats_out=st, fast_stats=self.fast_stats, defer_fold=self.defer_fold and stats_out is None,
-                          profile_slot=profile_slot, shards_out=so, shards_clear=sc, aer_cols=obs_cols)
+                          profile_slot=profile_slot, shards_out=so, shards_clear=sc, aer_cols=obs_cols, stream=stream)
             return
         self._act[0] = int(local_action)
         e.actions.copy_(self._act)
         e.launch_step((self.tick - 1) % e.H, self.tick % e.H, self.tick, aer_out=aer, stats_out=st, fast_stats=self.fast_stats,
                       defer_fold=self.defer_fold and stats_out is None, profile_slot=profile_slot, shards_out=so, shards_clear=sc,
-                      aer_cols=obs_cols)
+                      aer_cols=obs_cols, stream=stream)
 
     def rollout(self, n_steps):
         """advance n_steps of the pre-staged schedule in ONE launch (open-loop actions; HotPathEngine.launch_rollout)."""
