@@ -81,10 +81,14 @@ def _direct_communicator(dev, group):
 class ShardedStepper:
     """one env of m_total objects, one rank per shard.
 
-    Two send/receive buffer pairs alternate.  With `overlap=True` (GPU) the all-gather of step k is
+    Three send/receive buffer pairs rotate.  With `overlap=True` (GPU) the all-gather of step k is
     issued on a dedicated communication stream behind an event, so RCCL moves step k's payload over
     xGMI while the compute stream already runs the kernels of step k+1; the compute stream only waits
-    (on an event, not on the host) before it overwrites a payload buffer two steps later."""
+    (on an event, not on the host) before it touches a payload buffer again: step k accumulates into
+    buffer k % 3 and zeroes the statistics words of buffer (k + 1) % 3, whose all-gather was issued at
+    step k - 2 -- one whole step of slack, so the raw-statistics form (no fold launch) works in both modes."""
+
+    NB = 3
 
     def __init__(self, plan, local, group=None, direct_rccl=True, obs_cols=4):
         assert obs_cols in (1, 4)
@@ -94,13 +98,12 @@ class ShardedStepper:
         # payload of one rank: [ aer block 4 * m_pad | 8 folded statistics | 256 raw statistics words (uint64 bit patterns) ]
         # A local stepper with `raw_shards` (the HIP engine) lets the step kernel accumulate straight into the raw words of
         # the send buffer -- no fold launch -- and every rank folds all ranks' words on arrival; other steppers fill the 8
-        # folded statistics.  (The step kernel of step k also zeroes the raw words of the OTHER send buffer, whose last
-        # all-gather has completed in stream order; with the all-gather on a communication stream that is not guaranteed,
-        # so the overlapped mode keeps the folded form.)
+        # folded statistics.  (The step kernel of step k also zeroes the raw words of the NEXT send buffer, whose last
+        # all-gather -- two steps ago -- has completed: in stream order, or behind the event the compute stream waits on.)
         self.width = self.cols * plan.m_pad + STAT_STRIDE + RAW_WORDS
-        self.send = [torch.zeros(self.width, dtype=torch.float64, device=dev) for _ in range(2)]
-        self.recv = [torch.zeros(plan.world * self.width, dtype=torch.float64, device=dev) for _ in range(2)]
-        self._raw = [False, False]
+        self.send = [torch.zeros(self.width, dtype=torch.float64, device=dev) for _ in range(self.NB)]
+        self.recv = [torch.zeros(plan.world * self.width, dtype=torch.float64, device=dev) for _ in range(self.NB)]
+        self._raw = [False] * self.NB
         self.k = 0
         # the slices of the payload buffers the local stepper writes into, built once (a tensor slice costs the host 1-2 us:
         # at 13 us of GPU work per step the per-step host path decides whether the collective can hide behind the compute)
@@ -114,9 +117,9 @@ class ShardedStepper:
         self._gpu = torch.device(dev).type == "cuda"
         if self._gpu:
             self.comm = torch.cuda.Stream(device=dev)
-            self._ready = [torch.cuda.Event(), torch.cuda.Event()]
-            self._done = [torch.cuda.Event(), torch.cuda.Event()]
-            self._pending = [False, False]
+            self._ready = [torch.cuda.Event() for _ in range(self.NB)]
+            self._done = [torch.cuda.Event() for _ in range(self.NB)]
+            self._pending = [False] * self.NB
             # the all-gather enqueued by RCCL itself in our stream (no ProcessGroup stream hops, rccl.py); the
             # torch.distributed collective remains the fallback
             if direct_rccl and dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl":
@@ -130,20 +133,22 @@ class ShardedStepper:
 
     def step(self, global_action, overlap=False):
         p = self.plan
-        b = self.k & 1
+        b, bn = self.k % self.NB, (self.k + 1) % self.NB
         send, recv = self.send[b], self.recv[b]
         use_dist = self._use_dist
         overlap = overlap and self._gpu and use_dist
         cur = torch.cuda.current_stream() if self._gpu else None
-        if overlap and self._pending[b]:
-            cur.wait_event(self._done[b])   # payload of step k-2 has left
-            self._pending[b] = False
+        if self._gpu:
+            for q in (b, bn):               # buffers this step writes (payload) or zeroes (next buffer's statistics words):
+                if self._pending[q]:        # their last all-gather (three / two steps ago) must have left
+                    cur.wait_event(self._done[q])
+                    self._pending[q] = False
         # kernels of this step write the observation block and the statistics straight into `send`
-        raw = self._local_raw and not overlap
+        raw = self._local_raw
         kw = dict(self._kw, stream=cur.cuda_stream) if self._gpu else self._kw   # (the stream handle, looked up once per step)
         if raw:
             self.local.step(p.local_action(global_action), self._v_obs[b], None,
-                            shards_out=self._v_shards[b], shards_clear=self._v_shards[b ^ 1], **kw)
+                            shards_out=self._v_shards[b], shards_clear=self._v_shards[bn], **kw)
         else:
             self.local.step(p.local_action(global_action), self._v_obs[b], self._v_stats[b], **kw)
         self._raw[b] = raw
@@ -176,14 +181,14 @@ class ShardedStepper:
     def wait(self):
         """make the current stream wait for every all-gather issued so far."""
         if self._gpu:
-            for b in (0, 1):
+            for b in range(self.NB):
                 if self._pending[b]:
                     torch.cuda.current_stream().wait_event(self._done[b])
                     self._pending[b] = False
 
     # ---- views of the reassembled global state of the latest step (call after wait())
     def _latest(self):
-        return self.recv[(self.k - 1) & 1]
+        return self.recv[(self.k - 1) % self.NB]
 
     def global_obs(self):
         p = self.plan
@@ -196,7 +201,7 @@ class ShardedStepper:
         rows = self._latest().view(p.world, self.width)[:, self.cols * p.m_pad:].cpu().numpy()
         st = rows[:, :STAT_STRIDE]
         out = np.zeros(STAT_STRIDE)
-        if self._raw[(self.k - 1) & 1]:      # raw shard words of every rank: fold them as reward_fold_kernel would
+        if self._raw[(self.k - 1) % self.NB]:      # raw shard words of every rank: fold them as reward_fold_kernel would
             w = np.ascontiguousarray(rows[:, STAT_STRIDE:]).view(np.uint64).reshape(p.world * STAT_SHARDS, STAT_SHARD_WORDS)[:, :4]
             out[STAT_MAX_DPOS] = np.array([w[:, 0].max()], dtype=np.uint64).view(np.float64)[0]   # ordered bit patterns, NaN on top
             out[STAT_CNT_LT_1E4] = float((w[:, 1] & np.uint64(0xffffffff)).sum())

@@ -694,20 +694,24 @@ def test_direct_rccl_all_gather_equals_torch_distributed(hip):
             local = parallel.HipLocalStepper(eng, consts, fast_stats=True)
             sh = parallel.ShardedStepper(parallel.ShardPlan(m, 1, 0), local, direct_rccl=direct)
             assert (sh._rccl is not None) == direct
-            for k in range(3):
-                sh.step(7 * k + 1, overlap=(k == 2))
-                if k == 1:   # in-stream steps carry the RAW shard words (no fold launch); folded on arrival they must equal
-                    sh.wait()   # the numpy reductions of this step's metrics
-                    torch.cuda.synchronize()
-                    assert sh._raw[1] and sh._raw[0]
-                    st = sh.global_stats()
-                    dp = eng.metrics[local.tick % 2, 0, 0].cpu().numpy()
-                    assert st[hip.lib.STAT_MAX_DPOS] == dp.max() and st[hip.lib.STAT_CNT_LT_1E4] == (dp < 1e4).sum()
-                    assert st[hip.lib.STAT_CNT_LT_1E7] == (dp < 1e7).sum() and st[hip.lib.STAT_N_FAILED] == 0
-            assert not sh._raw[0]   # the overlapped step (k = 2, buffer 0) went through the fold
+            for k in range(9):   # in-stream and overlapped steps mixed: three payload buffers rotate, every step carries the RAW
+                sh.step(7 * k + 1, overlap=k in (2, 3, 4, 6, 8))   # shard words (no fold launch), step k zeroes buffer (k + 1) % 3's words
+                sh.wait()
+                torch.cuda.synchronize()
+                assert sh._raw[k % 3]
+                st = sh.global_stats()     # folded on arrival they must equal the numpy reductions of this step's metrics
+                dp = eng.metrics[local.tick % 2, 0, 0].cpu().numpy()
+                assert st[hip.lib.STAT_MAX_DPOS] == dp.max() and st[hip.lib.STAT_CNT_LT_1E4] == (dp < 1e4).sum(), k
+                assert st[hip.lib.STAT_CNT_LT_1E7] == (dp < 1e7).sum() and st[hip.lib.STAT_N_FAILED] == 0, k
+            for k in range(9, 14):   # and without a host sync in between (the events alone order the buffers)
+                sh.step(7 * k + 1, overlap=True)
             sh.wait()
             torch.cuda.synchronize()
-            got.append((sh.global_obs().cpu().numpy(), sh.global_stats(), sh.recv[0].cpu().numpy(), sh.recv[1].cpu().numpy()))
+            st = sh.global_stats()
+            dp = eng.metrics[local.tick % 2, 0, 0].cpu().numpy()
+            assert st[hip.lib.STAT_MAX_DPOS] == dp.max() and st[hip.lib.STAT_CNT_LT_1E7] == (dp < 1e7).sum()
+            got.append((sh.global_obs().cpu().numpy(), sh.global_stats(), sh.recv[0].cpu().numpy(), sh.recv[1].cpu().numpy(),
+                        sh.recv[2].cpu().numpy()))
             if sh._rccl is not None:
                 sh._rccl.close()
         for a, b in zip(got[0], got[1]):
