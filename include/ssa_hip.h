@@ -153,8 +153,9 @@ typedef struct ssa_step_params {
     uint64_t *stat_shards_clear; /* [E][SSA_STAT_SHARDS][SSA_STAT_SHARD_WORDS] or NULL: a shard set this launch ZEROES (nothing reads or adds to it
                                   during the launch).  Lets a consumer that takes the statistics as RAW shards -- the sharded
                                   multi-GPU step sends its rank's shard words in the all-gather payload and every rank
-                                  folds all ranks' words itself -- alternate two payload buffers without a fold / clear
-                                  launch: step k accumulates into buffer k & 1 and clears buffer (k + 1) & 1. */
+                                  folds all ranks' words itself -- rotate payload buffers without a fold / clear
+                                  launch: step k accumulates into buffer k % N and clears buffer (k + 1) % N (N = 2 when the
+                                  all-gather runs in the step's stream, 3 when it overlaps the next step on another one). */
     int32_t aer_cols;          /* columns of aer_out per object: 0 or 4 = (az, el, range, trace P); 1 = trace P only, [E*m] --
                                   the "per-object covariance-trace observation" of the sharded 160 000-object configuration:
                                   a quarter of the all-gather payload and no inverse trigonometry in the epilogue */
