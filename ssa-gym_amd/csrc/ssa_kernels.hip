@@ -1288,22 +1288,16 @@ typedef const __attribute__((address_space(4))) StepK* KernargPtr;
 // The leading arguments -- the two tile counts and the pointers k_arg.p.{P_in, x_in, x_true_in, status} repeated -- are plain
 // scalars: they are PRELOADED into SGPRs at wavefront launch (-amdgpu-kernarg-preload-count, _build.py), so the tile's loads -- the first link
 // of every wavefront's dependency chain -- leave without waiting for a scalar-memory round trip to the kernarg segment.
-#ifndef SSA_WPB
-#define SSA_WPB 1   // wavefronts per workgroup of the one-tile instance (independent wavefronts: no barrier, one Tiles block each)
-#endif
 template <int PROP, bool MULTI>
-__global__ void __launch_bounds__(MULTI ? 64 : 64 * SSA_WPB, SSA_STEP_WAVES) step_fast_kernel(int ntiles, int nwork, const double* pre_P_in,
+__global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(int ntiles, int nwork, const double* pre_P_in,
                                                                        const double* pre_x_in, const double* pre_x_true_in,
                                                                        const int32_t* pre_status, const StepK k_arg)
 {
-    __shared__ Tiles ts[MULTI ? 1 : SSA_WPB];
-    int lane = threadIdx.x & 63;
-    const int wv = (MULTI || SSA_WPB == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform: keep it scalar)
-    const int unit = (int)blockIdx.x * ((MULTI || SSA_WPB == 1) ? 1 : SSA_WPB) + wv;
-    Tiles& t = ts[wv];
+    __shared__ Tiles t;
+    int lane = threadIdx.x;
+    const int unit = (int)blockIdx.x;
     if (unit >= nwork) {   // deferred fold of the previous step's statistics: one extra wavefront per env
-        if (SSA_WPB == 1 || MULTI || (k_arg.p.stat_shards_prev && unit - nwork < k_arg.p.n_env))
-            fold_stat_shards((unsigned long long*)k_arg.p.stat_shards_prev, k_arg.p.stats_prev, unit - nwork, lane);
+        fold_stat_shards((unsigned long long*)k_arg.p.stat_shards_prev, k_arg.p.stats_prev, unit - nwork, lane);
         return;
     }
     const int64_t total = (int64_t)k_arg.p.n_env * k_arg.p.n_obj;
@@ -2084,10 +2078,6 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
     if (defer && p->stat_shards_prev && (!p->stats_prev || p->stat_shards_prev == p->stat_shards)) return SSA_E_INVALID;
     const int nfold = (defer && p->stat_shards_prev) ? p->n_env : 0;
     dim3 grid((unsigned)(nwork + nfold)), block(64);
-    if (per_wave == 1 && SSA_WPB > 1) {
-        grid = dim3((unsigned)((nwork + nfold + SSA_WPB - 1) / SSA_WPB));
-        block = dim3(64 * SSA_WPB);
-    }
     const int nparts = post_parts(p->n_obj, p->n_env);
     StatAcc* parts = (StatAcc*)p->stat_ws;
     hipStream_t s = (hipStream_t)stream;
