@@ -22,7 +22,14 @@ fs = fe['step'][20:]; ws = wr['step'][20:]
 f = sum(fs) / len(fs) * 1024; w = sum(ws) / len(ws) * 1024
 cf = out['calib_observe']['fetch_ratio']; cw = out['calib_observe']['write_ratio']
 out['step_raw'] = {'fetch_counter_bytes': f, 'write_counter_bytes': w, 'launches': len(fs)}
-out['fg_20000'] = round(f / cf + w / cw)      # corrected HBM(+Infinity-Cache-side) bytes per launch
+key = '%s_%s' % (os.environ.get('PROP', 'fg'), os.environ.get('M', '20000'))
+out[key] = round(f / cf + w / cw)      # corrected HBM(+Infinity-Cache-side) bytes per launch
 out['algorithmic_bytes'] = 896 * 20000
 print(json.dumps(out, indent=1))
-json.dump(out, open(os.path.join(ROOT, 'profiles', 'traffic.json'), 'w'), indent=1)
+dst = os.path.join(ROOT, 'profiles', 'traffic.json')
+if key != 'fg_20000' and os.path.exists(dst):      # the other configurations are merged into the file (bench.py looks its own key up)
+    old = json.load(open(dst))
+    old[key] = out[key]
+    old.setdefault('other_configurations', {})[key] = {'step_raw': out['step_raw'], 'calib_observe': out['calib_observe']}
+    out = old
+json.dump(out, open(dst, 'w'), indent=1)
