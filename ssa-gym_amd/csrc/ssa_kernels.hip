@@ -934,6 +934,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     // Phase 1 (row-local, lanes of the selected object's row): measurement of the sigma points, predicted measurement,
     // residuals; the rows [sigma - x | rz | Wc rz] go to the staging matrix.  Phase 2 (whole wavefront, below): the two
     // weighted moment matrices on the matrix unit, inverse, gain, state and covariance over all 64 lanes.
+    if (__any(my_update)) {   // whole-wave branch: a wavefront without a selected object skips the block, its variables included
     bool upd_go = false, taken = false, visible = false, attempted = false;
     double z[3] = {0.0, 0.0, 0.0}, y_row[3] = {0.0, 0.0, 0.0};   // (y_row: lane 13 of the row keeps the innovation)
     double* rec = nullptr;
@@ -1136,6 +1137,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         rec[SSA_UPD_VISIBLE] = visible ? 1.0 : 0.0;
         rec[SSA_UPD_ACTION] = attempted ? (double)act : -1.0;
     }
+    }   // wavefronts holding a selected object
     // envs whose action selects nobody still get a cleared record (written by object 0's row)
     if (valid && p.upd && obj == (int64_t)e * p.n_obj && l == 0 && !(act >= 0 && interval_ok && (int64_t)act < p.n_obj)) {   // (not `j`: it would live across the whole kernel)
         double* rec = p.upd + (int64_t)e * SSA_UPD_STRIDE;
