@@ -1,19 +1,17 @@
-mkdir -p gpurun_out
-timeout -k 10 200 python __graft_entry__.py smoke > gpurun_out/r2z_smoke.log 2>&1; echo "smoke rc $?"; tail -1 gpurun_out/r2z_smoke.log
-timeout -k 10 900 python bench.py > gpurun_out/r2z_bench.json 2> gpurun_out/r2z_bench.err; echo "bench rc $?"
-timeout -k 10 300 python bench.py --objects 2000 --no-cpu-baseline --no-legs > gpurun_out/r2z_2k.json 2> gpurun_out/r2z_2k.err
-timeout -k 10 300 python bench.py --objects 64 --no-cpu-baseline --no-legs > gpurun_out/r2z_64.json 2> gpurun_out/r2z_64.err
-timeout -k 10 600 python bench.py --objects 160000 --steps 600 --warmup 100 --no-cpu-baseline --no-legs > gpurun_out/r2z_160k.json 2> gpurun_out/r2z_160k.err
-MASTER_ADDR=127.0.0.1 timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 1500 --warmup 200 --no-cpu-baseline --no-legs > gpurun_out/r2z_rccl1_trace.json 2> gpurun_out/r2z_rccl1_trace.err
-python - <<'PY'
-import json
-for f in ("r2z_bench","r2z_2k","r2z_64","r2z_160k","r2z_rccl1_trace"):
-    d=json.load(open("gpurun_out/%s.json"%f))
-    print(f, d["value"], d["ms_per_step"], d["roofline"]["kernel_ms"], d["roofline"]["frac"], d["roofline"].get("traffic"), d["roofline"].get("fp64_frac"), {k:((d.get(k) or {}).get("value")) for k in ("rollout","j2","elements","resample","closed_loop")}, (d.get("gym_api") or {}).get("flatten",{}).get("value"), (d.get("gym_api") or {}).get("aer",{}).get("value"), (d.get("cpu_baseline") or {}).get("value"), (d.get("cpu_baseline_all_cores") or {}).get("value"))
+mkdir -p gpurun_out/skip
+cp ssa-gym_amd/libssa_hip.so /tmp/keep.so
+cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/skip
+export PROP=fg M=160000
+for v in full s1 s2 s4 s8 s31; do
+  if [ $v = full ]; then cp /tmp/keep.so $R/ssa-gym_amd/libssa_hip.so; else cp $R/build_ablate/skip/$v.so $R/ssa-gym_amd/libssa_hip.so; fi
+  timeout -k 10 120 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/$v -- python3 $R/profiles/pmc_workload.py > $OUT/$v.log 2>&1 || { echo "rocprof failed for $v"; break; }
+  python3 - <<PY
+import csv,glob
+f=glob.glob("$OUT/$v/*/*counter_collection.csv")[0]
+acc={}
+for r in csv.DictReader(open(f)):
+    if 'step_fast_kernel' in r['Kernel_Name']: acc.setdefault(r['Counter_Name'],[]).append(float(r['Counter_Value']))
+print("$v", {k: round(sum(v[20:])/len(v[20:])*1024/1e6,1) for k,v in acc.items()}, "MB per launch (raw counter)")
 PY
-timeout -k 10 600 bash profiles/collect.sh r02 > gpurun_out/r2z_collect.log 2>&1; echo "collect rc $?"; head -3 gpurun_out/r02/kernel_stats.csv | cut -c1-160
-cp ssa-gym_amd/libssa_hip.so /tmp/keep.so; cp build_ablate/libs/trace.so ssa-gym_amd/libssa_hip.so
-timeout -k 10 200 python build_ablate/wave_timeline.py > gpurun_out/r2z_tl20k.txt 2>&1; head -6 gpurun_out/r2z_tl20k.txt | tail -4
-M=64 timeout -k 10 200 python build_ablate/wave_timeline.py > gpurun_out/r2z_tl64.txt 2>&1
-STEPS=380 timeout -k 10 200 python build_ablate/wave_timeline.py > gpurun_out/r2z_tl_late.txt 2>&1
-cp /tmp/keep.so ssa-gym_amd/libssa_hip.so
+done
+cp /tmp/keep.so $R/ssa-gym_amd/libssa_hip.so

@@ -365,7 +365,12 @@ SSA_DEV void store16(double* dst, const double* src)
 template <bool NT>
 SSA_DEV void store_tile(const Tiles& t, const ssa_step_params& p, int lane, int64_t base, int cnt)
 {
-    if (lane < cnt * 18) store16<NT>(p.P_out + base * 36 + 2 * lane, t.P + 2 * lane);
+#ifdef SSA_SKIP_STORES   // diagnostic builds (write-traffic attribution): bit 1 = P, 2 = obs, 4 = x / x_true, 8 = metrics, 16 = status
+#define SSA_SKIP(b) ((SSA_SKIP_STORES) & (b))
+#else
+#define SSA_SKIP(b) 0
+#endif
+    if (!SSA_SKIP(1) && lane < cnt * 18) store16<NT>(p.P_out + base * 36 + 2 * lane, t.P + 2 * lane);
     {   // lanes [0, 12): x | [16, 28): x_true | [32, 40): the tail of P | [40, 64): obs -- one 16-byte store per lane, destination and
         // LDS source selected by lane range (see tile_issue_from)
         const bool sT = lane >= 16, sP = lane >= 32, sO = lane >= 40;
@@ -373,13 +378,14 @@ SSA_DEV void store_tile(const Tiles& t, const ssa_step_params& p, int lane, int6
         const int lim = sO ? cnt * 6 : sP ? cnt * 18 - 64 : cnt * 3;
         double* dst = sO ? p.obs + base * 12 : sP ? p.P_out + base * 36 + 128 : sT ? p.x_true_out + base * 6 : p.x_out + base * 6;
         const double* src = sO ? t.Obs : sP ? t.P + 128 : sT ? t.T : t.X;
-        if (i < lim) store16<NT>(dst + 2 * i, src + 2 * i);
+        const bool skip = sO ? SSA_SKIP(2) : sP ? SSA_SKIP(1) : SSA_SKIP(4);
+        if (!skip && i < lim) store16<NT>(dst + 2 * i, src + 2 * i);
     }
-    if (lane >= 12 && lane < 16) {
+    if (!SSA_SKIP(16) && lane >= 12 && lane < 16) {
         const int i = lane - 12;
         if (i < cnt) p.status[base + i] = t.St[i];
     }
-    if (lane < 16) {   // metrics [E][4][m]: four 32-byte runs per tile
+    if (!SSA_SKIP(8) && lane < 16) {   // metrics [E][4][m]: four 32-byte runs per tile
         const int kk = lane >> 2, jj = lane & 3;
         if (jj < cnt) {
             const int64_t obj = base + jj;
