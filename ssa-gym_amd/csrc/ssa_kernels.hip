@@ -934,12 +934,11 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         if (active && st_new == SSA_ST_OK && rg == 16) st_new = SSA_ST_PREDICT_LINALG;
     }
 
-    // ---- U5: the one update of this env (ssa_tasker_simple_2.py:292-315), in the row that owns the
-    // selected object.  Cross-lane traffic is row-level (DPP / bpermute); the small matrices are staged
-    // in the row's (now free) t.D area:  W[0..9) S | W[9..27) Pxz | W[27..36) inv(S) | W[36..54) K
+    // ---- U5: the one update of this env (ssa_tasker_simple_2.py:292-315) for the selected object.
     // Phase 1 (row-local, lanes of the selected object's row): measurement of the sigma points, predicted measurement,
-    // residuals; the rows [sigma - x | rz | Wc rz] go to the staging matrix.  Phase 2 (whole wavefront, below): the two
-    // weighted moment matrices on the matrix unit, inverse, gain, state and covariance over all 64 lanes.
+    // residuals; the rows [sigma - x | rz] go to the row's staging matrix.  Phase 2 (whole wavefront, below): the two
+    // weighted moment matrices on the matrix unit (the weights enter with the right operand), inverse, gain, state and
+    // covariance over all 64 lanes.
     if (__any(my_update)) {   // whole-wave branch: a wavefront without a selected object skips the block, its variables included
     bool upd_go = false, taken = false, visible = false, attempted = false;
     double z[3] = {0.0, 0.0, 0.0}, y_row[3] = {0.0, 0.0, 0.0};   // (y_row: lane 13 of the row keeps the innovation)
