@@ -209,6 +209,14 @@ class SSA_Tasker_Env(Env):
         self._upd_host = torch.zeros(_lib.UPD_STRIDE, dtype=torch.float64).pin_memory()
         nobs = self.m * (4 if self.obs_returned == 'aer' else 12)
         self._obs_host = torch.zeros(nobs, dtype=torch.float64).pin_memory()
+        # (numpy views and raw pointers of the mailboxes, taken once: each .numpy() / .data_ptr() costs the step a microsecond)
+        self._act_np, self._upd_np, self._stats_np = self._act_host.numpy(), self._upd_host.numpy(), self._stats_host.numpy()
+        self._act_ptr, self._upd_ptr, self._stats_ptr = self._act_host.data_ptr(), self._upd_host.data_ptr(), self._stats_host.data_ptr()
+        self._aer_ptr = self._aer_dev.data_ptr()
+        if self.obs_returned == 'aer':
+            # the reference hands out ONE persistent array, refreshed in place every step (:362-363); here that array is the
+            # pinned buffer the copy engine writes the device's (az, el, range, trace P) block into -- no host-side copy
+            self.observation = self._obs_host.numpy()
         self.x_true = _History(self, e.x_true, self.m, (6,))
         self.x_filter = _History(self, e.x_filter, self.m, (6,))
         self.P_filter = _History(self, e.P_filter, self.m, (6, 6))
@@ -277,7 +285,7 @@ class SSA_Tasker_Env(Env):
             return e.obs[slot].cpu().numpy().reshape(-1)
         elif self.obs_returned == 'aer':
             if reset:
-                self.observation = self.aer_obs(np.zeros(self.m * 4))
+                self.aer_obs(self.observation)
             else:
                 self.observation[:] = self._aer_dev.cpu().numpy()
             return self.observation
@@ -295,20 +303,22 @@ class SSA_Tasker_Env(Env):
         self.runtime['step prep'] += s - step_s
         # propagate + predict + update + observations/metrics + statistics: two launches (:265-322)
         import torch
-        self._act_host[0] = int(a)
-        # 'aer' observations come out of the post kernel of the same step (no extra launch)
-        e.launch_step((i - 1) % e.H, i % e.H, i, actions_ptr=self._act_host.data_ptr(),
-                      aer_out=self._aer_dev.data_ptr() if self.obs_returned == 'aer' else 0,
-                      stats_out=self._stats_host.data_ptr(), upd_out=self._upd_host.data_ptr(),
+        self._act_np[0] = int(a)
+        cur = torch.cuda.current_stream()     # (looked up once per step: launch and synchronisation share it)
+        # 'aer' observations come out of the step kernel's epilogue (no extra launch)
+        e.launch_step((i - 1) % e.H, i % e.H, i, actions_ptr=self._act_ptr,
+                      aer_out=self._aer_ptr if self.obs_returned == 'aer' else 0,
+                      stats_out=self._stats_ptr, upd_out=self._upd_ptr, stream=cur.cuda_stream,
                       fast_stats=(self.reward_type != 'shaped'))   # only 'shaped' needs argmax(sigma_pos) (:346)
-        src = self._aer_dev if self.obs_returned == 'aer' else e.obs[i % e.H].reshape(-1)
-        big = src.numel() * 8 > (1 << 19)   # large vectors: one pageable D2H beats pinned copy + host memcpy
+        aer = self.obs_returned == 'aer'
+        src = self._aer_dev if aer else e.obs[i % e.H].reshape(-1)
+        big = (not aer) and src.numel() * 8 > (1 << 19)   # large fresh vectors: one pageable D2H beats pinned copy + host memcpy
         if not big:
-            self._obs_host.copy_(src, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-        obs_np = src.cpu().numpy() if big else self._obs_host.numpy().copy()
-        rec = self._upd_host.numpy()
-        self._stats = self._stats_host.numpy().copy()
+            self._obs_host.copy_(src, non_blocking=True)    # ('aer': straight into self.observation's storage)
+        cur.synchronize()
+        obs_np = self.observation if aer else (src.cpu().numpy() if big else self._obs_host.numpy().copy())
+        rec = self._upd_np
+        self._stats = self._stats_np.copy()
         self._argmax_sigma = int(self._stats[_lib.STAT_ARGMAX_SPOS])
         t_dev = time.time()
         self.runtime['perform predictions'] += t_dev - s
@@ -321,7 +331,6 @@ class SSA_Tasker_Env(Env):
             done = True
         obs = obs_np
         if self.obs_returned == 'aer':
-            self.observation[:] = obs
             obs = self.observation
         elif self.obs_returned != 'flatten':
             obs = obs.reshape(self.m, 12)
