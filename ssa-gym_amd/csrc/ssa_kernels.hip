@@ -738,12 +738,13 @@ __device__ unsigned long long g_trace[16384 * 16];
 // TILE: 0 = the tile is loaded here; 1 = it was prefetched (commit now, request the next one after the
 // Kepler stage); 2 = the tiles already hold the state (a rollout's later steps)
 template <int PROP, int TILE>
-SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& p, int lane, int64_t obj, bool valid,
+SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& p, int lane, int64_t obj_in, bool valid,
                           int64_t base, int cnt, TileRegs& pf, int64_t next_base, int next_cnt, int tile)
 {
     int g = lane >> 4, l = lane & 15;
+    int64_t obj = obj_in;
     // env of the object: no division for the single-env case, a 32-bit one otherwise (n_env * n_obj < 2^31)
-    const int e = (valid && p.n_env > 1) ? (int)((uint32_t)obj / (uint32_t)p.n_obj) : 0;
+    int e = (valid && p.n_env > 1) ? (int)((uint32_t)obj / (uint32_t)p.n_obj) : 0;
     const int64_t j = valid ? obj - (int64_t)e * p.n_obj : 0;
     // the action / time index of this object's env, fetched early (used after the transform)
     // (one env: wave-uniform scalar loads; per-lane loads with their 64-bit address arithmetic only for vectorised envs)
@@ -870,6 +871,11 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     asm volatile("" : "+v"(lane));
     g = lane >> 4;
     l = lane & 15;
+    // ... and so are the object index and its env (the multi-tile instance spilled these and the action word across the
+    // propagator: 24 bytes per lane and tile = 61 MB of scratch writes per 160 000-object step); the action word is read
+    // again where the rare paths below need it (a scalar load here would sit in front of every LDS wait that follows)
+    obj = base + g;
+    e = (valid && p.n_env > 1) ? (int)((uint32_t)obj / (uint32_t)p.n_obj) : 0;
     SSA_TR(3);
     // the next tile's inputs: in flight during the transform / covariance / observation / store of this one
     if (TILE == 1) tile_issue(pf, p, lane, next_base, next_cnt);
@@ -1140,15 +1146,27 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     if (my_update && rec && l == 0) {
         rec[SSA_UPD_OBS_TAKEN] = taken ? 1.0 : 0.0;
         rec[SSA_UPD_VISIBLE] = visible ? 1.0 : 0.0;
-        rec[SSA_UPD_ACTION] = attempted ? (double)act : -1.0;
+        rec[SSA_UPD_ACTION] = attempted ? (double)p.actions[e] : -1.0;   // (my_update: the env's action IS this object)
     }
+    // The update is the register-pressure peak behind the propagator and only ONE wavefront of a launch runs it: whatever is
+    // live across it would be spilled by EVERY wavefront.  So the values that are cheap to get again are got again behind
+    // it: the lane coordinates, the object / env, and the next tile's loads (issued a second time).
+    asm volatile("" : "+v"(lane));
+    g = lane >> 4;
+    l = lane & 15;
+    obj = base + g;
+    e = (valid && p.n_env > 1) ? (int)((uint32_t)obj / (uint32_t)p.n_obj) : 0;
+    if (TILE == 1) tile_issue(pf, p, lane, next_base, next_cnt);
     }   // wavefronts holding a selected object
     // envs whose action selects nobody still get a cleared record (written by object 0's row)
-    if (valid && p.upd && obj == (int64_t)e * p.n_obj && l == 0 && !(act >= 0 && interval_ok && (int64_t)act < p.n_obj)) {   // (not `j`: it would live across the whole kernel)
+    if (valid && p.upd && obj == (int64_t)e * p.n_obj && l == 0) {   // (object 0 of an env: one lane per env)
+      const int a_env = p.actions[e];
+      if (!(a_env >= 0 && interval_ok && (int64_t)a_env < p.n_obj)) {
         double* rec = p.upd + (int64_t)e * SSA_UPD_STRIDE;
         rec[SSA_UPD_OBS_TAKEN] = 0.0;
         rec[SSA_UPD_VISIBLE] = 0.0;
         rec[SSA_UPD_ACTION] = -1.0;
+      }
     }
 
     // ---- F1: failed filters carry the sentinels (ssa_tasker_simple_2.py:157-158, 369-382)

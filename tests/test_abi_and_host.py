@@ -178,7 +178,7 @@ def test_step_kernels_keep_their_register_budget(tmp_path):
     one round) and must not spill on the common path: the build relies on a whole-TU compiler switch
     (-disable-machine-licm, _build.py), so a toolchain change that brings the spills back (41.7 MB of scratch traffic
     per launch when it happened) has to fail HERE, not show up as a slower bench.  Scratch accesses are allowed only
-    as the save / restore around the rare out-of-line calls (non-elliptic conics, the complete farnocchia())."""
+    as the save / restore around the rare out-of-line calls of SSA_PROP_ELEMENTS (the complete farnocchia())."""
     import re
     notes, dis = _code_object(tmp_path)
     kern = {}
@@ -208,9 +208,11 @@ def test_step_kernels_keep_their_register_budget(tmp_path):
         ins = [ln.split()[0] for ln in body.splitlines() if ln.strip() and not ln.strip().startswith(("//", ";"))]
         calls = [i for i, op in enumerate(ins) if op == "s_swappc_b64"]
         stray = [i for i, op in enumerate(ins) if op.startswith("scratch_") and not (calls and min(abs(i - c) for c in calls) <= 96)]
-        if "Lb0E" in name:      # one tile per wavefront (every launch up to 20 480 objects: the headline kernels): none
-            assert not stray, (name, stray[:8], "scratch access away from any call: a spill on the common path")
-        else:                   # grid-stride / rollout instances carry staging registers around a loop: a bounded handful
-            assert kern[name]["vgpr_spill_count"] <= 24, (name, kern[name], "more spilled registers than the recorded ceiling")
+        # none in any instance -- the grid-stride one once spilled the object / env / action words across the propagator in
+        # EVERY wavefront (24 bytes per lane and tile: 61 MB of scratch writes per 160 000-object step, found as write
+        # traffic 1.58x the algorithmic bytes)
+        assert not stray, (name, stray[:8], "scratch access away from any call: a spill on the common path")
+        if "ILi0E" not in name:     # FG / J2 instances make no out-of-line call: no scratch at all
+            assert kern[name]["private_segment_fixed_size"] == 0 and kern[name]["vgpr_spill_count"] == 0, (name, kern[name])
         checked += 1
     assert checked == 9
