@@ -305,7 +305,8 @@ static_assert(sizeof(Tiles) <= 7680, "Tiles must fit 20 wavefronts per CU (see a
 //   tile_issue : 16-byte wave-contiguous loads into 8 VGPRs.  `main` = P entries [2 lane, 2 lane + 2);
 //                `aux` by lane: 0-7 the tail of P | 32-43 x_filter | 48-59 x_true | 60-63 status (bits)
 //   tile_commit: registers -> LDS tiles (rows beyond `cnt` are zero / marked failed)
-struct TileRegs { double2 main, aux; };
+struct TileRegs { double2 main, aux; int st; };   // (the status word travels in its own register: packing it into `aux` put a wait for
+                                                 // EVERY outstanding load right behind the tile's loads)
 // one 16-byte lane of a tile load (plain: marking the inputs streaming was measured slower, 45.4 k vs 46.5 k)
 SSA_DEV double2 load16(const double* src) { return *reinterpret_cast<const double2*>(src); }
 SSA_DEV void tile_issue_from(TileRegs& r, const double* P_in, const double* x_in, const double* x_true_in, const int32_t* status,
@@ -314,6 +315,7 @@ SSA_DEV void tile_issue_from(TileRegs& r, const double* P_in, const double* x_in
     const double2 zero = make_double2(0.0, 0.0);
     r.main = zero;
     r.aux = zero;
+    r.st = SSA_ST_PREDICT_NAN;
     if (cnt <= 0) return;
     const double* Pin = P_in + base * 36;
     if (lane < cnt * 18) r.main = load16(Pin + 2 * lane);
@@ -325,10 +327,7 @@ SSA_DEV void tile_issue_from(TileRegs& r, const double* P_in, const double* x_in
     const int lim = sX ? cnt * 3 : cnt * 18 - 64;
     const double* src = sT ? x_true_in + base * 6 : sX ? x_in + base * 6 : Pin + 128;
     if (i < lim) r.aux = load16(src + 2 * i);
-    if (lane >= 60) {
-        const int k = lane - 60;
-        r.aux.x = __hiloint2double(0, (k < cnt) ? status[base + k] : SSA_ST_PREDICT_NAN);
-    }
+    if (lane >= 60 && lane - 60 < cnt) r.st = status[base + (lane - 60)];
 }
 SSA_DEV void tile_issue(TileRegs& r, const ssa_step_params& p, int lane, int64_t base, int cnt)
 {
@@ -341,7 +340,7 @@ SSA_DEV void tile_commit(Tiles& t, const TileRegs& r, int lane)
     const int i = lane - (sT ? 48 : sX ? 32 : 0);
     double* dst = sT ? t.T : sX ? t.X : t.P + 128;
     if (i < (sX ? 12 : 8)) reinterpret_cast<double2*>(dst)[i] = r.aux;
-    if (lane >= 60) t.St[lane - 60] = __double2loint(r.aux.x);
+    if (lane >= 60) t.St[lane - 60] = r.st;
 }
 typedef double v2d __attribute__((ext_vector_type(2)));
 // one 16-byte lane of a tile store.  NT (non-temporal): for launches of up to 20 480 objects and for rollouts the
