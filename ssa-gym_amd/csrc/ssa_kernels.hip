@@ -742,6 +742,18 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
 {
     int g = lane >> 4, l = lane & 15;
     int64_t obj = obj_in;
+    // (TILE 0: the kernel issued the tile's loads from its preloaded pointer arguments before anything else.)  First thing here,
+    // so that these scalar loads complete with the action / time words' below -- placed behind the wait for the tile they
+    // put one more scalar-memory round trip between the tile's arrival and its commit to LDS
+#ifndef SSA_NO_EARLY_ARGS
+    if (TILE == 0) {
+        // the epilogue's output pointers are fetched NOW: their scalar loads (kernarg segment) overlap the tile's HBM round
+        // trip instead of each adding a scalar-memory round trip to the store path of a latency-bound wavefront
+        asm volatile("" ::"s"(p.P_out), "s"(p.x_out), "s"(p.x_true_out), "s"(p.obs), "s"(p.metrics), "s"(p.stat_shards), "s"(p.upd),
+                     "s"(p.aer_out), "s"(p.n_obj));
+    }
+#endif
+
     // env of the object: no division for the single-env case, a 32-bit one otherwise (n_env * n_obj < 2^31)
     int e = (valid && p.n_env > 1) ? (int)((uint32_t)obj / (uint32_t)p.n_obj) : 0;
     const int64_t j = valid ? obj - (int64_t)e * p.n_obj : 0;
@@ -781,15 +793,6 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     }
 #endif
 
-    // (TILE 0: the kernel issued the tile's loads from its preloaded pointer arguments before anything else)
-#ifndef SSA_NO_EARLY_ARGS
-    if (TILE == 0) {
-        // the epilogue's output pointers are fetched NOW: their scalar loads (kernarg segment) overlap the tile's HBM round
-        // trip instead of each adding a scalar-memory round trip to the store path of a latency-bound wavefront
-        asm volatile("" ::"s"(p.P_out), "s"(p.x_out), "s"(p.x_true_out), "s"(p.obs), "s"(p.metrics), "s"(p.stat_shards), "s"(p.upd),
-                     "s"(p.aer_out), "s"(p.n_obj));
-    }
-#endif
     if (TILE != 2) tile_commit(t, pf, lane);            // TILE 1: requested one tile ago (or by the kernel prologue)
     if (lane < 8) t.Z[lane] = 0.0;
     if (TILE != 2 && lane < 36) t.Q[lane] = C.Q[lane];   // (a rollout's later steps find it in place)
