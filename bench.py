@@ -208,6 +208,27 @@ def gym_api_rate(m, mode, n=300):
             "obs_bytes_per_step": m * (12 if mode == 'flatten' else 4) * 8}
 
 
+def vec_env_rate(m, E=8, n=60):
+    """BASELINE config 5's per-GPU load through the vector-env API: E envs of m objects advanced by ONE launch per
+    SSA_Tasker_VecEnv.step() (per-env actions and time indices, auto-reset), host in the loop, the E 'aer' observation
+    vectors returned over PCIe.  Reported in 20 000-object env-steps per second (E per call).  Never `value`."""
+    from ssa_gym_amd.envs import env_config
+    from ssa_gym_amd.envs.vector_env import SSA_Tasker_VecEnv
+    cfg = dict(env_config)
+    cfg.update(rso_count=m, steps=480, reward_type='trinary', obs_returned='aer', seed=0, device_rng=True)
+    env = SSA_Tasker_VecEnv(cfg, num_envs=E, seed=0)
+    acts = lambda k: [(k * 7 + 13 * e) % m for e in range(E)]    # noqa: E731
+    for k in range(10):
+        env.step(acts(k))
+    t0 = time.perf_counter()
+    for k in range(n):
+        env.step(acts(10 + k))
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(E / dt * (m / 20000.0), 2), "ms_per_vector_step": round(1e3 * dt, 5), "envs": E,
+            "obs_bytes_per_step": E * m * 4 * 8,
+            "note": "SSA_Tasker_VecEnv.step(): %d envs x %d objects per launch, host in the loop, PCIe inclusive" % (E, m)}
+
+
 def self_launch(argv, n):
     """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as CHILD processes of a parent
     that never touches the GPU (no torch import here, no HIP call), relay rank 0's JSON line and exit with the
@@ -500,6 +521,8 @@ def main():
         legs["closed_loop"] = closed_loop_rate(m, Kl, Wl)
         legs["gym_api"] = {"flatten": gym_api_rate(m, 'flatten'), "aer": gym_api_rate(m, 'aer'),
                            "note": "SSA_Tasker_Env.step() per call, host in the loop, PCIe + one sync inclusive (20 000 objects)"}
+        if m == 20000:
+            legs["vec_env"] = vec_env_rate(m)
 
     cpu, cpu_all = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N=1 only

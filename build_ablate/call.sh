@@ -1,2 +1,7 @@
 mkdir -p gpurun_out
-timeout -k 10 800 python -m pytest tests -m gpu -q -s -rA > gpurun_out/r2z_pytest_verbose.log 2>&1; echo "pytest rc $?"; grep -c "PASSED" gpurun_out/r2z_pytest_verbose.log; grep "^\[" gpurun_out/r2z_pytest_verbose.log | cut -c1-260 | head -60
+timeout -k 10 600 python - > gpurun_out/r2z_vec.txt 2>&1 <<'PY'
+import sys; sys.argv=['bench.py']
+import bench
+print(bench.vec_env_rate(20000))
+PY
+tail -3 gpurun_out/r2z_vec.txt
