@@ -75,6 +75,41 @@ def host_cpu_share():
     return n
 
 
+MIN_TIMED_S = 0.05      # every rate of the line is the median over repeats of its timed block, repeated until >= 50 ms in total
+MIN_REPEATS, MAX_REPEATS = 3, 400
+
+
+def timed_repeats(block, sync, agree=None, prepare=None):
+    """`block()` enqueues EXACTLY the K steps of one timed block; `sync()` is the fence on both sides of it.  The block is
+    repeated until the timed blocks add up to MIN_TIMED_S (a 20-step block of 14 us steps is 0.3 ms: one sample of it says
+    little); returns (median, min, max, repeats) of the per-block elapsed seconds.  `agree(x)` makes a per-rank number
+    rank-uniform (MAX over ranks), so that every rank runs the same number of repeats.  `prepare()` runs untimed before
+    every block (e.g. an env reset when the episode would end inside the block)."""
+    agree = agree or (lambda v: v)
+    prepare = prepare or (lambda: None)
+    el = []
+    prepare()
+    sync()
+    t0 = time.perf_counter()
+    block()
+    sync()
+    el.append(agree(time.perf_counter() - t0))
+    reps = int(min(MAX_REPEATS, max(MIN_REPEATS, np.ceil(MIN_TIMED_S / max(el[0], 1e-9)))))
+    for _ in range(reps - 1):
+        prepare()
+        sync()
+        t0 = time.perf_counter()
+        block()
+        sync()
+        el.append(agree(time.perf_counter() - t0))
+    return float(np.median(el)), float(min(el)), float(max(el)), len(el)
+
+
+def spread(K, scale, med, lo, hi, reps):
+    """fields every leg reports next to its rate: repeats and the min / max rate over them"""
+    return {"repeats": reps, "value_spread": [round(K / hi * scale, 2), round(K / lo * scale, 2)]}
+
+
 def cpu_baseline(m, budget_s=15.0, all_cores=False):
     """C oracle (oracle/ssa_oracle.c), same step definition, bounded sample: one host core, or (all_cores) its
     OpenMP build over the cores this process may run on."""
@@ -130,15 +165,14 @@ def local_variant_rate(m, K, W, propagator, resample=False, seed=100):
             i += 1
             local.step(-1)
     run(W)
-    local.flush()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(K)
-    local.flush()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+
+    def sync():
+        local.flush()
+        torch.cuda.synchronize()
+    el, lo, hi, reps = timed_repeats(lambda: run(K), sync)
     out = {"value": round(K / el * (m / 20000.0), 2), "ms_per_step": round(1e3 * el / K, 5),
            "failed_filters": int((eng.status != 0).sum().item())}
+    out.update(spread(K, m / 20000.0, el, lo, hi, reps))
     del eng, local, zn
     return out
 
@@ -178,20 +212,22 @@ def closed_loop_rate(m, K, W, seed=100):
             st["n"] += 1
     eng.launch_agent_select(0, 0, _lib.AGENT_VISIBLE_GREEDY, word.data_ptr(), fallback_ptr=fb.data_ptr())
     run(W)
-    eng.flush_stats()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(K)
-    eng.flush_stats()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+
+    def sync():
+        eng.flush_stats()
+        torch.cuda.synchronize()
+
+    def block():
+        st["n"] = W
+        run(K)
+    el, lo, hi, reps = timed_repeats(block, sync)
     chosen = picks[W:W + K, 0].cpu().numpy()
-    return {"value": round(K / el * (m / 20000.0), 2), "ms_per_step": round(1e3 * el / K, 5), "agent": "agent_visible_greedy (device)",
-            "distinct_objects_selected": int(len(set(chosen.tolist()))), "failed_filters": int((eng.status != 0).sum().item()),
+    return {"value": round(K / el * (m / 20000.0), 2), "ms_per_step": round(1e3 * el / K, 5), **spread(K, m / 20000.0, el, lo, hi, reps),
+            "agent": "agent_visible_greedy (device)", "distinct_objects_selected": int(len(set(chosen.tolist()))), "failed_filters": int((eng.status != 0).sum().item()),
             "note": "closed loop on the device: step launch + ssa_agent_select_f64 (2 launches) per step, no host round trip"}
 
 
-def gym_api_rate(m, mode, n=300):
+def gym_api_rate(m, mode, n=200):
     """env.step() through the gym API (host in the loop: action in, launch, one sync, statistics + observation out over
     PCIe): the closed-loop rate an unmodified agents.py / RLlib worker sees.  Never `value`."""
     from ssa_gym_amd.envs import env_config, make
@@ -200,11 +236,19 @@ def gym_api_rate(m, mode, n=300):
     env = make(config=cfg)
     for k in range(20):
         env.step(k % m)
-    t0 = time.perf_counter()
-    for k in range(n):
-        env.step((20 + k) % m)
-    dt = (time.perf_counter() - t0) / n
-    return {"value": round(1.0 / dt * (m / 20000.0), 2), "ms_per_step": round(1e3 * dt, 5),
+    cnt = {"k": 20}
+
+    def prepare():
+        if env.i + n >= env.n - 1:
+            env.reset()
+
+    def block():
+        for _ in range(n):
+            env.step(cnt["k"] % m)
+            cnt["k"] += 1
+    el, lo, hi, reps = timed_repeats(block, lambda: None, prepare=prepare)
+    dt = el / n
+    return {"value": round(1.0 / dt * (m / 20000.0), 2), "ms_per_step": round(1e3 * dt, 5), **spread(n, m / 20000.0, el, lo, hi, reps),
             "obs_bytes_per_step": m * (12 if mode == 'flatten' else 4) * 8}
 
 
@@ -220,11 +264,16 @@ def vec_env_rate(m, E=8, n=60):
     acts = lambda k: [(k * 7 + 13 * e) % m for e in range(E)]    # noqa: E731
     for k in range(10):
         env.step(acts(k))
-    t0 = time.perf_counter()
-    for k in range(n):
-        env.step(acts(10 + k))
-    dt = (time.perf_counter() - t0) / n
+    cnt = {"k": 10}
+
+    def block():
+        for _ in range(n):
+            env.step(acts(cnt["k"]))
+            cnt["k"] += 1
+    el, lo, hi, reps = timed_repeats(block, lambda: None)
+    dt = el / n
     return {"value": round(E / dt * (m / 20000.0), 2), "ms_per_vector_step": round(1e3 * dt, 5), "envs": E,
+            **spread(n, E * m / 20000.0, el, lo, hi, reps),
             "obs_bytes_per_step": E * m * 4 * 8,
             "note": "SSA_Tasker_VecEnv.step(): %d envs x %d objects per launch, host in the loop, PCIe inclusive" % (E, m)}
 
@@ -425,16 +474,20 @@ def main():
         allgather_probe = None
         for k in range(W):
             one_step(k)
-    fence()
-    t0 = time.perf_counter()
-    for k in range(W, W + K):
-        one_step(k)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    # The timed block: EXACTLY K steps between two fences (barrier + synchronize), MAX over ranks.  The driver's K = 20 makes
+    # that block 0.3 ms, so it is repeated (same K, same fences) until the blocks add up to 50 ms and `value` is the MEDIAN
+    # block; min / max go into `value_spread`.
+    def max_over_ranks(v):
+        if not use_dist:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
+
+    def timed_block():
+        for k in range(W, W + K):
+            one_step(k)
+    elapsed, el_min, el_max, repeats = timed_repeats(timed_block, fence, agree=max_over_ranks)
 
     # sanity: nothing diverged during the run
     n_failed = int((eng.status != 0).sum().item())
@@ -493,13 +546,11 @@ def main():
                 local.rollout(kk)
                 state["i"] += kk
                 done += kk
-        roll_steps(W)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        roll_steps(K)
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        roll = {"steps_per_launch": R, "value": round(K / el * (m / 20000.0), 2), "ms_per_step": round(1e3 * el / K, 5),
+        Kr = max(K, 4 * R)        # (at least four full launches per timed block, whatever --steps was)
+        roll_steps(max(W, R))
+        el, lo, hi, reps = timed_repeats(lambda: roll_steps(Kr), torch.cuda.synchronize)
+        roll = {"steps_per_launch": R, "steps": Kr, "value": round(Kr / el * (m / 20000.0), 2), "ms_per_step": round(1e3 * el / Kr, 5),
+                **spread(Kr, m / 20000.0, el, lo, hi, reps),
                 "failed_filters": int((eng.status != 0).sum().item()),
                 "note": "open-loop schedule only (actions of a launch known up front); bit-identical to per-step launches"}
 
@@ -508,7 +559,7 @@ def main():
     # predict() (the UKF default is parity-unpinned: filterpy is absent), and the gym API with the host in the loop
     legs = {}
     if rank == 0 and world == 1 and not use_dist and not args.no_legs:
-        Kl, Wl = min(K, 1000), min(W, 100)
+        Kl, Wl = min(max(K, 200), 1000), min(max(W, 50), 100)   # (legs: at least 200 steps per timed block)
         for name, kw in (("j2", dict(propagator="j2")), ("elements", dict(propagator="elements")),
                          ("resample", dict(propagator=args.propagator, resample=True))):
             if name == args.propagator:
@@ -536,6 +587,8 @@ def main():
             "metric": "env_steps_per_sec_at_20k_objects", "value": round(value, 2),
             "unit": "env-steps/s (20 000-object UKF+propagate steps, summed over GPUs)",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 5),
+            "repeats": repeats, "value_spread": [round(K / el_max * world * (m / 20000.0), 2), round(K / el_min * world * (m / 20000.0), 2)],
+            "timing": "median over `repeats` timed blocks of exactly `steps` steps, each between two fences (repeated until >= 50 ms in total)",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "ssa_tasker_simple-v2 hot path: %d objects/GPU x %d GPU, %s + "
                                    "UKF predict (13 sigma points) + 1 az-el-range update/step%s" %

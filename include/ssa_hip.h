@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SSA_ABI_VERSION 15
+#define SSA_ABI_VERSION 16
 
 /* error codes */
 #define SSA_OK 0
@@ -64,6 +64,14 @@ extern "C" {
                                 kept for update() (believed to be what the released filterpy 1.4.5 does).  Which
                                 of the two the reference's unpinned `filterpy` requirement resolved to cannot be checked
                                 offline (the package is absent): the default is PARITY-UNPINNED, both are tested. */
+
+#define SSA_FLAG_REFERENCE_COV 2u /* the prior covariance in the reference's own arithmetic: P = sum_i (sigma_i' - x)(Wc_i (sigma_i'
+                                - x))^T + Q over all 13 points (filterpy's unscented_transform, call ssa_tasker_simple_2.py:275), whose
+                                Wc_0 ~ -2e8 term cancels the other twelve.  For filters that have diverged late in a predict-mostly
+                                episode that cancellation makes P indefinite and the NEXT predict fails with LinAlgError -- the
+                                reference loses 2-3 % of its filters per 480-step episode this way (:271-285, 369-382).  Default
+                                off: the same matrix expanded around sigma_0' (no cancellation, those filters survive).  On = the
+                                BEHAVIOUR-FAITHFUL form; the env selects it together with SSA_PROP_ELEMENTS. */
 
 /* layout of the per-env update record written by ssa_env_step_f64 (doubles) */
 #define SSA_UPD_STRIDE 64
@@ -300,6 +308,10 @@ int64_t ssa_agent_select_workspace_bytes(int64_t n_obj, int32_t n_env);
  * NIS   nis[k] = y[k]^T inv(S[k]) y[k]                     (fitness_test() :750-754). */
 int ssa_nees_f64(const double *x_true, const double *x, const double *P, double *nees, int64_t n, void *stream);
 int ssa_nis_f64(const double *y, const double *S, double *nis, int64_t n, void *stream);
+/* chi-square containment of fitness_test() (ssa_tasker_simple_2.py:757-760 NIS, :770-771 NEES): counts[0] = number of v[k] with
+ * lo < v[k] < hi (lo, hi = stats.chi2.ppf([alpha/2, 1 - alpha/2], df), computed by the caller), counts[1] = number of non-NaN
+ * v[k] (the reference drops NaN NIS values before the mean and keeps NaN NEES values in it).  counts: device int64[2]. */
+int ssa_chi2_contained_f64(const double *v, int64_t n, double lo, double hi, int64_t *counts, void *stream);
 
 /* library identification */
 int ssa_abi_version(void);

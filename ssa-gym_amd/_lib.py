@@ -46,11 +46,12 @@ class ssa_rollout_params(C.Structure):
 
 
 # constants of include/ssa_hip.h
-ABI_VERSION = 15
+ABI_VERSION = 16
 ST_OK, ST_PREDICT_NAN, ST_PREDICT_LINALG, ST_UPDATE_NAN, ST_UPDATE_LINALG = range(5)
 OBS_AER, OBS_XYZ = 0, 1
 PROP_ELEMENTS, PROP_FG, PROP_J2_RK4 = 0, 1, 2
 FLAG_RESAMPLE = 1
+FLAG_REFERENCE_COV = 2
 UPD_STRIDE, UPD_OBS_TAKEN, UPD_Z_TRUE, UPD_Y, UPD_S, UPD_SIGMAS_H, UPD_VISIBLE, UPD_ACTION = 64, 0, 1, 4, 7, 16, 55, 56
 STAT_SHARDS = 128
 STAT_SHARD_WORDS = 16
@@ -89,6 +90,7 @@ SIGNATURES = {
     "ssa_agent_select_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
     "ssa_nees_f64": (C.c_int, [c_dp, c_dp, c_dp, c_dp, C.c_int64, c_dp]),
     "ssa_nis_f64": (C.c_int, [c_dp, c_dp, c_dp, C.c_int64, c_dp]),
+    "ssa_chi2_contained_f64": (C.c_int, [c_dp, C.c_int64, C.c_double, C.c_double, c_dp, c_dp]),
 }
 
 _lib = None

@@ -553,6 +553,68 @@ SSA_DEV void wave_lds_sync()
 #endif
 }
 
+// U3, covariance in the REFERENCE's own arithmetic (SSA_FLAG_REFERENCE_COV): filterpy's unscented_transform evaluates
+//   P = sum_i (sigma_i' - x) (Wc_i (sigma_i' - x))^T + Q,      i = 0 .. 12,  Wc_0 ~ -2e8 at alpha = 1e-4
+// -- a sum of thirteen outer products whose first term cancels the other twelve.  For a filter whose prior has diverged
+// (|sigma_0' - x| ~ 1e9 m late in a predict-only episode) that cancellation leaves rounding noise of 1e10 m^2 in P: the
+// covariance turns indefinite, robust_cholesky (dynamics.py:402-417) exhausts its ladder at the next predict and the
+// reference marks the filter FAILED (ssa_tasker_simple_2.py:271-285, 369-382): 2-3 % of the filters of a 480-step
+// episode.  covariance_finish() above evaluates the same matrix expanded around sigma_0' without that cancellation and
+// such filters survive; this form reproduces the reference's failure behaviour (tests/test_episode_failures.py).
+// The thirteen rows y_i = sigma_i' - x go to LDS (factor tile + D, contiguous and free by now), the matrix unit forms the
+// three 4x4 tiles of sum_i y_i (Wc_i y_i)^T in four k-chunks (the last one holds point 12 alone), the weight enters with
+// the right operand, as in the reference.
+SSA_DEV int ybase(int g) { return g * 104 + (g & 1) * 28 + (g >> 1) * 32; }   // 0, 132, 240, 372: bank slots as dbase()
+SSA_DEV void covariance_reference(Tiles& t, const ssa_consts& C, int lane, const double (&o)[6])
+{
+    static_assert(372 + 16 * 8 <= OBJ_PER_WAVE * 36 + 408, "y rows fit the factor tile + D");
+    typedef double v2d_t __attribute__((ext_vector_type(2)));
+    double* const Y = t.UA;
+    {
+        const int g = lane >> 4, l = lane & 15;
+        if (l <= 12) {
+            const double* xb = &t.X[g * 6];
+            v2d_t* dst = reinterpret_cast<v2d_t*>(&Y[ybase(g) + l * 8]);
+            dst[0] = v2d_t{o[0] - xb[0], o[1] - xb[1]};
+            dst[1] = v2d_t{o[2] - xb[2], o[3] - xb[3]};
+            dst[2] = v2d_t{o[4] - xb[4], o[5] - xb[5]};
+            dst[3] = v2d_t{0.0, 0.0};
+        }
+    }
+    wave_lds_sync();
+    const int hi = lane >> 4, mid = (lane >> 2) & 3, lo = lane & 3;
+    const double* src = &Y[ybase(mid) + hi * 8 + lo];
+    Moments mo = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+        double a0 = src[kc * 32], a1 = src[kc * 32 + 4];
+        if (kc == 3 && hi != 0) { a0 = 0.0; a1 = 0.0; }           // rows 13 .. 15 do not exist
+        const double w = (kc == 0 && hi == 0) ? C.Wc0 : C.Wi;
+        const double b0 = w * a0, b1 = w * a1;
+        mo.c00 = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, b0, mo.c00, 0, 0, 0);
+        mo.c01 = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, b1, mo.c01, 0, 0, 0);
+        mo.c11 = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, b1, mo.c11, 0, 0, 0);
+    }
+    const int hi1 = hi & 1, lo1 = lo & 1;
+    double* P = &t.P[mid * 36];
+    const double p00 = mo.c00 + t.Q[hi * 6 + lo];
+    const double p01 = mo.c01 + t.Q[hi * 6 + 4 + lo1];
+    const double p11 = mo.c11 + t.Q[(4 + hi1) * 6 + 4 + lo1];
+    // scipy's cholesky reads the upper triangle only; the entries a <= b are mirrored (as covariance_finish)
+    if (hi <= lo) {
+        P[hi * 6 + lo] = p00;
+        P[lo * 6 + hi] = p00;
+    }
+    if (lo < 2) {
+        P[hi * 6 + 4 + lo] = p01;
+        P[(4 + lo) * 6 + hi] = p01;
+        if (hi <= lo) {
+            P[(4 + hi) * 6 + 4 + lo] = p11;
+            P[(4 + lo) * 6 + 4 + hi] = p11;
+        }
+    }
+}
+
 // U2 (common case): upper Cholesky of scale*P for the row's object, lane-distributed: lane c owns column c of the factor in
 // registers; step j (LAPACK dpotf2('U') order) needs column j's finished entries U[i][j], i < j, and the pivot -- all held
 // by lane j -- in every lane, which is one v_mov_b64_dpp row_newbcast:j each (21 per factorisation, no LDS round trip, no
@@ -923,7 +985,8 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     const bool nan_x = ((__ballot(l < 6 && xb_l != xb_l) >> (g * 16)) & 0xFFFFull) != 0;
     wave_lds_sync();
 #if !(defined(SSA_ABLATE) && (SSA_ABLATE & 4))
-    covariance_finish(t, C, lane, mo);
+    if (C.flags & SSA_FLAG_REFERENCE_COV) covariance_reference(t, C, lane, o);   // (wave-uniform branch)
+    else covariance_finish(t, C, lane, mo);
 #endif
     wave_lds_sync();
     SSA_TR(5);
@@ -2043,6 +2106,34 @@ __global__ void nis_kernel(const double* __restrict__ y, const double* __restric
     out[i] = q;
 }
 
+// fitness_test()'s chi-square containment (ssa_tasker_simple_2.py:750-775): how many of v[0..n) lie strictly inside (lo, hi) -- the
+// two-sided 95 % critical points of chi2(df) the caller passes in -- next to the number of non-NaN entries (the reference drops
+// NaN NIS values before taking the mean, :757, and keeps them in the NEES mean, :771).  counts[0] = inside, counts[1] = non-NaN.
+__global__ void __launch_bounds__(64) chi2_zero_kernel(unsigned long long* __restrict__ counts)
+{
+    if (threadIdx.x < 2) counts[threadIdx.x] = 0ull;
+}
+__global__ void __launch_bounds__(256) chi2_contained_kernel(const double* __restrict__ v, int64_t n, double lo, double hi,
+                                                             unsigned long long* __restrict__ counts)
+{
+    unsigned inside = 0, valid = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double x = v[i];
+        inside += (x > lo) && (x < hi);
+        valid += (x == x);
+    }
+    // per wavefront: two ballots per 64 values would need a loop of its own; a shuffle tree of two 32-bit counters is 12 steps
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        inside += __shfl_down(inside, off, 64);
+        valid += __shfl_down(valid, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (inside) atomicAdd(counts, (unsigned long long)inside);
+        if (valid) atomicAdd(counts + 1, (unsigned long long)valid);
+    }
+}
+
 static GeoK make_geo(const ssa_consts* c)
 {
     GeoK g;
@@ -2354,6 +2445,19 @@ int ssa_nis_f64(const double* y, const double* S, double* nis, int64_t n, void* 
     if (n == 0) return SSA_OK;
     if (!y || !S || !nis || n < 0) return SSA_E_INVALID;
     hipLaunchKernelGGL(nis_kernel, dim3(nblk(n, 64)), dim3(64), 0, (hipStream_t)stream, y, S, nis, n);
+    return launch_status();
+}
+
+int ssa_chi2_contained_f64(const double* v, int64_t n, double lo, double hi, int64_t* counts, void* stream)
+{
+    if (!counts || n < 0 || (n > 0 && !v)) return SSA_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(chi2_zero_kernel, dim3(1), dim3(64), 0, s, (unsigned long long*)counts);
+    if (n > 0) {
+        int64_t nb = (n + 256 * 8 - 1) / (256 * 8);
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(chi2_contained_kernel, dim3((unsigned)nb), dim3(256), 0, s, v, n, lo, hi, (unsigned long long*)counts);
+    }
     return launch_status();
 }
 

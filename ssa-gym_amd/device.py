@@ -214,3 +214,15 @@ def nis(y, S):
     out = torch.empty(n, dtype=f64, device=y.device)
     _lib.check(lib.ssa_nis_f64(_chk(y, "y"), _chk(S, "S"), _chk(out, "nis"), n, _stream()), "ssa_nis_f64")
     return out
+
+
+def chi2_contained(values, lo, hi):
+    """(inside, valid) = number of entries strictly inside (lo, hi) and number of non-NaN entries of a float64 device tensor
+    (fitness_test()'s chi-square containment, ssa_tasker_simple_2.py:757-760, 770-771)."""
+    lib = _lib.load()
+    v = values.reshape(-1)
+    out = torch.empty(2, dtype=torch.int64, device=v.device)
+    _lib.check(lib.ssa_chi2_contained_f64(_chk(v, "values"), v.numel(), float(lo), float(hi), out.data_ptr(), _stream()),
+               "ssa_chi2_contained_f64")
+    c = out.cpu()
+    return int(c[0]), int(c[1])

@@ -22,7 +22,38 @@ def resolve_kernel_variant(config):
         raise NotImplementedError("hx/mean_z/residual_z combination %s has no fused kernel" % (ids,))
     if fx_id != ("fx", "farnocchia"):
         raise NotImplementedError("fx %r has no fused kernel" % (config['fx'],))
-    propagator = config.get('propagator', getattr(config['fx'], 'propagator', 'fg'))
+    propagator = config.get('propagator', getattr(dynamics.unwrap_partial(config['fx']), 'propagator', 'fg'))
     if propagator not in ('fg', 'elements', 'j2'):
         raise NotImplementedError("unknown propagator %r" % (propagator,))
     return model, propagator
+
+
+def resolve_perturbation(config):
+    """(J2, R_eq) of the device integrator for this config, or None for the defaults: the acceleration bound to an
+    fx_xyz_cowell token (`ad` / ad_kwargs, envs/dynamics.py:168-201 of the reference), or config['ad'] / config['ad_kwargs']
+    next to a Cowell / J2 propagator."""
+    fx = dynamics.unwrap_partial(config['fx'])
+    if config.get('ad') is not None:
+        fx = dynamics.fx_xyz_cowell.with_ad(config['ad'], **dict(config.get('ad_kwargs') or {}))
+    if hasattr(fx, 'perturbation'):
+        return fx.perturbation()
+    return None
+
+
+def kernel_consts(config, Q, R, dt, obs_limit_rad, obs_lla):
+    """(ssa_consts, measurement model) for a config dict: the ONE place where SSA_Tasker_Env and SSA_Tasker_VecEnv turn the
+    operator tokens and the optional keys `propagator`, `resample_sigmas`, `covariance_form` ('reference' | 'centred';
+    default: 'reference' with the 'elements' propagator -- the behaviour-faithful variant -- else 'centred'), `ad` /
+    `ad_kwargs` into kernel constants."""
+    from .. import host
+    model, propagator = resolve_kernel_variant(config)
+    kw = {}
+    pert = resolve_perturbation(config)
+    if pert is not None:
+        if propagator != 'j2':
+            raise NotImplementedError("an acceleration (ad) needs the Cowell / J2 propagator, got %r" % (propagator,))
+        kw.update(j2=pert[0], r_eq=pert[1])
+    consts = host.make_consts(Q, R, config['alpha'], config['beta'], config['kappa'], dt, obs_limit_rad, obs_lla, obs_type=model,
+                              propagator=propagator, resample=bool(config.get('resample_sigmas', False)),
+                              update_interval=config['update_interval'], covariance=config.get('covariance_form'), **kw)
+    return consts, model

@@ -123,9 +123,65 @@ class _RobustCholesky(_Operator):
         return U.cpu().numpy().reshape(6, 6)
 
 
+class _Accel(_Operator):
+    """perturbing-acceleration token for fx_xyz_cowell's `ad` hook (reference: envs/dynamics.py:21 ad_none, :168
+    `fx_xyz_cowell(x, dt, k, rtol, *, events=None, ad=ad_none, **ad_kwargs)`).  The reference hands `ad` to poliastro's
+    func_twobody inside a DOP853 integration; here a token selects the acceleration term of the device integrator."""
+
+    def __init__(self, name, reference):
+        self.kernel_id, self.reference, self.__name__ = ("ad", name), reference, "ad_" + name
+
+    def __call__(self, t0, u_, k_, **kw):
+        raise _lib.SsaHipError("acceleration tokens select a term of the device integrator; they are not evaluated on the host")
+
+
+ad_none = _Accel("none", "envs/dynamics.py:21 ad_none")
+ad_j2 = _Accel("j2", "poliastro.core.perturbations.J2_perturbation (ad_kwargs J2, R)")
+
+
+class _FxCowell(_FxFarnocchia):
+    """fx_xyz_cowell (envs/dynamics.py:168-201): Cowell's formulation r'' = -mu r / |r|^3 + ad(t, u, k, **ad_kwargs).  The
+    reference integrates it with DOP853 (and never calls it on its hot path); on the device it is the classical RK4
+    integrator of SSA_PROP_J2_RK4 in sub-steps of at most 5 s.  `ad` is a token: ad_none (two-body: J2 = 0) or ad_j2 with
+    ad_kwargs J2 / R (defaults: poliastro's Earth).  `fx_xyz_cowell.with_ad(ad_j2, J2=.., R=..)` or
+    `functools.partial(fx_xyz_cowell, ad=ad_j2, J2=.., R=..)` -- the form a reference user would write -- both resolve."""
+    reference = "envs/dynamics.py:168 fx_xyz_cowell"
+
+    def __init__(self, ad=None, **ad_kwargs):
+        super().__init__('j2')
+        self.ad = ad_none if ad is None else ad
+        self.ad_kwargs = dict(ad_kwargs)
+
+    def with_ad(self, ad, **ad_kwargs):
+        return _FxCowell(ad, **ad_kwargs)
+
+    def perturbation(self):
+        """(J2, R_eq) the device integrator runs with"""
+        kid = getattr(self.ad, "kernel_id", None)
+        if kid == ("ad", "none") or getattr(self.ad, "__name__", None) == "ad_none":
+            return 0.0, host.R_EQ_EARTH
+        if kid == ("ad", "j2") or getattr(self.ad, "__name__", None) == "J2_perturbation":
+            extra = set(self.ad_kwargs) - {"J2", "R"}
+            if extra:
+                raise NotImplementedError("ad_kwargs %s have no device counterpart (J2, R)" % sorted(extra))
+            return float(self.ad_kwargs.get("J2", host.J2_EARTH)), float(self.ad_kwargs.get("R", host.R_EQ_EARTH))
+        raise NotImplementedError("acceleration %r has no device integrator term; supported: ad_none, ad_j2 "
+                                  "(no CPU fallback by design)" % (self.ad,))
+
+    def __call__(self, x, dt, k=None, rtol=None, *, events=None, ad=None, **ad_kwargs):
+        if ad is not None or ad_kwargs:
+            return self.with_ad(self.ad if ad is None else ad, **(ad_kwargs or self.ad_kwargs))(x, dt)
+        torch, device = _dev()
+        j2, r_eq = self.perturbation()
+        xd = device.as_dev(np.asarray(x, dtype=np.float64).reshape(1, 6))
+        nsub = max(1, int(np.ceil(abs(dt) / 5.0)))
+        return device.propagate_j2(xd, float(dt), j2, r_eq, nsub).cpu().numpy().reshape(6)
+
+
 fx_xyz_farnocchia = _FxFarnocchia('fg')            # default: reduced strong-elliptic form (SSA_PROP_FG)
 fx_xyz_farnocchia_elements = _FxFarnocchia('elements')  # operation-by-operation variant (SSA_PROP_ELEMENTS)
 fx_xyz_j2_rk4 = _FxFarnocchia('j2')                # EXTENSION: two-body + J2, RK4 (no reference counterpart)
+fx_xyz_cowell = _FxCowell()                        # envs/dynamics.py:168: Cowell with a pluggable acceleration (default ad_none)
 hx_aer_erfa = _HxAer()
 hx_xyz = _HxXyz()
 mean_z_uvw = _MeanZUvw()
@@ -135,10 +191,23 @@ residual_xyz = _ResidualXyz()
 robust_cholesky = _RobustCholesky()
 
 
+def unwrap_partial(fn):
+    """functools.partial(fx_xyz_cowell, ad=..., **ad_kwargs) -- how a reference user binds the acceleration before handing
+    `fx` to the env -- becomes the equivalent token"""
+    import functools
+    if isinstance(fn, functools.partial) and isinstance(fn.func, _FxCowell) and not fn.args:
+        kw = dict(fn.keywords or {})
+        for ignored in ("k", "rtol", "events"):     # integrator controls of the reference's DOP853 call
+            kw.pop(ignored, None)
+        return fn.func.with_ad(kw.pop("ad", fn.func.ad), **(kw or fn.func.ad_kwargs))
+    return fn
+
+
 def kernel_id_of(fn, role):
     """map a config callable to a fused-kernel variant; unknown callables are refused (the
     reference would call arbitrary Python per sigma point; that is exactly the path this
     package replaces, and there is deliberately no CPU fallback)."""
+    fn = unwrap_partial(fn)
     if isinstance(fn, _Operator):
         kid = fn.kernel_id
     elif role == "residual_z" and fn is np.subtract:

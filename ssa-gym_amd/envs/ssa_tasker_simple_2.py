@@ -14,7 +14,7 @@ import numpy as np
 
 from .. import _lib, host
 from . import transformations
-from ._config import resolve_kernel_variant
+from ._config import kernel_consts, resolve_kernel_variant
 from ._gymshim import Env, np_random, spaces
 from .results import error_failed
 
@@ -178,10 +178,7 @@ class SSA_Tasker_Env(Env):
         if hist == 'auto':
             hist = 'full' if self.n * bytes_per_step <= 64 * 2 ** 30 else 2
         self._H = self.n if hist == 'full' else max(2, int(hist))
-        self._consts = host.make_consts(self.Q, self.R, self.alpha, self.beta, self.kappa, self.dt, self.obs_limit,
-                                        self.obs_lla, obs_type=self._model, propagator=propagator,
-                                        resample=bool(config.get('resample_sigmas', False)),
-                                        update_interval=self.update_interval)
+        self._consts, _ = kernel_consts(config, self.Q, self.R, self.dt, self.obs_limit, self.obs_lla)
         self._engine = None
         self._device_rng = bool(config.get('device_rng', False))
         self.np_random = None
@@ -558,6 +555,50 @@ class SSA_Tasker_Env(Env):
         k = np.where(self.obs_taken[:self.i + 1])[0]
         if len(k):
             out[k] = device.nis(torch.as_tensor(self._y[k]).to("cuda"), torch.as_tensor(self._S_sel[k]).to("cuda")).cpu().numpy()
+        return out
+
+    # two-sided chi-square critical points stats.chi2.ppf([alpha / 2, 1 - alpha / 2], df) for the reference's alpha = 0.05
+    # (:756, :762); other alphas need scipy
+    _CHI2_95 = {3: (0.21579528262389788, 9.348403604496145), 6: (1.2373442457912032, 14.449375335447922)}
+
+    @classmethod
+    def _chi2_points(cls, alpha, df):
+        if abs(alpha - 0.05) < 1e-15 and df in cls._CHI2_95:
+            return cls._CHI2_95[df]
+        from scipy import stats
+        lo, hi = stats.chi2.ppf([alpha / 2, 1 - alpha / 2], df=df)
+        return float(lo), float(hi)
+
+    def fitness_chi2(self, alpha=0.05):
+        """Tests 2 and 4 of fitness_test() (:750-775): the percentage of normalised innovations squared (NaN dropped, :757)
+        and of normalised estimation errors squared (NaN kept in the mean, :771) inside the two-sided (1 - alpha) chi-square
+        interval, counted ON THE DEVICE (ssa_nis_f64 / ssa_nees_f64 + ssa_chi2_contained_f64) over the steps simulated so
+        far that are still resident.  Returns {'Test 2: NIS chi2': pct, 'Test 4: NEES chi2': pct, counts...}."""
+        import torch
+        from .. import device
+        e = self._engine
+        out = {}
+        k = np.where(self.obs_taken[:self.i + 1])[0]
+        lo, hi = self._chi2_points(alpha, 3)
+        if len(k):
+            nis = device.nis(torch.as_tensor(self._y[k]).to("cuda"), torch.as_tensor(self._S_sel[k]).to("cuda"))
+            inside, valid = device.chi2_contained(nis, lo, hi)
+        else:
+            inside, valid = 0, 0
+        out['Test 2: NIS chi2'] = round(100.0 * inside / valid, 2) if valid else float('nan')
+        out['nis_inside'], out['nis_valid'] = inside, valid
+        first = max(0, self.i - e.H + 1)
+        slots = [i % e.H for i in range(first, self.i + 1)]
+        if slots == list(range(slots[0], slots[0] + len(slots))):     # contiguous in the history tensors: no gather
+            sl = slice(slots[0], slots[0] + len(slots))
+            xt, x, P = e.x_true[sl], e.x_filter[sl], e.P_filter[sl]
+        else:
+            xt, x, P = e.x_true[slots], e.x_filter[slots], e.P_filter[slots]
+        nees = device.nees(xt.reshape(-1, 6), x.reshape(-1, 6), P.reshape(-1, 6, 6))
+        lo, hi = self._chi2_points(alpha, 6)
+        inside, _ = device.chi2_contained(nees, lo, hi)
+        out['Test 4: NEES chi2'] = round(100.0 * inside / nees.numel(), 2)
+        out['nees_inside'], out['nees_total'] = inside, int(nees.numel())
         return out
 
     def failed_filters(self):

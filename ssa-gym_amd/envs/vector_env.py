@@ -13,7 +13,7 @@ import numpy as np
 
 from .. import _lib, host
 from . import transformations
-from ._config import resolve_kernel_variant
+from ._config import kernel_consts
 from ._gymshim import np_random, spaces
 
 
@@ -32,13 +32,8 @@ class SSA_Tasker_VecEnv:
         self.P_0 = np.diag(self.x_sigma ** 2) if config['P_0'] is None else np.copy(config['P_0'])
         R = np.diag(self.z_sigma ** 2) if config['R'] is None else np.copy(config['R'])
         Q = host.Q_discrete_white_noise(dim=2, dt=self.dt, var=config['q_sigma'] ** 2, block_size=3, order_by_dim=False)
-        model, propagator = resolve_kernel_variant(config)   # same acceptance rules as SSA_Tasker_Env
         obs_lla = np.array(config['observer']) * [host.deg2rad, host.deg2rad, 1]
-        self._consts = host.make_consts(Q, R, config['alpha'], config['beta'], config['kappa'], self.dt,
-                                        np.radians(config['obs_limit']), obs_lla, obs_type=model,
-                                        propagator=propagator,
-                                        resample=bool(config.get('resample_sigmas', False)),
-                                        update_interval=config['update_interval'])
+        self._consts, model = kernel_consts(config, Q, R, self.dt, np.radians(config['obs_limit']), obs_lla)   # as SSA_Tasker_Env
         trans = (np.asarray(config['trans_matrix']) if config.get('trans_matrix') is not None
                  else transformations.trans_matrix_table(config['t_0'], self.dt, self.n))
         self._gen = torch.Generator(device="cuda").manual_seed(int(seed))

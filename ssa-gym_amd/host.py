@@ -78,8 +78,12 @@ R_EQ_EARTH = 6378136.6     # poliastro Earth.R [m]
 
 
 def make_consts(Q, R, alpha, beta, kappa, dt, obs_limit_rad, obs_lla, obs_type='aer', propagator='fg',
-                resample=False, update_interval=1, j2=J2_EARTH, r_eq=R_EQ_EARTH, rk4_substeps=None):
-    """pack the per-environment constants for the kernels (include/ssa_hip.h: ssa_consts)."""
+                resample=False, update_interval=1, j2=J2_EARTH, r_eq=R_EQ_EARTH, rk4_substeps=None, covariance=None):
+    """pack the per-environment constants for the kernels (include/ssa_hip.h: ssa_consts).
+
+    covariance: 'reference' = the prior covariance in the reference's own arithmetic (SSA_FLAG_REFERENCE_COV: reproduces the
+    reference's episode-level filter failures), 'centred' = the cancellation-free expansion; None = 'reference' with the
+    'elements' propagator (the behaviour-faithful variant), 'centred' otherwise."""
     Wm, Wc, scale = merwe_weights(alpha, beta, kappa)
     sm, sc = exact_weight_sums(Wm, Wc)
     c = _lib.ssa_consts()
@@ -96,6 +100,10 @@ def make_consts(Q, R, alpha, beta, kappa, dt, obs_limit_rad, obs_lla, obs_type='
     c.j2, c.r_eq = float(j2), float(r_eq)
     # RK4 sub-step <= 5 s: local error (n h)^5/120 |r| < 1e-6 m even in LEO
     c.rk4_substeps = int(rk4_substeps) if rk4_substeps else max(1, int(np.ceil(abs(dt) / 5.0)))
-    c.flags = _lib.FLAG_RESAMPLE if resample else 0
+    if covariance is None:
+        covariance = 'reference' if propagator == 'elements' else 'centred'
+    if covariance not in ('reference', 'centred'):
+        raise ValueError("covariance must be 'reference' or 'centred', got %r" % (covariance,))
+    c.flags = (_lib.FLAG_RESAMPLE if resample else 0) | (_lib.FLAG_REFERENCE_COV if covariance == 'reference' else 0)
     c.update_interval = int(update_interval)
     return c

@@ -216,3 +216,32 @@ def test_step_kernels_keep_their_register_budget(tmp_path):
             assert kern[name]["private_segment_fixed_size"] == 0 and kern[name]["vgpr_spill_count"] == 0, (name, kern[name])
         checked += 1
     assert checked == 9
+
+
+def test_acceleration_tokens_and_covariance_form_resolve_on_the_host(pkg):
+    """config resolution is host logic (no GPU): the fx_xyz_cowell / ad tokens of envs/dynamics.py:168-201 and the
+    covariance form that goes with each propagator (SSA_FLAG_REFERENCE_COV with 'elements': the behaviour-faithful variant)."""
+    import functools
+    from ssa_gym_amd import _lib, host
+    from ssa_gym_amd.envs import dynamics as D, env_config
+    from ssa_gym_amd.envs._config import kernel_consts, resolve_kernel_variant, resolve_perturbation
+    fj = functools.partial(D.fx_xyz_cowell, ad=D.ad_j2, J2=1e-3, rtol=1e-11)
+    assert resolve_kernel_variant(dict(env_config, fx=fj)) == ('aer', 'j2')
+    assert resolve_perturbation(dict(env_config, fx=fj)) == (1e-3, host.R_EQ_EARTH)
+    assert resolve_perturbation(dict(env_config, fx=D.fx_xyz_cowell)) == (0.0, host.R_EQ_EARTH)
+    assert resolve_perturbation(dict(env_config)) is None
+    with pytest.raises(NotImplementedError):
+        resolve_perturbation(dict(env_config, fx=D.fx_xyz_cowell.with_ad(D.ad_j2, J3=1.0)))
+    Q, R, lla = np.eye(6), np.eye(3), np.array([0.6, -1.3, 20.0])
+    flags = {}
+    for prop in ('fg', 'elements', 'j2'):
+        c, model = kernel_consts(dict(env_config, propagator=prop), Q, R, 20.0, 0.0, lla)
+        flags[prop] = c.flags
+        assert model == 'aer'
+    assert flags['elements'] & _lib.FLAG_REFERENCE_COV and not flags['fg'] & _lib.FLAG_REFERENCE_COV and not flags['j2'] & _lib.FLAG_REFERENCE_COV
+    c, _ = kernel_consts(dict(env_config, propagator='fg', covariance_form='reference', resample_sigmas=True), Q, R, 20.0, 0.0, lla)
+    assert c.flags == (_lib.FLAG_REFERENCE_COV | _lib.FLAG_RESAMPLE)
+    c, _ = kernel_consts(dict(env_config, propagator='elements', covariance_form='centred'), Q, R, 20.0, 0.0, lla)
+    assert c.flags == 0
+    with pytest.raises(ValueError):
+        kernel_consts(dict(env_config, covariance_form='exact'), Q, R, 20.0, 0.0, lla)

@@ -434,3 +434,88 @@ def test_anees_and_nis_of_an_episode(envs):
         want = env.y[i, aa] @ np.linalg.inv(env.S[i, aa]) @ env.y[i, aa]
         assert nis[i] == pytest.approx(want, rel=1e-8)
     assert np.isnan(nis[0]) and np.isnan(nis[21:]).all()
+
+
+def test_chi2_containment_of_fitness_test(envs):
+    """Tests 2 and 4 of fitness_test() (ssa_tasker_simple_2.py:750-775): the 95 % chi-square containment of the NIS (NaN dropped)
+    and NEES (NaN kept) series, counted on the device (ssa_chi2_contained_f64), against the reference's numpy / scipy expressions."""
+    import torch
+    from scipy import stats
+    from ssa_gym_amd import device
+    cfg = dict(envs.env_config)
+    cfg.update(rso_count=12, steps=40, reward_type='trinary', obs_returned='flatten', seed=4, history='full', obs_limit=15)
+    env = envs.make(config=cfg)
+    for k in range(1, 31):
+        env.step(k % 12)
+    got = env.fitness_chi2()
+    alpha = 0.05
+    ci = [alpha / 2, 1 - alpha / 2]
+    # Test 2 (:750-760)
+    NIS = []
+    for i in range(1, env.i + 1):
+        a = int(env.actions[i])
+        NIS.append(env.y[i, a] @ np.linalg.inv(env.S[i, a]) @ env.y[i, a] if env.obs_taken[i] else np.nan)
+    NIS = np.array(NIS)
+    NIS = NIS[~np.isnan(NIS)]
+    cr = stats.chi2.ppf(ci, df=3)
+    assert env._chi2_points(alpha, 3) == pytest.approx(tuple(cr), rel=1e-12)
+    assert env._chi2_points(alpha, 6) == pytest.approx(tuple(stats.chi2.ppf(ci, df=6)), rel=1e-12)
+    assert 0 < len(NIS) < 30                                   # (a 15-degree mask: some selected objects were not visible)
+    assert got['nis_valid'] == len(NIS)
+    assert got['Test 2: NIS chi2'] == np.round(np.mean((NIS > cr[0]) * (NIS < cr[1])) * 100, 2)
+    # Test 4 (:762-771) over the simulated steps
+    cr6 = stats.chi2.ppf(ci, df=6)
+    delta = np.asarray(env.x_true[:env.i + 1]) - np.asarray(env.x_filter[:env.i + 1])
+    Pf = np.asarray(env.P_filter[:env.i + 1])
+    nees = np.array([[delta[i, j] @ np.linalg.inv(Pf[i, j]) @ delta[i, j] for j in range(12)] for i in range(env.i + 1)])
+    near = np.minimum(np.abs(nees - cr6[0]), np.abs(nees - cr6[1])) < 1e-6 * nees      # (no entry sits on a critical point)
+    assert not near.any()
+    assert got['nees_total'] == nees.size and got['nees_inside'] == int(((nees > cr6[0]) * (nees < cr6[1])).sum())
+    assert got['Test 4: NEES chi2'] == np.round(np.mean((nees > cr6[0]) * (nees < cr6[1])) * 100, 2)
+    # the primitive on its own: NaN handling and the strict inequalities
+    v = torch.tensor([0.1, np.nan, 0.5, 2.0, 9.0, 9.5, np.inf, 0.5], dtype=torch.float64, device="cuda")
+    assert device.chi2_contained(v, 0.5, 9.0) == (1, 7)
+    assert device.chi2_contained(v[:0], 0.5, 9.0) == (0, 0)
+    big = torch.rand(300001, dtype=torch.float64, device="cuda") * 20
+    inside, valid = device.chi2_contained(big, cr6[0], cr6[1])
+    b = big.cpu().numpy()
+    assert valid == b.size and inside == int(((b > cr6[0]) & (b < cr6[1])).sum())
+
+
+def test_cowell_acceleration_hook(envs):
+    """the reference's pluggable acceleration (envs/dynamics.py:168-201 fx_xyz_cowell(..., ad=ad_none, **ad_kwargs)): the tokens
+    ad_none / ad_j2 bound to fx_xyz_cowell -- directly or with functools.partial, as a reference user would -- select the device
+    integrator's term; ad_none reproduces two-body Farnocchia, ad_j2 the J2 extension, and the env accepts either as `fx`."""
+    import functools
+    from ssa_gym_amd import device, host
+    from ssa_gym_amd.envs import dynamics as D
+    from ssa_gym_amd.envs._config import kernel_consts, resolve_perturbation
+    x = golden("catalogue_subset.npy")[5]
+    kep = D.fx_xyz_farnocchia(x, 20.0)
+    two = D.fx_xyz_cowell(x, 20.0)                                     # default ad = ad_none
+    assert np.linalg.norm(two[:3] - kep[:3]) / np.linalg.norm(kep[:3]) < 1e-11
+    fj = functools.partial(D.fx_xyz_cowell, ad=D.ad_j2, J2=host.J2_EARTH, R=host.R_EQ_EARTH)
+    want = device.propagate_j2(device.as_dev(x.reshape(1, 6)), 20.0, host.J2_EARTH, host.R_EQ_EARTH, 4).cpu().numpy().reshape(6)
+    assert np.array_equal(D.unwrap_partial(fj)(x, 20.0), want)
+    assert np.array_equal(D.fx_xyz_cowell(x, 20.0, ad=D.ad_j2), want)
+    assert np.array_equal(D.fx_xyz_cowell.with_ad(D.ad_j2, J2=2 * host.J2_EARTH)(x, 20.0),
+                          device.propagate_j2(device.as_dev(x.reshape(1, 6)), 20.0, 2 * host.J2_EARTH, host.R_EQ_EARTH, 4).cpu().numpy().reshape(6))
+    # the env: fx = partial(fx_xyz_cowell, ad=ad_j2) steps exactly like fx = fx_xyz_j2_rk4; ad_none like J2 = 0
+    base = dict(envs.env_config)
+    base.update(rso_count=8, steps=12, reward_type='trinary', obs_returned='flatten', seed=2)
+    runs = {}
+    for name, fx in (("token", D.fx_xyz_j2_rk4), ("partial", fj), ("none", D.fx_xyz_cowell)):
+        cfg = dict(base, fx=fx)
+        env = envs.make(config=cfg)
+        for k in range(5):
+            obs, _, _, _ = env.step(k)
+        runs[name] = obs
+    assert np.array_equal(runs["token"], runs["partial"])
+    assert not np.array_equal(runs["token"], runs["none"])
+    assert resolve_perturbation(dict(base, fx=D.fx_xyz_cowell)) == (0.0, host.R_EQ_EARTH)
+    c, _ = kernel_consts(dict(base, fx=fj), env.Q, env.R, 20.0, 0.0, env.obs_lla)
+    assert c.j2 == host.J2_EARTH and c.propagator == 2
+    with pytest.raises(NotImplementedError):
+        resolve_perturbation(dict(base, fx=D.fx_xyz_cowell.with_ad(lambda t, u, k: 0)))
+    with pytest.raises(NotImplementedError):       # an acceleration next to the analytic two-body propagator has no kernel
+        kernel_consts(dict(base, ad=D.ad_j2), env.Q, env.R, 20.0, 0.0, env.obs_lla)

@@ -1,0 +1,98 @@
+"""Episode-level failure behaviour (parity of what a whole episode DOES, not of one step).
+
+In the reference a filter fails when predict() raises LinAlgError (robust_cholesky's ladder exhausted, dynamics.py:402-417) or
+returns NaN (newton() gave up, farnocchia.py:337-353); filter_error() then overwrites it with the 1e20 sentinels
+(ssa_tasker_simple_2.py:271-285, 369-382) and the next np.max(delta_pos) ends a 'jones' / 'shaped' episode (:325-343).  With the
+env defaults (alpha = 1e-4) the reference loses 2-3 % of its filters over a 480-step round-robin episode: the prior covariance
+sum_i Wc_i y_i y_i^T carries Wc_0 ~ -2e8, and for a diverged (hyperbolic) prior its cancellation noise makes P indefinite.
+
+Measured on the oracle (reference order of operations) and on the HIP path, same inputs:
+  * SSA_PROP_ELEMENTS + SSA_FLAG_REFERENCE_COV (what config['propagator'] = 'elements' selects): the BEHAVIOUR-FAITHFUL variant --
+    failure counts per 60-step window, status-code mix and the 'jones' termination step within the stated band of the oracle;
+  * SSA_PROP_FG (the default, the headline of bench.py): more accurate than the reference on diverged states, its filters
+    survive -- zero failures, asserted as exactly that: a documented behavioural difference.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import episode_workload as ew
+from conftest import GOLDEN
+
+FIXTURE = os.path.join(GOLDEN, "episode_failures_oracle.json")
+
+
+def band(a, b):
+    """two failure counts are 'the same statistics' when they differ by no more than three standard deviations of a
+    Poisson count of their size (+3): the oracle's own two summation orders differ by 52 vs 64 at step 479"""
+    return abs(a - b) <= 3.0 * np.sqrt(max(a, b)) + 3.0
+
+
+@pytest.fixture(scope="module")
+def workload():
+    return ew.workload(m=2000, seed=7)
+
+
+@pytest.fixture(scope="module")
+def oracle_runs(workload):
+    import oracle as orc
+    orc.build()
+    return {"reference_order": ew.run_oracle(workload), "centred_means": ew.run_oracle(workload, centred=True)}
+
+
+def test_oracle_episode_matches_the_committed_fixture(oracle_runs):
+    """the fixture (tests/golden/gen_episode_failures.py, generated in the build container) pins the oracle's episode: same
+    libm, same summation order -> same counts; a different host libm may move single filters across the ladder's edge"""
+    fx = json.load(open(FIXTURE))["seed7"]
+    for name in ("reference_order", "centred_means"):
+        got, want = oracle_runs[name], fx[name]
+        print(name, got)
+        assert got["jones_done_step"] == want["jones_done_step"]
+        for w in ew.WINDOWS:
+            assert band(got["failed_at"][w], want["failed_at"][str(w)]), (name, w, got, want)
+    # the headline fact: the reference arithmetic loses filters late in the episode, almost all to LinAlgError
+    ro = oracle_runs["reference_order"]
+    assert ro["failed_at"][240] <= 2 and 30 <= ro["failed_at"][479] <= 90
+    assert ro["status_mix"][ew.orc.ST_PREDICT_LINALG] >= 0.8 * ro["failed_at"][479]
+
+
+@pytest.mark.gpu
+def test_elements_variant_reproduces_the_reference_failures_fg_does_not(workload, oracle_runs):
+    import torch
+    import ssa_gym_amd
+    from ssa_gym_amd import _lib, device, host, engine
+    ssa_gym_amd.build()
+    _lib.load()
+
+    class H:
+        pass
+    hip = H()
+    hip.torch, hip.lib, hip.dev, hip.host, hip.engine = torch, _lib, device, host, engine
+    ro = oracle_runs["reference_order"]
+    runs = {"elements (reference covariance: the env's 'elements')": ew.run_hip(hip, workload, "elements"),
+            "elements + centred covariance": ew.run_hip(hip, workload, "elements", covariance="centred"),
+            "fg (default)": ew.run_hip(hip, workload, "fg"),
+            "fg + reference covariance": ew.run_hip(hip, workload, "fg", covariance="reference")}
+    print("oracle (reference order)", ro)
+    print("oracle (centred means)  ", oracle_runs["centred_means"])
+    for k, v in runs.items():
+        print(k, v)
+    el = runs["elements (reference covariance: the env's 'elements')"]
+    # ---- the behaviour-faithful variant: same failure statistics as the reference arithmetic
+    for w in ew.WINDOWS:
+        assert band(el["failed_at"][w], ro["failed_at"][w]), (w, el["failed_at"], ro["failed_at"])
+    assert el["failed_at"][479] >= 30
+    assert el["status_mix"][_lib.ST_PREDICT_LINALG] >= 0.8 * el["failed_at"][479]          # the ladder, not Kepler
+    assert el["status_mix"][_lib.ST_UPDATE_NAN] == 0 and el["status_mix"][_lib.ST_UPDATE_LINALG] == 0
+    assert abs(el["jones_done_step"] - ro["jones_done_step"]) <= 1
+    assert el["first_failure_step"] is not None and 150 <= el["first_failure_step"] <= 400
+    # ---- the default: NOT the reference's failure behaviour (more accurate on diverged states; nothing fails), stated as such
+    fg = runs["fg (default)"]
+    assert all(v == 0 for v in fg["failed_at"].values()), fg
+    assert abs(fg["jones_done_step"] - ro["jones_done_step"]) <= 1        # a 'jones' episode still ends at the same step
+    # what each ingredient contributes: the reference's covariance arithmetic alone (with the accurate propagator) fails nothing,
+    # its propagator alone (with the cancellation-free covariance) a tenth of the reference's count
+    assert all(v == 0 for v in runs["fg + reference covariance"]["failed_at"].values())
+    assert runs["elements + centred covariance"]["failed_at"][479] <= 0.4 * ro["failed_at"][479]
