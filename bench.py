@@ -177,10 +177,12 @@ def local_variant_rate(m, K, W, propagator, resample=False, seed=100):
     return out
 
 
-def closed_loop_rate(m, K, W, seed=100):
-    """closed loop WITHOUT the host: per step one launch of the step kernel, then the device-side agent (the reference's
-    agent_visible_greedy, agents.py:36: arg-max of trace(P) over the visible objects -- ssa_agent_select_f64, two small
-    launches) writes the action word the next step reads, all in one stream.  Same workload, episodes of 480 steps."""
+def closed_loop_rate(m, K, W, seed=100, persistent=True, chunk=120, agent=None):
+    """closed loop WITHOUT the host: the reference's agent_visible_greedy (agents.py:36: arg-max of trace(P) over the visible
+    objects) chooses every step's action on the device.  persistent: ssa_env_closed_loop_f64 -- `chunk` steps and their decisions
+    per launch, the wavefronts agree on the next action among themselves while the next predicts already run; else the
+    multi-launch form: per step one launch of the step kernel, then ssa_agent_select_f64 (two small launches) writes the action
+    word the next step reads, all in one stream.  Same workload, episodes of 480 steps."""
     import torch
     from ssa_gym_amd import _lib, engine, host
     pb = build_problem(m, seed=seed)
@@ -191,26 +193,47 @@ def closed_loop_rate(m, K, W, seed=100):
     eng.load_state(0, pb["x_true"], pb["x"], np.broadcast_to(pb["P0"], (m, 6, 6)))
     snap = eng.snapshot(0)
     word = torch.zeros(1, dtype=torch.int32, device="cuda")
-    fb = torch.zeros(1, dtype=torch.int32, device="cuda")
-    picks = torch.zeros((K + W + 1, 2), dtype=torch.int64, device="cuda")
+    fb = torch.zeros(max(K, W, chunk) + 2, dtype=torch.int32, device="cuda")
+    picks = torch.zeros((K + W + 2 + chunk, 2), dtype=torch.int64, device="cuda")
+    log = torch.zeros(chunk + 1, dtype=torch.int32, device="cuda")
+    stats = torch.zeros((chunk, _lib.STAT_STRIDE), dtype=torch.float64, device="cuda")
     st = {"i": 0, "tick": 0, "n": 0}
+    AG = _lib.AGENT_VISIBLE_GREEDY if agent is None else int(agent)
+
+    def new_episode():
+        eng.flush_stats()
+        st["tick"] += (-st["tick"]) % 480
+        eng.restore(st["tick"] % 2, snap)
+        st["i"] = 0
+        eng.launch_agent_select(st["tick"], st["tick"], AG, (log if persistent else word).data_ptr(), fallback_ptr=fb.data_ptr())
 
     def run(n):
-        for _ in range(n):
+        done = 0
+        while done < n:
             if st["i"] == 479:
-                eng.flush_stats()
-                st["tick"] += (-st["tick"]) % 480
-                eng.restore(st["tick"] % 2, snap)
-                st["i"] = 0
-                eng.launch_agent_select(st["tick"], st["tick"], _lib.AGENT_VISIBLE_GREEDY, word.data_ptr(), fallback_ptr=fb.data_ptr())
+                new_episode()
+            if persistent:
+                kk = min(chunk, n - done, 479 - st["i"])
+                t = st["tick"]
+                ok = eng.launch_closed_loop(t % 2, t + 1, AG, log[:kk + 1], stats, fallback=fb[:kk + 1],
+                                            picks=picks[st["n"]:st["n"] + kk + 1])
+                if not ok:
+                    raise RuntimeError("ssa_env_closed_loop_f64 declined %d objects" % m)
+                log[:1].copy_(log[kk:kk + 1])        # the decision after the chunk's last step opens the next chunk
+                st["i"] += kk
+                st["tick"] += kk
+                st["n"] += kk
+                done += kk
+                continue
             st["i"] += 1
             st["tick"] += 1
             t = st["tick"]
             eng.launch_step((t - 1) % 2, t % 2, t, actions_ptr=word.data_ptr(), fast_stats=True, defer_fold=True)
-            eng.launch_agent_select(t, t, _lib.AGENT_VISIBLE_GREEDY, word.data_ptr(), fallback_ptr=fb.data_ptr(),
-                                    pick_ptr=picks.data_ptr() + 16 * st["n"])
+            eng.launch_agent_select(t, t, AG, word.data_ptr(), fallback_ptr=fb.data_ptr(),
+                                    pick_ptr=picks.data_ptr() + 16 * (st["n"] + 1))
             st["n"] += 1
-    eng.launch_agent_select(0, 0, _lib.AGENT_VISIBLE_GREEDY, word.data_ptr(), fallback_ptr=fb.data_ptr())
+            done += 1
+    eng.launch_agent_select(0, 0, AG, (log if persistent else word).data_ptr(), fallback_ptr=fb.data_ptr())
     run(W)
 
     def sync():
@@ -221,10 +244,15 @@ def closed_loop_rate(m, K, W, seed=100):
         st["n"] = W
         run(K)
     el, lo, hi, reps = timed_repeats(block, sync)
-    chosen = picks[W:W + K, 0].cpu().numpy()
+    if persistent and int(eng.loop_error[0]) != 0:
+        raise RuntimeError("ssa_env_closed_loop_f64 gave up on a timeout")
+    chosen = picks[W + 1:W + K + 1, 0].cpu().numpy()
     return {"value": round(K / el * (m / 20000.0), 2), "ms_per_step": round(1e3 * el / K, 5), **spread(K, m / 20000.0, el, lo, hi, reps),
-            "agent": "agent_visible_greedy (device)", "distinct_objects_selected": int(len(set(chosen.tolist()))), "failed_filters": int((eng.status != 0).sum().item()),
-            "note": "closed loop on the device: step launch + ssa_agent_select_f64 (2 launches) per step, no host round trip"}
+            "agent": "agent_visible_greedy (device)", "distinct_objects_selected": int(len(set(chosen.tolist()))),
+            "failed_filters": int((eng.status != 0).sum().item()),
+            "note": ("closed loop in ONE persistent launch per %d steps (ssa_env_closed_loop_f64): state resident in LDS, the decision made "
+                     "between the wavefronts while the next predicts run; no host round trip" % chunk) if persistent else
+                    "closed loop on the device: step launch + ssa_agent_select_f64 (2 launches) per step, no host round trip"}
 
 
 def gym_api_rate(m, mode, n=200):
@@ -569,7 +597,8 @@ def main():
             legs["j2"].update(note="EXTENSION without reference counterpart (SURVEY section 0): two-body + J2, RK4, 4 sub-steps")
         legs["resample"].update(note="predict() redraws the sigma points from the prior (SSA_FLAG_RESAMPLE); `value` keeps the "
                                      "propagated points; which of the two the reference's unpinned filterpy does is unverifiable offline")
-        legs["closed_loop"] = closed_loop_rate(m, Kl, Wl)
+        legs["closed_loop"] = closed_loop_rate(m, max(Kl, 480), Wl)
+        legs["closed_loop_per_step_launches"] = closed_loop_rate(m, Kl, Wl, persistent=False)
         legs["gym_api"] = {"flatten": gym_api_rate(m, 'flatten'), "aer": gym_api_rate(m, 'aer'),
                            "note": "SSA_Tasker_Env.step() per call, host in the loop, PCIe + one sync inclusive (20 000 objects)"}
         if m == 20000:

@@ -37,6 +37,8 @@ extern "C" {
 #define SSA_OK 0
 #define SSA_E_INVALID (-1) /* bad size / null pointer / unknown flag */
 #define SSA_E_LAUNCH (-2)  /* hipGetLastError() != hipSuccess after launch */
+#define SSA_E_UNSUPPORTED (-3) /* valid arguments, but this entry point does not cover the configuration (the caller takes the
+                                  general one: e.g. ssa_env_closed_loop_f64 with more objects than wavefronts resident at once) */
 
 /* per-object filter status (int32), persists across steps.
  * ssa_tasker_simple_2.py:271-285, 300-313, 369-382 (filter_error): a failed filter is
@@ -312,6 +314,43 @@ int ssa_nis_f64(const double *y, const double *S, double *nis, int64_t n, void *
  * lo < v[k] < hi (lo, hi = stats.chi2.ppf([alpha/2, 1 - alpha/2], df), computed by the caller), counts[1] = number of non-NaN
  * v[k] (the reference drops NaN NIS values before the mean and keeps NaN NEES values in it).  counts: device int64[2]. */
 int ssa_chi2_contained_f64(const double *v, int64_t n, double lo, double hi, int64_t *counts, void *stream);
+
+/* ---------------------------------------------------------------- closed loop: K steps AND their K decisions in one launch
+ * The loop `a = agent(obs, env); obs, r, done, _ = env.step(a)` of the reference's drivers (run_environment.py:26-29,
+ * compare_agents.py:41-42) for one of its greedy agents (agents.py:7-81, SSA_AGENT_*): what K x [ssa_env_step_f64 +
+ * ssa_agent_select_f64] enqueue, with bit-identical states and identical actions, but as ONE persistent launch -- every
+ * wavefront keeps its objects in LDS across the steps (as ssa_env_rollout_f64), and the wavefronts agree on the next action
+ * among themselves through agent-scope atomics while the next step's predicts (which do not depend on it) already run.
+ * One env; every wavefront must be resident at once -- one per four objects plus one service wavefront per 64 of those plus
+ * one (they fold the wavefronts' scores into the decision): n_obj <= 20 160 on MI355X; SSA_E_UNSUPPORTED otherwise -- use the
+ * per-step calls.  `first` as for ssa_env_rollout_f64.
+ *   actions[0]   in : the action of the first step (e.g. from ssa_agent_select_f64 on the state the launch starts from)
+ *   actions[k]   out: the agent's choice for step k (0-based), k = 1 .. K  (actions[K]: the decision after the last step)
+ *   fallback[k]     : used for actions[k] when no object qualifies at that decision (the reference samples at random,
+ *                     agents.py:40-42: the caller supplies the draws); NULL -> -1 (no update)
+ *   stats_out[k]    : [SSA_STAT_STRIDE] reward statistics of step k (arg-max sigma_pos not computed: -1 / NaN, as with stat_shards)
+ *   upd_out[k]      : [SSA_UPD_STRIDE] update record of step k, or NULL
+ *   picks[k]        : optional [K+1][2] int64: arg-max (-1 = fallback used) and the winning score's bits of decision k >= 1
+ *   error           : optional device-visible int32, set to 1 if a wavefront waited 2 s for a decision and the launch gave up
+ *                     (every wait is bounded; outputs are then incomplete)
+ * The rings hold the last `history` steps as after K per-step calls. */
+typedef struct ssa_closed_loop_params {
+    int32_t n_steps;           /* K >= 1 */
+    int32_t history;           /* H >= 2 */
+    int32_t slot_out;          /* step k reads slot (slot_out + k - 1) mod H, writes slot (slot_out + k) mod H */
+    int32_t agent;             /* SSA_AGENT_* */
+    double *x_true_ring, *x_ring, *P_ring, *obs_ring, *metrics_ring;   /* as ssa_rollout_params */
+    double *upd_out;           /* [K][SSA_UPD_STRIDE] or NULL */
+    double *stats_out;         /* [K][SSA_STAT_STRIDE] */
+    int32_t *actions;          /* [K + 1] */
+    const int32_t *fallback;   /* [K + 1] or NULL */
+    int64_t *picks;            /* [K + 1][2] or NULL */
+    int32_t *error;            /* or NULL */
+    void *workspace;           /* ssa_closed_loop_workspace_bytes() bytes of device memory (contents irrelevant) */
+    int64_t workspace_bytes;
+} ssa_closed_loop_params;
+int ssa_env_closed_loop_f64(const ssa_consts *c_host, const ssa_step_params *first, const ssa_closed_loop_params *r, void *stream);
+int64_t ssa_closed_loop_workspace_bytes(int64_t n_obj, int32_t n_env);
 
 /* library identification */
 int ssa_abi_version(void);

@@ -45,7 +45,17 @@ class ssa_rollout_params(C.Structure):
     ]
 
 
+class ssa_closed_loop_params(C.Structure):
+    _fields_ = [
+        ("n_steps", C.c_int32), ("history", C.c_int32), ("slot_out", C.c_int32), ("agent", C.c_int32),
+        ("x_true_ring", c_dp), ("x_ring", c_dp), ("P_ring", c_dp), ("obs_ring", c_dp), ("metrics_ring", c_dp),
+        ("upd_out", c_dp), ("stats_out", c_dp), ("actions", c_dp), ("fallback", c_dp), ("picks", c_dp), ("error", c_dp),
+        ("workspace", c_dp), ("workspace_bytes", C.c_int64),
+    ]
+
+
 # constants of include/ssa_hip.h
+E_INVALID, E_LAUNCH, E_UNSUPPORTED = -1, -2, -3
 ABI_VERSION = 16
 ST_OK, ST_PREDICT_NAN, ST_PREDICT_LINALG, ST_UPDATE_NAN, ST_UPDATE_LINALG = range(5)
 OBS_AER, OBS_XYZ = 0, 1
@@ -69,6 +79,8 @@ SIGNATURES = {
     "ssa_env_step_profile_ms": (C.c_int, [C.c_int32, C.POINTER(C.c_float)]),
     "ssa_stats_fold_f64": (C.c_int, [c_dp, c_dp, C.c_int32, c_dp]),
     "ssa_env_rollout_f64": (C.c_int, [C.POINTER(ssa_consts), C.POINTER(ssa_step_params), C.POINTER(ssa_rollout_params), c_dp]),
+    "ssa_env_closed_loop_f64": (C.c_int, [C.POINTER(ssa_consts), C.POINTER(ssa_step_params), C.POINTER(ssa_closed_loop_params), c_dp]),
+    "ssa_closed_loop_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
     "ssa_env_step_work_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
     "ssa_reward_stats_f64": (C.c_int, [c_dp, c_dp, c_dp, c_dp, C.c_int64, C.c_int32, c_dp]),
     "ssa_reward_stats_workspace_bytes": (C.c_int64, [C.c_int32]),

@@ -784,6 +784,9 @@ SSA_DEV void aer_obs_tile(const Tiles& t, const ssa_step_params& p, const ssa_co
     else aer_obs_tile_at(t, p, C, g, l, obj, p.env_time[0] + p.time_offset);
 }
 
+#ifdef SSA_CL_TRACE   // diagnostic build only (build_ablate/closed_loop_timeline.py): closed_loop_kernel, steps SSA_CL_TRACE and + 1
+__device__ unsigned long long g_cl_trace[8192 * 16];
+#endif
 #ifdef SSA_TRACE   // diagnostic build only (build_ablate/wave_timeline.py): per-wave phase timestamps, 100 MHz wall clock
 __device__ unsigned long long g_trace[16384 * 16];
 #define SSA_TR(k) do { if (lane == 0 && tile < 16384) g_trace[tile * 16 + (k)] = wall_clock64(); } while (0)
@@ -798,9 +801,103 @@ __device__ unsigned long long g_trace[16384 * 16];
 // only by the lanes that need them.
 // TILE: 0 = the tile is loaded here; 1 = it was prefetched (commit now, request the next one after the
 // Kepler stage); 2 = the tiles already hold the state (a rollout's later steps)
-template <int PROP, int TILE>
+// Where a wavefront learns its env's action.  ActEarly: the action word is in memory when the step starts (per-step launches,
+// rollouts).  ActLate (closed_loop_kernel, one env): the action of step k is decided ON THE DEVICE from the state step k - 1
+// left, while the predicts of step k are already running -- a wavefront asks for it only where the update needs it, behind
+// its predict, and every row prefetches the update's inputs for its OWN object in case it turns out to be the selected one.
+struct ActEarly {
+    static constexpr bool late = false;
+    SSA_DEV int get() { return -1; }
+    SSA_DEV void before_wait(Tiles&, int, int) {}
+    SSA_DEV void mid_step(Tiles&, int) {}
+};
+struct ActLate;
+struct LoopK;
+SSA_DEV void closed_loop_prescore(ActLate& a, Tiles& t, int lane, int cnt);   // (defined with the closed-loop kernel)
+SSA_DEV void closed_loop_store(const LoopK* lk, Tiles& t, int lane, int kk, int64_t base, int cnt);
+constexpr unsigned CL_ABORT_GEN = 0xFFFFFFFFu;            // decision number that means "give up" (a wavefront timed out)
+constexpr unsigned long long CL_TIMEOUT_TICKS = 200000000ull;   // 2 s of the 100 MHz wall clock without the awaited decision
+struct ActLate {
+    static constexpr bool late = true;
+    unsigned long long* flag;        // this wavefront's group flag: (decision number << 32) | action
+    unsigned long long* all_flags;   // [nflags] flags, 16 words apart (abort broadcast)
+    int* err;                        // device word set to 1 on a timeout (may be host-mapped)
+    int nflags;
+    unsigned want;                   // decision needed: the step's index (>= 1); 0 = `first`
+    int first;                       // action of the launch's first step (decided by the caller)
+    int last;                        // the action get() returned most recently
+    bool aborted;
+#ifdef SSA_CL_TRACE
+    unsigned long long t_wait, t_seen;
+#endif
+    int agent;                       // SSA_AGENT_*
+    const ssa_consts* C;             // (kernarg copy)
+    const double* M;                 // GCRS -> ITRS matrix of the current step
+    int* vis;                        // [OBJ_PER_WAVE] in LDS: visibility of the tile's objects at the current step
+    // work that does not depend on the decision, done where a wavefront would otherwise only wait for it: the visibility of its
+    // objects' NEW true states (the agents' mask, agents.py:36-42) -- off the path decision -> update -> score -> decision
+    SSA_DEV void before_wait(Tiles& t, int lane, int cnt) { closed_loop_prescore(*this, t, lane, cnt); }
+    // The outputs of step k leave for HBM inside step k + 1, behind its Cholesky stage (the tile is intact until then): right
+    // after the decision every wavefront is released at once, and 18 MB of tile stores issued at that moment delayed the
+    // acknowledgements of the parts the NEXT decision waits for (late announcers: +3 us, build_ablate/closed_loop_timeline.py);
+    // here they overlap the Kepler stage instead.
+    const LoopK* lk;                 // the kernel's argument block
+    int pend;                        // step whose tile is still to be stored (-1: none)
+    int64_t base;
+    int cnt;
+    SSA_DEV void mid_step(Tiles& t, int lane)
+    {
+        if (pend < 0) return;
+        closed_loop_store(lk, t, lane, pend, base, cnt);
+        pend = -1;
+    }
+    SSA_DEV void abort_all()
+    {
+        const int lane = threadIdx.x;
+        for (int i = lane; i < nflags; i += 64)
+            __hip_atomic_store(all_flags + (int64_t)i * 16, (unsigned long long)CL_ABORT_GEN << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0 && err) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // the decision `want`: polls the group flag (agent-scope loads: coherent across the XCDs' L2s) with a bounded wait -- every
+    // wavefront reaches an exit whatever the others do
+    SSA_DEV int get()
+    {
+        if (want == 0u) { last = first; return first; }
+#ifdef SSA_CL_NOWAIT   // diagnostic (build_ablate/closed_loop_variants.py): no wait for the decision -- what the exchange's latency costs
+        return first;
+#endif
+        const unsigned long long t0 = wall_clock64();
+#ifdef SSA_CL_TRACE
+        t_wait = t0;
+#endif
+        unsigned lo, hi;
+        for (;;) {
+            const unsigned long long v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+            hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+            if (hi >= want) break;
+            if (wall_clock64() - t0 > CL_TIMEOUT_TICKS) {
+                abort_all();
+                hi = CL_ABORT_GEN;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (hi == CL_ABORT_GEN) {
+            aborted = true;
+            return -2;
+        }
+#ifdef SSA_CL_TRACE
+        t_seen = wall_clock64();
+#endif
+        last = (int)lo;
+        return (int)lo;
+    }
+};
+
+template <int PROP, int TILE, class ACT>
 SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& p, int lane, int64_t obj_in, bool valid,
-                          int64_t base, int cnt, TileRegs& pf, int64_t next_base, int next_cnt, int tile)
+                          int64_t base, int cnt, TileRegs& pf, int64_t next_base, int next_cnt, int tile, ACT& asrc)
 {
     int g = lane >> 4, l = lane & 15;
     int64_t obj = obj_in;
@@ -822,7 +919,10 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     // the action / time index of this object's env, fetched early (used after the transform)
     // (one env: wave-uniform scalar loads; per-lane loads with their 64-bit address arithmetic only for vectorised envs)
     int act, tix;
-    if (p.n_env > 1) {
+    if (ACT::late) {   // (one env; the action arrives behind the predict)
+        act = -1;
+        tix = valid ? p.env_time[0] + p.time_offset : 0;
+    } else if (p.n_env > 1) {
         act = valid ? p.actions[e] : -1;
         tix = valid ? p.env_time[e] + p.time_offset : 0;
     } else {
@@ -834,16 +934,19 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     // wavefront is the longest-living one of the launch, so its inputs (this step's GCRS->ITRS matrix, the measurement noise)
     // leave HBM now and wait in LDS, instead of costing two memory round trips when the update starts
     const bool interval_ok = (C.update_interval <= 1) || (tix % C.update_interval == 0);
-    const bool my_update = valid && act >= 0 && (int64_t)act == j && interval_ok;
+    bool my_update = !ACT::late && valid && act >= 0 && (int64_t)act == j && interval_ok;
+    // (ActLate: every row prefetches for its own object)
+    const bool may_update = ACT::late ? (valid && interval_ok) : my_update;
     // ... and it issues ahead of its SIMD's other wavefronts from here on: at equal priority its predict runs at a fifth of the
     // SIMD and the update then starts when everybody else is finishing (the kernel's tail)
-    if (__any(my_update)) __builtin_amdgcn_s_setprio(3);
+    if (!ACT::late && __any(my_update)) __builtin_amdgcn_s_setprio(3);
     int tmod = 0;                                           // row of `trans` / `z_noise` (episodes wrap)
     double upd_in = 0.0;
-    if (my_update && l < 12) {
+    if (may_update && l < 12) {
         tmod = time_row(tix, p.n_time);
+        const int64_t aobj = ACT::late ? j : (int64_t)act;
         const double* src = (l < 9) ? p.trans + (int64_t)tmod * 9 + l
-                                    : p.z_noise + (int64_t)e * p.zn_stride_env + (int64_t)tmod * p.zn_stride_time + (int64_t)act * p.zn_stride_obj + (l - 9);
+                                    : p.z_noise + (int64_t)e * p.zn_stride_env + (int64_t)tmod * p.zn_stride_time + aobj * p.zn_stride_obj + (l - 9);
         upd_in = *src;
     }
     SSA_TR(0);
@@ -871,7 +974,8 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
 #else
     const int rung = robust_chol_row_lds(t, C.scale, g, l);
 #endif
-    if (my_update && l < 12) t.Obs[g * 12 + l] = upd_in;
+    asrc.mid_step(t, lane);   // (closed loop: the PREVIOUS step's tile leaves for HBM now, its last reader of t.Obs)
+    if (may_update && l < 12) t.Obs[g * 12 + l] = upd_in;
     wave_lds_sync();
     SSA_TR(2);
     const bool chol_fail = (rung == 16);
@@ -1010,6 +1114,12 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     // residuals; the rows [sigma - x | rz] go to the row's staging matrix.  Phase 2 (whole wavefront, below): the two
     // weighted moment matrices on the matrix unit (the weights enter with the right operand), inverse, gain, state and
     // covariance over all 64 lanes.
+    if (ACT::late) {   // the closed loop's decision for this step: needed from here on, and normally made long ago
+        asrc.before_wait(t, lane, cnt);
+        act = asrc.get();
+        my_update = valid && act >= 0 && (int64_t)act == obj && interval_ok;   // (one env: the object index IS the index in the env)
+        if (__any(my_update)) __builtin_amdgcn_s_setprio(3);
+    }
     if (__any(my_update)) {   // whole-wave branch: a wavefront without a selected object skips the block, its variables included
     bool upd_go = false, taken = false, visible = false, attempted = false;
     double z[3] = {0.0, 0.0, 0.0}, y_row[3] = {0.0, 0.0, 0.0};   // (y_row: lane 13 of the row keeps the innovation)
@@ -1211,7 +1321,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     if (my_update && rec && l == 0) {
         rec[SSA_UPD_OBS_TAKEN] = taken ? 1.0 : 0.0;
         rec[SSA_UPD_VISIBLE] = visible ? 1.0 : 0.0;
-        rec[SSA_UPD_ACTION] = attempted ? (double)p.actions[e] : -1.0;   // (my_update: the env's action IS this object)
+        rec[SSA_UPD_ACTION] = attempted ? (double)(ACT::late ? act : p.actions[e]) : -1.0;   // (my_update: the env's action IS this object)
     }
     // The update is the register-pressure peak behind the propagator and only ONE wavefront of a launch runs it: whatever is
     // live across it would be spilled by EVERY wavefront.  So the values that are cheap to get again are got again behind
@@ -1225,7 +1335,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     }   // wavefronts holding a selected object
     // envs whose action selects nobody still get a cleared record (written by object 0's row)
     if (valid && p.upd && obj == (int64_t)e * p.n_obj && l == 0) {   // (object 0 of an env: one lane per env)
-      const int a_env = p.actions[e];
+      const int a_env = ACT::late ? act : p.actions[e];
       if (!(a_env >= 0 && interval_ok && (int64_t)a_env < p.n_obj)) {
         double* rec = p.upd + (int64_t)e * SSA_UPD_STRIDE;
         rec[SSA_UPD_OBS_TAKEN] = 0.0;
@@ -1245,6 +1355,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         if (l < 6) t.X[g * 6 + l] = (l < 3) ? X_FAILED_POS : X_FAILED_VEL;
     }
     if (valid && st_in != SSA_ST_OK) {  // already failed: the filter state passes through unchanged (:272)
+        if (ACT::late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (its previous state left for HBM earlier in THIS step)
         for (int idx = l; idx < 36; idx += 16) t.P[g * 36 + idx] = p.P_in[obj * 36 + idx];
         if (l < 6) t.X[g * 6 + l] = p.x_in[obj * 6 + l];
     }
@@ -1261,7 +1372,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     }
     wave_lds_sync();
     SSA_TR(7);
-    {
+    if (!ACT::late) {   // (closed_loop_kernel stores the tile itself, AFTER it has announced its part of the decision)
 #if !(defined(SSA_ABLATE) && (SSA_ABLATE & 32))
         store_tile<TILE != 1>(t, p, lane, base, cnt);
         SSA_TR(8);
@@ -1413,7 +1524,8 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(int ntile
         const int64_t base = (int64_t)tile * OBJ_PER_WAVE;
         const int cnt = (int)((total - base) < OBJ_PER_WAVE ? (total - base) : OBJ_PER_WAVE);
         tile_issue_from(pf, pre_P_in, pre_x_in, pre_x_true_in, pre_status, lane, base, cnt);
-        process_wave<PROP, 0>(t, k_arg.c, k_arg.p, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, pf, 0, 0, tile);
+        ActEarly early;
+        process_wave<PROP, 0>(t, k_arg.c, k_arg.p, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, pf, 0, 0, tile, early);
         return;
     }
     {
@@ -1441,7 +1553,8 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(int ntile
         const int nt = tile + nwork;
         const int64_t nbase = (int64_t)nt * OBJ_PER_WAVE;
         const int ncnt = nt < ntiles ? (int)((total - nbase) < OBJ_PER_WAVE ? (total - nbase) : OBJ_PER_WAVE) : 0;
-        process_wave<PROP, 1>(t, k.c, k.p, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, pf, nbase, ncnt, tile);
+        ActEarly early;
+        process_wave<PROP, 1>(t, k.c, k.p, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, pf, nbase, ncnt, tile, early);
         wave_lds_sync();   // the tile's LDS reads (store) precede the next tile's commit
     }
 }
@@ -1515,7 +1628,8 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) rollout_kernel(const RollK
             pk.actions = r.actions + (int64_t)kk * E;
             pk.stat_shards = r.stat_shards + (int64_t)kk * E * SSA_STAT_SHARDS * SSA_STAT_SHARD_WORDS;
             pk.aer_out = nullptr;
-            process_wave<PROP, 2>(t, k.c, pk, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, pf, 0, 0, tile);
+            ActEarly early;
+            process_wave<PROP, 2>(t, k.c, pk, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, pf, 0, 0, tile, early);
             wave_lds_sync();
         }
     }
@@ -1854,17 +1968,26 @@ __global__ void aer_obs_kernel(const double* __restrict__ x, const double* __res
 
 // agents.py score arrays + visibility (one lane per object).  sc[0..3] = trace P | log(det P_cur / det P_prev) | |dpos| | |dvel|;
 // WANT selects what is evaluated (bit k = row k, bit 4 = visibility) -- the two log-determinants are the expensive part.
-template <int WANT>
-SSA_DEV bool agent_score_rows(const double* __restrict__ xt, const double* __restrict__ x, const double* __restrict__ Pc,
-                              const double* __restrict__ Pp, const double* __restrict__ M, const GeoK& g, int64_t i, double* sc)
+// log det through the (plain) Cholesky factor: det > 0 for the covariances the filter keeps; anything else gives NaN, which
+// the arg-max skips
+SSA_DEV double logdet_chol(const double (&A)[21])
 {
-    double A[21], U[21];
-    if (WANT & 3) {
+    double U[21];
+    double ld = __builtin_nan("");
+    if (chol6_upper(A, 0.0, U)) {
+        ld = 0.0;
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = r; c < 6; ++c) A[tri(r, c)] = Pc[i * 36 + r * 6 + c];
+        for (int c = 0; c < 6; ++c) ld += 2.0 * log(U[tri(c, c)]);
     }
+    return ld;
+}
+// the scores from values in registers: xt / x = true and estimated state, A = upper triangle of P_cur, ld_prev = logdet_chol of
+// P_prev (NaN when there is none); *ld_cur (optional) receives logdet_chol(P_cur) -- the closed-loop kernel hands it on as the
+// next step's ld_prev instead of factorising the same matrix twice.  M = GCRS -> ITRS matrix of the step.
+template <int WANT>
+SSA_DEV bool agent_score_core(const double (&xt)[6], const double (&x)[6], const double (&A)[21], double ld_prev,
+                              const double* __restrict__ M, const GeoK& g, double* sc, double* ld_cur)
+{
     if (WANT & 1) {
         double tr = 0.0;
 #pragma unroll
@@ -1872,43 +1995,56 @@ SSA_DEV bool agent_score_rows(const double* __restrict__ xt, const double* __res
         sc[0] = tr;
     }
     if (WANT & 2) {
-        // log det through the (plain) Cholesky factor: det > 0 for the covariances the filter keeps; anything
-        // else gives NaN, which the arg-max skips
-        double ld_c = __builtin_nan(""), ld_p = __builtin_nan("");
-        if (chol6_upper(A, 0.0, U)) {
-            ld_c = 0.0;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) ld_c += 2.0 * log(U[tri(c, c)]);
-        }
-        if (Pp) {
-#pragma unroll
-            for (int r = 0; r < 6; ++r)
-#pragma unroll
-                for (int c = r; c < 6; ++c) A[tri(r, c)] = Pp[i * 36 + r * 6 + c];
-            if (chol6_upper(A, 0.0, U)) {
-                ld_p = 0.0;
-#pragma unroll
-                for (int c = 0; c < 6; ++c) ld_p += 2.0 * log(U[tri(c, c)]);
-            }
-        }
-        sc[1] = ld_c - ld_p;
+        const double ld_c = logdet_chol(A);
+        if (ld_cur) *ld_cur = ld_c;
+        sc[1] = ld_c - ld_prev;
     }
     if (WANT & 12) {
         double d[6];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) d[c] = x[i * 6 + c] - xt[i * 6 + c];
+        for (int c = 0; c < 6; ++c) d[c] = x[c] - xt[c];
         sc[2] = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
         sc[3] = sqrt(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
     }
     bool vis = true;
     if (WANT & 16) {
-        double Mm[9], xx[3] = {xt[i * 6], xt[i * 6 + 1], xt[i * 6 + 2]}, zz[3];
+        double Mm[9], xx[3] = {xt[0], xt[1], xt[2]}, zz[3];
 #pragma unroll
         for (int c = 0; c < 9; ++c) Mm[c] = M[c];
         hx_aer(xx, Mm, g.enu, g.obs, zz);
         vis = zz[1] >= g.obs_limit;
     }
     return vis;
+}
+template <int WANT>
+SSA_DEV bool agent_score_rows(const double* __restrict__ xt, const double* __restrict__ x, const double* __restrict__ Pc,
+                              const double* __restrict__ Pp, const double* __restrict__ M, const GeoK& g, int64_t i, double* sc)
+{
+    double A[21] = {0.0}, xtv[6] = {0.0}, xv[6] = {0.0};
+    if (WANT & 3) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = r; c < 6; ++c) A[tri(r, c)] = Pc[i * 36 + r * 6 + c];
+    }
+    double ld_p = __builtin_nan("");
+    if ((WANT & 2) && Pp) {
+        double B[21];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = r; c < 6; ++c) B[tri(r, c)] = Pp[i * 36 + r * 6 + c];
+        ld_p = logdet_chol(B);
+    }
+    if (WANT & 12) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) xv[c] = x[i * 6 + c];
+    }
+    if (WANT & 28) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) xtv[c] = xt[i * 6 + c];
+    }
+    return agent_score_core<WANT>(xtv, xv, A, ld_p, M, g, sc, nullptr);
 }
 __global__ void agent_scores_kernel(const double* __restrict__ xt, const double* __restrict__ x, const double* __restrict__ Pc,
                                     const double* __restrict__ Pp, const double* __restrict__ M, GeoK g,
@@ -1994,6 +2130,442 @@ __global__ void __launch_bounds__(64) agent_final_kernel(const AgentPart* __rest
         action_out[e] = (arg >= 0) ? (int32_t)arg : (fallback ? fallback[e] : -1);
         if (pick_out) { pick_out[2 * e] = arg; pick_out[2 * e + 1] = __double_as_longlong(best); }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Closed loop in ONE launch (the reference's `a = agent(obs, env); obs, r, done, _ = env.step(a)` of
+// run_environment.py:26-29 for its greedy agents, agents.py:7-81).  As in rollout_kernel a wavefront keeps its four objects'
+// state in LDS across the K steps and writes every step's outputs to that step's ring slot; in addition the NEXT step's
+// action is decided inside the launch:
+//   * after step k every compute wavefront scores its objects (agent_score_core: the arithmetic of ssa_agent_select_f64, so
+//     the choices are identical to the multi-launch loop's), merges them with its share of the step's reward statistics into
+//     one 32-byte part, stores it and bumps its GROUP's arrival counter (64 wavefronts per group) -- and goes on with step
+//     k + 1's predicts, which do not depend on the action;
+//   * one SERVICE wavefront per group (extra workgroups of the same launch, no objects of their own) polls that counter, folds
+//     the group's 64 parts and bumps the launch's counter; one more service wavefront polls that one, folds the groups, writes
+//     the action (or the caller's fallback when nothing qualifies) and the step's statistics, and publishes (decision number,
+//     action) in every group's flag word;
+//   * a compute wavefront reads its group's flag only where the update needs it (ActLate), so the decision's latency hides
+//     behind the predict.
+// (First version: the last wavefront to arrive did the folding.  The wavefront that runs the update arrives last, lost three
+// more microseconds folding while the others were already in their next predict, so it was the last to arrive at the NEXT
+// step too -- every step waited for one wavefront's predict + update + folds in series: 14.4 us per step against 10.2 without
+// the wait, build_ablate/closed_loop_timeline.py.  Folders without objects cannot fall behind.)
+// No compute wavefront can be two steps ahead (the update of step k + 1 needs every part of step k), hence two sets of parts,
+// indexed by the step's parity, suffice; the counters only ever grow.  All words that cross wavefronts are agent-scope atomics
+// (coherent across the XCDs' L2s); a store is ordered before the atomic that announces it by waiting for its
+// acknowledgement (s_waitcnt vmcnt(0)).  Every wait is bounded: a wavefront that times out publishes the abort generation in
+// every flag and all wavefronts leave -- the grid drains whatever happens.  Needs every wavefront resident at once (one tile
+// per compute wavefront + the service wavefronts): the launcher checks that against the occupancy the runtime reports and
+// refuses otherwise.
+struct ClPart { double best; long long arg; unsigned long long mx, cnt; };   // cnt: [< 1e4] | [< 1e7] << 21 | [failed] << 42
+SSA_DEV void cl_merge(ClPart& a, const ClPart& b)
+{
+    agent_merge(a.best, a.arg, b.best, b.arg);
+    a.mx = b.mx > a.mx ? b.mx : a.mx;
+    a.cnt += b.cnt;
+}
+SSA_DEV ClPart cl_identity()
+{
+    ClPart r;
+    r.best = 0.0; r.arg = -1; r.mx = 0ull; r.cnt = 0ull;
+    return r;
+}
+SSA_DEV ClPart cl_load(const unsigned long long* w)
+{
+    ClPart r;
+    r.best = __longlong_as_double((long long)__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    r.arg = (long long)__hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r.mx = __hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r.cnt = __hip_atomic_load(w + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return r;
+}
+SSA_DEV void cl_store(unsigned long long* w, const ClPart& v)
+{
+    __hip_atomic_store(w, (unsigned long long)__double_as_longlong(v.best), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(w + 1, (unsigned long long)v.arg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(w + 2, v.mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(w + 3, v.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Fold over the 64 lanes, result wave-uniform.  Four DPP rotations leave every row's fold in all of its lanes, four readlanes
+// combine the rows (the ds_bpermute shuffle tree this replaces took ~1.5 us per fold: 48 dependent LDS-crossbar round trips).
+// The agent's "first maximum" (highest score, lowest index among equals, agent_merge) becomes two folds of integers: the
+// score as an order-preserving 64-bit key (0 = no candidate), then the lowest index among the lanes that hold the maximum.
+template <int CTRL>
+SSA_DEV unsigned long long dpp_u64(unsigned long long v)
+{
+    return (unsigned long long)__builtin_amdgcn_update_dpp((long long)v, (long long)v, CTRL, 0xF, 0xF, true);
+}
+SSA_DEV unsigned long long lane_u64(unsigned long long v, int l)
+{
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)v, l);
+}
+struct OpMax { SSA_DEV unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a > b ? a : b; } };
+struct OpMin { SSA_DEV unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a < b ? a : b; } };
+struct OpAdd { SSA_DEV unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a + b; } };
+template <class OP>
+SSA_DEV unsigned long long wave_fold_u64(unsigned long long v, OP op)
+{
+    v = op(v, dpp_u64<0x128>(v));   // row_ror:8
+    v = op(v, dpp_u64<0x124>(v));   // row_ror:4
+    v = op(v, dpp_u64<0x122>(v));   // row_ror:2
+    v = op(v, dpp_u64<0x121>(v));   // row_ror:1
+    return op(op(lane_u64(v, 0), lane_u64(v, 16)), op(lane_u64(v, 32), lane_u64(v, 48)));
+}
+SSA_DEV unsigned long long score_key(double v)   // order-preserving; > 0 for every non-NaN double (-0 ranks as +0)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v + 0.0);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+SSA_DEV double score_of_key(unsigned long long k)
+{
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+}
+SSA_DEV ClPart cl_wave_reduce(const ClPart& a)
+{
+    const unsigned long long key = a.arg >= 0 ? score_key(a.best) : 0ull;
+    const unsigned long long top = wave_fold_u64(key, OpMax());
+    const unsigned long long cand = (a.arg >= 0 && key == top) ? (unsigned long long)a.arg : ~0ull;
+    const unsigned long long who = wave_fold_u64(cand, OpMin());
+    ClPart r;
+    r.arg = top ? (long long)who : -1;
+    r.best = top ? score_of_key(top) : 0.0;
+    r.mx = wave_fold_u64(a.mx, OpMax());
+    r.cnt = wave_fold_u64(a.cnt, OpAdd());
+    return r;
+}
+// own stores acknowledged (visible at agent scope) before what follows
+SSA_DEV void cl_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// workspace layout in 8-byte words (ng = groups of 64 compute wavefronts); everything before `parts` must be zero at launch
+struct ClLayout {
+    int64_t flags, gcount, fcount, parts, gparts, cparts, total;
+    int ng;
+};
+static __host__ __device__ inline ClLayout cl_layout(int nwork)
+{
+    ClLayout L;
+    L.ng = (nwork + 63) / 64;
+    L.flags = 0;                                   // [ng] x 16 words: one 128-byte line per group
+    L.gcount = (int64_t)L.ng * 16;                 // [ng] x 16: arrivals so far (all steps)
+    L.fcount = L.gcount + (int64_t)L.ng * 16;      // x 16: folded groups so far (all steps)
+    L.parts = L.fcount + 16;                       // [2][nwork] x 4
+    L.gparts = L.parts + (int64_t)8 * nwork;       // [2][ng] x 4
+    L.cparts = L.gparts + (int64_t)8 * L.ng;       // [2] x 4: the part of the wavefront that ran the update (straight to the decision)
+    L.total = L.cparts + 8;
+    return L;
+}
+
+SSA_DEV void closed_loop_prescore(ActLate& a, Tiles& t, int lane, int cnt)
+{
+    if (a.agent == SSA_AGENT_NAIVE_GREEDY) return;       // (no visibility mask: agents.py:7)
+    const int g = lane >> 4, l = lane & 15;
+    if (l == 0 && g < cnt) {
+        GeoK geo;
+        for (int i = 0; i < 9; ++i) geo.enu[i] = a.C->enu[i];
+        for (int i = 0; i < 3; ++i) geo.obs[i] = a.C->obs_itrs[i];
+        geo.obs_limit = a.C->obs_limit; geo.Wi = a.C->Wi; geo.sum_wm_m1 = a.C->sum_wm_m1;
+        double xt[6], x[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, A[21] = {0.0}, sc[4];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) xt[c] = t.T[g * 6 + c];
+        a.vis[g] = agent_score_core<16>(xt, x, A, 0.0, a.M, geo, sc, nullptr) ? 1 : 0;
+    }
+}
+
+// The wavefront that runs the update of a step announces its part last (the update is three microseconds the others do not
+// have): it hands it to the deciding wavefront DIRECTLY instead of through its group's fold -- one exchange level less on the
+// path decision -> update -> decision.  Who that is follows from the action alone, so everybody agrees on it: the tile of the
+// selected object, or tile 0 when the action selects nobody.
+SSA_DEV int closer_tile(int act, int64_t total) { return (act >= 0 && (int64_t)act < total) ? (act >> 2) : 0; }
+SSA_DEV int block_of_tile(int tile, int n)   // inverse of xcd_tile()
+{
+    const int q = n >> 3, r = n & 7;
+    int x = 0;
+#pragma unroll
+    for (int c = 1; c < 8; ++c)
+        if (tile >= c * q + (c < r ? c : r)) x = c;
+    return (tile - (x * q + (x < r ? x : r))) * 8 + x;
+}
+// bounded wait of a service wavefront: until *counter >= target (returns true), or the launch was abandoned / the wait timed
+// out (false; on a timeout the abort generation has been published)
+SSA_DEV bool cl_service_wait(const unsigned long long* counter, unsigned long long target, ActLate& ab)
+{
+    // polling at the LOWEST issue priority: the service wavefronts share their SIMDs with compute wavefronts, and a top-priority
+    // polling loop took a third of those SIMDs' issue slots (the compute wavefronts next to them finished microseconds late and
+    // everybody waited for them); top priority only for the fold that follows
+    __builtin_amdgcn_s_setprio(0);
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        const unsigned long long v = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane_u64(v, 0) >= target) {
+            __builtin_amdgcn_s_setprio(3);
+            return true;
+        }
+        const unsigned long long f = __hip_atomic_load(ab.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(lane_u64(f, 0) >> 32) == CL_ABORT_GEN) return false;
+        if (wall_clock64() - t0 > CL_TIMEOUT_TICKS) {
+            ab.abort_all();
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+struct LoopK {   // ONE kernel argument (see RollK)
+    StepK k;
+    ssa_closed_loop_params c;
+};
+SSA_DEV void closed_loop_store(const LoopK* lk, Tiles& t, int lane, int kk, int64_t base, int cnt)
+{
+    const ssa_closed_loop_params& r = lk->c;
+    const int64_t total = lk->k.p.n_obj;
+    const int so = (r.slot_out + kk) % r.history;
+    ssa_step_params q = lk->k.p;
+    q.x_true_out = r.x_true_ring + so * total * 6;
+    q.x_out = r.x_ring + so * total * 6;
+    q.P_out = r.P_ring + so * total * 36;
+    q.obs = r.obs_ring + so * total * 12;
+    q.metrics = r.metrics_ring + so * 4 * total;
+    store_tile<true>(t, q, lane, base, cnt);
+}
+template <int PROP>
+__global__ void __launch_bounds__(64, SSA_STEP_WAVES) closed_loop_kernel(const LoopK a, int ntiles, int nwork)
+{
+    const StepK& k_arg = a.k;
+    __shared__ Tiles t;
+    __shared__ double ld_prev[OBJ_PER_WAVE];   // agent_shannon: log det of each object's covariance one step ago
+    __shared__ ClPart rowpart[OBJ_PER_WAVE];
+    __shared__ int vis_row[OBJ_PER_WAVE];
+    int lane = threadIdx.x;
+    const int64_t total = k_arg.p.n_obj;       // (one env)
+    const int H = a.c.history, K = a.c.n_steps;
+    const int w = (int)blockIdx.x;
+    const ClLayout L = cl_layout(nwork);
+    unsigned long long* const ws = (unsigned long long*)a.c.workspace;
+    ActLate asrc;
+    asrc.all_flags = ws + L.flags;
+    asrc.err = a.c.error;
+    asrc.nflags = L.ng;
+    asrc.aborted = false;
+    asrc.last = -1;
+    asrc.agent = a.c.agent;
+    asrc.vis = vis_row;
+
+    // ---------------- service wavefronts: w in [nwork, nwork + ng) fold one group each, w == nwork + ng decides
+    if (w >= nwork) {
+        __builtin_amdgcn_s_setprio(3);
+        const int G = w - nwork;
+        if (G < L.ng) {
+            const int gsize = (nwork - G * 64) < 64 ? (nwork - G * 64) : 64;
+            asrc.flag = ws + L.flags + (int64_t)G * 16;
+            asrc.first = a.c.actions[0];
+            unsigned long long target = 0ull;   // arrivals of this group so far, all steps
+            for (int kk = 0; kk < K; ++kk) {
+                asrc.want = (unsigned)kk;       // this step's action says whose part bypasses the groups
+                __builtin_amdgcn_s_setprio(0);
+                const int act = asrc.get();
+                if (asrc.aborted) return;
+                const int cw = block_of_tile(closer_tile(act, total), nwork);
+                target += (unsigned long long)(gsize - ((cw >> 6) == G ? 1 : 0));
+                if (!cl_service_wait(ws + L.gcount + (int64_t)G * 16, target, asrc)) return;
+                const int q = kk & 1;
+                ClPart me = cl_identity();
+                if (lane < gsize && G * 64 + lane != cw) me = cl_load(ws + L.parts + ((int64_t)q * nwork + (int64_t)G * 64 + lane) * 4);
+                const ClPart red = cl_wave_reduce(me);
+                if (lane == 0) {
+                    cl_store(ws + L.gparts + ((int64_t)q * L.ng + G) * 4, red);
+                    cl_stores_done();
+                    __hip_atomic_fetch_add(ws + L.fcount, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            return;
+        }
+        asrc.flag = ws + L.flags;
+        for (int kk = 0; kk < K; ++kk) {
+            if (!cl_service_wait(ws + L.fcount, (unsigned long long)(kk + 1) * (unsigned long long)(L.ng + 1), asrc)) return;
+            const int q = kk & 1;
+            ClPart f = cl_identity();
+            if (lane == 63) f = cl_load(ws + L.cparts + (int64_t)q * 4);    // the update's wavefront
+            for (int i0 = 0; i0 < L.ng; i0 += 128) {     // (two loads in flight per lane: 128 groups = 32 768 objects per round)
+                ClPart b0 = cl_identity(), b1 = cl_identity();
+                if (i0 + lane < L.ng) b0 = cl_load(ws + L.gparts + ((int64_t)q * L.ng + i0 + lane) * 4);
+                if (i0 + lane + 64 < L.ng) b1 = cl_load(ws + L.gparts + ((int64_t)q * L.ng + i0 + lane + 64) * 4);
+                cl_merge(f, b0);
+                cl_merge(f, b1);
+            }
+            f = cl_wave_reduce(f);
+            const ssa_closed_loop_params& r = a.c;
+            const int action = (f.arg >= 0) ? (int)f.arg : (r.fallback ? r.fallback[kk + 1] : -1);   // (wave-uniform)
+            const unsigned long long word = ((unsigned long long)(unsigned)(kk + 1) << 32) | (unsigned long long)(unsigned)action;
+            for (int i = lane; i < L.ng; i += 64)
+                __hip_atomic_store(ws + L.flags + (int64_t)i * 16, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) {   // (for the host: nobody in the launch reads these)
+                r.actions[kk + 1] = action;
+                if (r.picks) { r.picks[2 * (int64_t)(kk + 1)] = f.arg; r.picks[2 * (int64_t)(kk + 1) + 1] = __double_as_longlong(f.best); }
+                double* o = r.stats_out + (int64_t)kk * SSA_STAT_STRIDE;
+                o[SSA_STAT_MAX_DPOS] = __longlong_as_double((long long)f.mx);
+                o[SSA_STAT_CNT_LT_1E4] = (double)(f.cnt & 0x1fffffull);
+                o[SSA_STAT_CNT_LT_1E7] = (double)((f.cnt >> 21) & 0x1fffffull);
+                o[SSA_STAT_ARGMAX_SPOS] = -1.0;
+                o[SSA_STAT_N_FAILED] = (double)(f.cnt >> 42);
+                o[SSA_STAT_MAX_SPOS] = __builtin_nan("");
+                o[6] = 0.0; o[7] = 0.0;
+            }
+        }
+        return;
+    }
+
+    // ---------------- compute wavefronts
+    const int64_t sx = total * 6, sP = total * 36, so_ = total * 12, sm = 4 * k_arg.p.n_obj;
+    const int tile = xcd_tile(w, nwork);
+    const int64_t base = (int64_t)tile * OBJ_PER_WAVE;
+    const int cnt = (int)((total - base) < OBJ_PER_WAVE ? (total - base) : OBJ_PER_WAVE);
+    const int G = w >> 6;
+    asrc.flag = ws + L.flags + (int64_t)G * 16;
+    asrc.first = a.c.actions[0];
+    asrc.pend = -1;
+    asrc.base = base;
+    asrc.cnt = cnt;
+    TileRegs pf;
+    typedef const __attribute__((address_space(4))) LoopK* LoopArgPtr;
+    LoopArgPtr kp = (LoopArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    GeoK geo;
+    {   // the tile's state from the input slot
+        const int si0 = (a.c.slot_out + H - 1) % H;
+        ssa_step_params p0 = k_arg.p;
+        p0.x_true_in = a.c.x_true_ring + si0 * sx;
+        p0.x_in = a.c.x_ring + si0 * sx;
+        p0.P_in = a.c.P_ring + si0 * sP;
+        tile_issue(pf, p0, lane, base, cnt);
+        tile_commit(t, pf, lane);
+        if (lane < 36) t.Q[lane] = k_arg.c.Q[lane];
+        wave_lds_sync();
+        if (a.c.agent == SSA_AGENT_SHANNON && (lane & 15) == 0) {   // log det of the covariances the launch starts from
+            const int g = lane >> 4;
+            double A[21];
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = r; c < 6; ++c) A[tri(r, c)] = t.P[g * 36 + r * 6 + c];
+            ld_prev[g] = logdet_chol(A);
+        }
+        wave_lds_sync();
+    }
+    unsigned wave_slot;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(wave_slot));
+    bool boost = false;   // this wavefront ran the previous step's update: it is behind the others
+    for (int kk = 0; kk < K; ++kk) {
+        // issue priority rotated per step (see rollout_kernel) -- except for the wavefront that ran the update: it lost
+        // microseconds the others spent on the next predict, and if it stays behind it is the last to announce its part of
+        // the NEXT step too, with every wavefront waiting for it.  It catches up at top priority.
+        if (boost) __builtin_amdgcn_s_setprio(3);
+        else switch ((wave_slot + (unsigned)kk) & 3u) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+        asm volatile("" : "+s"(kp));
+        asm volatile("" : "+v"(lane));
+        const StepK& k = ((const LoopK*)kp)->k;
+        const ssa_closed_loop_params& r = ((const LoopK*)kp)->c;
+        const int so = (r.slot_out + kk) % H, si = (so + H - 1) % H;
+        ssa_step_params pk = k.p;
+        pk.time_offset = k.p.time_offset + kk;
+        pk.x_true_in = r.x_true_ring + si * sx;  pk.x_true_out = r.x_true_ring + so * sx;
+        pk.x_in = r.x_ring + si * sx;            pk.x_out = r.x_ring + so * sx;
+        pk.P_in = r.P_ring + si * sP;            pk.P_out = r.P_ring + so * sP;
+        pk.obs = r.obs_ring + so * so_;
+        pk.metrics = r.metrics_ring + so * sm;
+        pk.upd = r.upd_out ? r.upd_out + (int64_t)kk * SSA_UPD_STRIDE : nullptr;
+        pk.actions = r.actions + kk;
+        pk.stat_shards = nullptr;      // the statistics travel with the decision (ClPart)
+        pk.stats = nullptr;
+        pk.aer_out = nullptr;
+        pk.stat_shards_clear = nullptr;
+#ifdef SSA_CL_TRACE
+        const bool trc = (kk == SSA_CL_TRACE || kk == SSA_CL_TRACE + 1) && w < 8192 && lane == 0;
+        unsigned long long* const trp = g_cl_trace + (int64_t)w * 16 + (kk - SSA_CL_TRACE) * 8;
+        if (trc) { trp[0] = wall_clock64(); trp[7] = 0ull; }
+#define SSA_CLT(i) do { if (trc) trp[i] = wall_clock64(); } while (0)
+#define SSA_CLF(b) do { if (trc) trp[7] |= (b); } while (0)
+#else
+#define SSA_CLT(i) do { } while (0)
+#define SSA_CLF(b) do { } while (0)
+#endif
+        asrc.want = (unsigned)kk;
+        asrc.C = &k.c;
+        asrc.lk = (const LoopK*)kp;
+        asrc.M = k.p.trans + (int64_t)time_row(k.p.env_time[0] + pk.time_offset, k.p.n_time) * 9;
+        process_wave<PROP, 2>(t, k.c, pk, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, pf, 0, 0, tile, asrc);
+        wave_lds_sync();
+        if (asrc.aborted) return;
+        boost = tile == closer_tile(asrc.last, total);           // the update ran here (or would have)
+#ifdef SSA_CL_TRACE
+        if (trc) { trp[1] = asrc.t_wait; trp[2] = asrc.t_seen; }
+        if (boost) SSA_CLF(1ull);
+#endif
+        SSA_CLT(3);
+        // ---- this wavefront's part: the agent's score of its objects (lane 0 of each row) and the step's statistics
+#ifdef SSA_CL_NOTREE   // diagnostic: no exchange at all (1: scores still computed, 2: not even those)
+        if (SSA_CL_NOTREE == 2) { asrc.pend = kk; continue; }
+#endif
+        {
+            const int g = lane >> 4, l = lane & 15;
+            if (l == 0) {
+                ClPart me = cl_identity();
+                if (g < cnt) {
+                    double xt[6], x[6], A[21], sc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) { xt[c] = t.T[g * 6 + c]; x[c] = t.X[g * 6 + c]; }
+#pragma unroll
+                    for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+                        for (int c = rr; c < 6; ++c) A[tri(rr, c)] = t.P[g * 36 + rr * 6 + c];
+                    // (the visibility of the new true state was evaluated where the wavefront waited for this step's action)
+                    const bool vis = (r.agent == SSA_AGENT_NAIVE_GREEDY) || vis_row[g] != 0;
+                    double v = 0.0;
+                    switch (r.agent) {
+                        case SSA_AGENT_NAIVE_GREEDY:
+                        case SSA_AGENT_VISIBLE_GREEDY: agent_score_core<1>(xt, x, A, 0.0, nullptr, geo, sc, nullptr); v = sc[0]; break;
+                        case SSA_AGENT_SHANNON: {
+                            double ld_c;
+                            agent_score_core<2>(xt, x, A, ld_prev[g], nullptr, geo, sc, &ld_c);
+                            ld_prev[g] = ld_c;
+                            v = sc[1];
+                            break;
+                        }
+                        case SSA_AGENT_POS_ERROR: agent_score_core<12>(xt, x, A, 0.0, nullptr, geo, sc, nullptr); v = sc[2]; break;
+                        default: agent_score_core<12>(xt, x, A, 0.0, nullptr, geo, sc, nullptr); v = sc[3]; break;
+                    }
+                    if (vis && v == v) { me.best = v; me.arg = base + g; }
+                    const double dp = t.Met[g * 4 + 0];
+                    me.mx = (unsigned long long)__double_as_longlong(dp) & 0x7fffffffffffffffull;   // (ordered bits; NaN on top: np.max)
+                    me.cnt = (unsigned long long)(dp < 1e4) | ((unsigned long long)(dp < 1e7) << 21) | ((unsigned long long)(t.St[g] != 0) << 42);
+                }
+                rowpart[g] = me;
+            }
+        }
+        wave_lds_sync();
+#ifdef SSA_CL_NOTREE
+        if (lane == 0 && rowpart[0].arg == -12345) a.c.stats_out[0] = rowpart[1].best;   // (keeps the scores alive)
+        asrc.pend = kk;
+        continue;
+#endif
+        if (lane == 0) {
+            ClPart me = rowpart[0];
+            cl_merge(me, rowpart[1]);
+            cl_merge(me, rowpart[2]);
+            cl_merge(me, rowpart[3]);
+            const bool closer = tile == closer_tile(asrc.last, total);
+            cl_store(closer ? ws + L.cparts + (int64_t)(kk & 1) * 4 : ws + L.parts + ((int64_t)(kk & 1) * nwork + w) * 4, me);
+            cl_stores_done();
+            __hip_atomic_fetch_add(closer ? ws + L.fcount : ws + L.gcount + (int64_t)G * 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (nobody waits for it here)
+        }
+        SSA_CLT(4);
+        asrc.pend = kk;      // the step's outputs leave inside the next step (ActLate::mid_step)
+    }
+    if (asrc.pend >= 0) closed_loop_store((const LoopK*)kp, t, lane, asrc.pend, base, cnt);
 }
 
 // first maximum of score over mask (single block; 8 loads in flight per thread)
@@ -2161,6 +2733,9 @@ using namespace ssa;
 extern "C" {
 
 int ssa_abi_version(void) { return SSA_ABI_VERSION; }
+#ifdef SSA_CL_TRACE
+int ssa_debug_cl_trace_copy(void* host, int64_t nbytes) { return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_cl_trace), (size_t)nbytes) == hipSuccess ? 0 : -1; }
+#endif
 #ifdef SSA_TRACE
 int ssa_debug_trace_copy(void* host, int64_t nbytes) { return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), (size_t)nbytes) == hipSuccess ? 0 : -1; }
 #endif
@@ -2298,6 +2873,60 @@ int ssa_env_rollout_f64(const ssa_consts* c, const ssa_step_params* p, const ssa
     else hipLaunchKernelGGL(rollout_kernel<2>, dim3(nwork), dim3(64), 0, s, rk, (int)ntiles, nwork);
     hipLaunchKernelGGL(rollout_fold_kernel, dim3(r->n_steps, p->n_env), dim3(64), 0, s, (unsigned long long*)r->stat_shards, r->stats_ring,
                        p->n_env, r->n_steps, r->slot_out, r->history);
+    return launch_status();
+}
+int64_t ssa_closed_loop_workspace_bytes(int64_t n_obj, int32_t n_env)
+{
+    if (n_obj <= 0 || n_env != 1) return 0;
+    const int64_t ntiles = (n_obj + OBJ_PER_WAVE - 1) / OBJ_PER_WAVE;
+    if (ntiles >= ((int64_t)1 << 30)) return 0;
+    return cl_layout((int)ntiles).total * 8;
+}
+// wavefronts of closed_loop_kernel<prop> the device holds at once (the runtime's occupancy figure x compute units)
+static int64_t closed_loop_capacity(int prop)
+{
+    static int64_t cached[3] = {0, 0, 0};
+    if (cached[prop] <= 0) {
+        int per_cu = 0;
+        hipError_t e;
+        if (prop == SSA_PROP_FG) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, closed_loop_kernel<1>, 64, 0);
+        else if (prop == SSA_PROP_ELEMENTS) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, closed_loop_kernel<0>, 64, 0);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, closed_loop_kernel<2>, 64, 0);
+        if (e != hipSuccess || per_cu <= 0) return 0;
+        cached[prop] = (int64_t)per_cu * device_cu_count();
+    }
+    return cached[prop];
+}
+int ssa_env_closed_loop_f64(const ssa_consts* c, const ssa_step_params* p, const ssa_closed_loop_params* r, void* stream)
+{
+    if (!c || !p || !r || p->n_obj <= 0 || r->n_steps < 1 || r->history < 2) return SSA_E_INVALID;
+    if (r->slot_out < 0 || r->slot_out >= r->history) return SSA_E_INVALID;
+    if (!r->x_true_ring || !r->x_ring || !r->P_ring || !r->obs_ring || !r->metrics_ring || !r->stats_out || !r->actions || !r->workspace)
+        return SSA_E_INVALID;
+    if (!p->status || !p->trans || !p->env_time || !p->z_noise) return SSA_E_INVALID;
+    if (r->agent < SSA_AGENT_NAIVE_GREEDY || r->agent > SSA_AGENT_VEL_ERROR) return SSA_E_INVALID;
+    if (c->obs_type != SSA_OBS_AER && c->obs_type != SSA_OBS_XYZ) return SSA_E_INVALID;
+    if (c->propagator != SSA_PROP_FG && c->propagator != SSA_PROP_ELEMENTS && c->propagator != SSA_PROP_J2_RK4) return SSA_E_INVALID;
+    if (c->propagator == SSA_PROP_J2_RK4 && (c->rk4_substeps < 1 || c->rk4_substeps > 4096)) return SSA_E_INVALID;
+    if (p->n_env != 1) return SSA_E_UNSUPPORTED;
+    const int64_t ntiles = (p->n_obj + OBJ_PER_WAVE - 1) / OBJ_PER_WAVE;
+    const int64_t cap = closed_loop_capacity(c->propagator);
+    const ClLayout L = cl_layout((int)ntiles);
+    if (ntiles + L.ng + 1 > cap) return SSA_E_UNSUPPORTED;   // every wavefront (compute + service) must be resident: the decision is a grid-wide exchange
+    if (r->workspace_bytes < L.total * 8) return SSA_E_INVALID;
+    LoopK lk;
+    lk.k.c = *c;
+    lk.k.p = *p;
+    lk.k.p.aer_out = nullptr;
+    lk.c = *r;
+    hipStream_t s = (hipStream_t)stream;
+    // counters, flags: zero (a memset node: capturable)
+    if (hipMemsetAsync(r->workspace, 0, (size_t)L.parts * 8, s) != hipSuccess) return SSA_E_LAUNCH;
+    const int nwork = (int)ntiles;
+    const dim3 grid((unsigned)(nwork + L.ng + 1));
+    if (c->propagator == SSA_PROP_FG) hipLaunchKernelGGL(closed_loop_kernel<1>, grid, dim3(64), 0, s, lk, nwork, nwork);
+    else if (c->propagator == SSA_PROP_ELEMENTS) hipLaunchKernelGGL(closed_loop_kernel<0>, grid, dim3(64), 0, s, lk, nwork, nwork);
+    else hipLaunchKernelGGL(closed_loop_kernel<2>, grid, dim3(64), 0, s, lk, nwork, nwork);
     return launch_status();
 }
 int ssa_stats_fold_f64(uint64_t* stat_shards, double* stats, int32_t n_env, void* stream)

@@ -219,6 +219,55 @@ class HotPathEngine:
         if rc:
             raise _lib.SsaHipError("ssa_env_rollout_f64 failed with code %d" % rc)
 
+    def launch_closed_loop(self, slot_in, time_offset, kind, actions, stats_out, upd_out=None, fallback=None, picks=None, stream=None):
+        """K steps AND the K decisions of a greedy agent in ONE persistent launch (include/ssa_hip.h:
+        ssa_env_closed_loop_f64).  `actions`: device int32 [K + 1], actions[0] = the first step's action (given), the kernel
+        writes actions[1..K]; `stats_out` device float64 [K][STAT_STRIDE]; `upd_out` [K][UPD_STRIDE] or None; `fallback`
+        int32 [K + 1] or None; `picks` int64 [K + 1][2] or None.  Step k reads history slot (slot_in + k) % H and writes
+        (slot_in + k + 1) % H with time index time_offset + k.  Returns False -- nothing enqueued -- when the library
+        declines the configuration (several envs, or more objects than resident wavefronts x 4): the caller then issues
+        the per-step launches.  self.loop_error (host-mapped int32) turns 1 if the launch gave up on a timeout."""
+        if self.E != 1:
+            return False
+        K = int(actions.numel()) - 1
+        if K < 1:
+            raise _lib.SsaHipError("closed loop: actions must hold K + 1 >= 2 words")
+        for t, dt, n, nm in ((actions, torch.int32, K + 1, "actions"), (stats_out, f64, K * _lib.STAT_STRIDE, "stats_out"),
+                             (upd_out, f64, K * _lib.UPD_STRIDE, "upd_out"), (fallback, torch.int32, K + 1, "fallback"),
+                             (picks, torch.int64, 2 * (K + 1), "picks")):
+            if t is None:
+                continue
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dt and t.is_contiguous() and t.numel() >= n):
+                raise _lib.SsaHipError("closed loop: %s must be a contiguous CUDA %s tensor of >= %d elements" % (nm, dt, n))
+        if getattr(self, "_loop_ws", None) is None:
+            nb = int(self._lib.ssa_closed_loop_workspace_bytes(self.m, self.E))
+            if nb <= 0:
+                return False
+            self._loop_ws = torch.zeros(nb // 8, dtype=torch.int64, device=self.dev)
+            self._loop_err_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self.loop_error = self._loop_err_host.numpy()
+        s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        self.flush_stats(s)
+        r = _lib.ssa_closed_loop_params()
+        r.n_steps, r.history, r.slot_out, r.agent = K, self.H, (int(slot_in) + 1) % self.H, int(kind)
+        r.x_true_ring, r.x_ring, r.P_ring = self._bx_t, self._bx, self._bP
+        r.obs_ring, r.metrics_ring = self._bo, self._bm
+        r.upd_out = upd_out.data_ptr() if upd_out is not None else 0
+        r.stats_out, r.actions = stats_out.data_ptr(), actions.data_ptr()
+        r.fallback = fallback.data_ptr() if fallback is not None else 0
+        r.picks = picks.data_ptr() if picks is not None else 0
+        r.error = self._loop_err_host.data_ptr()
+        r.workspace, r.workspace_bytes = self._loop_ws.data_ptr(), self._loop_ws.numel() * 8
+        p = self._p
+        p.time_offset = int(time_offset)
+        p.launch_mask, p.stat_shards_prev, p.stats_prev, p.aer_out = 0, 0, 0, 0
+        rc = self._lib.ssa_env_closed_loop_f64(self._cref, self._pref, C.byref(r), s)
+        if rc == _lib.E_UNSUPPORTED:
+            return False
+        if rc:
+            raise _lib.SsaHipError("ssa_env_closed_loop_f64 failed with code %d" % rc)
+        return True
+
     def launch_agent_select(self, slot_cur, time_offset, kind, action_ptr, fallback_ptr=0, pick_ptr=0, stream=None, have_prev=True):
         """enqueue the device-side agent (include/ssa_hip.h: ssa_agent_select_f64): choose, for every env, the action of
         the NEXT step from history slot `slot_cur` (and the slot before it for the Shannon agent) and store it in the

@@ -181,6 +181,8 @@ class SSA_Tasker_Env(Env):
         self._consts, _ = kernel_consts(config, self.Q, self.R, self.dt, self.obs_limit, self.obs_lla)
         self._engine = None
         self._device_rng = bool(config.get('device_rng', False))
+        # run_agent(): the persistent closed-loop kernel (one launch per chunk) unless config['closed_loop'] == 'per_step'
+        self._closed_loop_persistent = config.get('closed_loop', 'persistent') != 'per_step'
         self.np_random = None
         self.init_seed = self.seed(config.get('seed'))[0]
         self.reset()
@@ -457,24 +459,45 @@ class SSA_Tasker_Env(Env):
         K = min(int(n_steps), self.n - 1 - self.i)
         if fallback_actions is None:
             fallback_actions = [self.action_space.sample() for _ in range(K + 1)]
-        fb = torch.as_tensor(np.asarray(fallback_actions, dtype=np.int32)[:K + 1]).to(e.dev)
-        assert fb.numel() >= K, "one fallback action per decision"
+        fbh = np.asarray(fallback_actions, dtype=np.int32)[:K + 1]
+        assert fbh.size >= K, "one fallback action per decision"
+        if fbh.size < K + 1:      # (the decision AFTER the last step is computed too and nobody uses it)
+            fbh = np.concatenate([fbh, np.full(K + 1 - fbh.size, -1, dtype=np.int32)])
+        fb = torch.as_tensor(fbh).to(e.dev)
         log = torch.full((K + 1,), -1, dtype=torch.int32, device=e.dev)     # log[k] = action of step i0 + k + 1
         actions, rewards, dones = [], [], []
         pos, done = 0, False
         e.launch_agent_select(self.i, self.i, kind, log.data_ptr(), fallback_ptr=fb.data_ptr(), have_prev=self.i >= 1)
+        persistent = bool(self._closed_loop_persistent)
         while pos < K and not done:
-            kk = min(K - pos, e.H - 1)
+            # 'trinary' has no early `done`: the whole run is one chunk; otherwise every step of a chunk must stay resident
+            # in the history ring, because the step that turns out to be the last one is the state this call returns
+            kk = (K - pos) if (persistent and self.reward_type == 'trinary') else min(K - pos, e.H - 1)
             i0 = self.i
-            for k in range(kk):
-                i = i0 + k + 1
-                e.launch_step((i - 1) % e.H, i % e.H, i, actions_ptr=log.data_ptr() + 4 * (pos + k), fast_stats=True, defer_fold=True)
-                if pos + k + 1 < K:     # (the decision for the step after this one)
-                    e.launch_agent_select(i, i, kind, log.data_ptr() + 4 * (pos + k + 1), fallback_ptr=fb.data_ptr() + 4 * (pos + k + 1))
-            e.flush_stats()
-            slots = [(i0 + 1 + k) % e.H for k in range(kk)]
-            stats = e.stats[slots, 0].cpu().numpy()          # synchronises the stream
-            upd = e.upd[slots, 0].cpu().numpy()
+            used = False
+            if persistent:
+                # ONE launch for the kk steps and their kk decisions (ssa_env_closed_loop_f64)
+                stats_d = torch.empty((kk, _lib.STAT_STRIDE), dtype=torch.float64, device=e.dev)
+                upd_d = torch.empty((kk, _lib.UPD_STRIDE), dtype=torch.float64, device=e.dev)
+                used = e.launch_closed_loop(i0 % e.H, i0 + 1, kind, log[pos:pos + kk + 1], stats_d, upd_d, fallback=fb[pos:pos + kk + 1])
+                if used:
+                    stats = stats_d.cpu().numpy()                      # synchronises the stream
+                    upd = upd_d.cpu().numpy()
+                    if int(e.loop_error[0]) != 0:
+                        raise _lib.SsaHipError("ssa_env_closed_loop_f64: a wavefront timed out waiting for a decision (launch abandoned)")
+                else:
+                    persistent = False
+                    kk = min(kk, e.H - 1)
+            if not used:
+                for k in range(kk):
+                    i = i0 + k + 1
+                    e.launch_step((i - 1) % e.H, i % e.H, i, actions_ptr=log.data_ptr() + 4 * (pos + k), fast_stats=True, defer_fold=True)
+                    if pos + k + 1 < K:     # (the decision for the step after this one)
+                        e.launch_agent_select(i, i, kind, log.data_ptr() + 4 * (pos + k + 1), fallback_ptr=fb.data_ptr() + 4 * (pos + k + 1))
+                e.flush_stats()
+                slots = [(i0 + 1 + k) % e.H for k in range(kk)]
+                stats = e.stats[slots, 0].cpu().numpy()          # synchronises the stream
+                upd = e.upd[slots, 0].cpu().numpy()
             acts = log[pos:pos + kk].cpu().numpy()
             for k in range(kk):
                 self.i += 1

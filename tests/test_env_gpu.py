@@ -365,14 +365,16 @@ def test_failed_action_leaves_no_update_record_and_rollout_dates_failures(envs):
 @pytest.mark.parametrize("agent_name,lim", [("agent_visible_greedy", 10.0), ("agent_shannon", 10.0), ("agent_pos_error_greedy", 5.0),
                                             ("agent_vel_error_greedy", 5.0), ("agent_naive_greedy", -90.0), ("agent_visible_greedy", 89.9)])
 @pytest.mark.parametrize("hist", ['full', 2])
-def test_closed_loop_on_device_equals_host_loop(envs, agent_name, lim, hist):
+@pytest.mark.parametrize("loop", ['persistent', 'per_step'])
+def test_closed_loop_on_device_equals_host_loop(envs, agent_name, lim, hist, loop):
     """SURVEY 8f-1 / agents.py:7-81: env.run_agent() -- the agent's arg-max chained into the next step's launch on the
     device -- against the host loop `a = agent(obs, env); env.step(a)` of the reference's drivers (here with
     ssa_gym_amd.agents, whose scores come from the same device arithmetic): identical action sequence, bit-identical
     states, same rewards.  obs_limit 89.9 deg: nothing is ever visible -> every decision is the fallback draw."""
     from ssa_gym_amd import agents
     cfg = dict(envs.env_config)
-    cfg.update(rso_count=37, steps=40, reward_type='trinary', obs_returned='flatten', seed=11, obs_limit=lim, history=hist)
+    cfg.update(rso_count=37, steps=40, reward_type='trinary', obs_returned='flatten', seed=11, obs_limit=lim, history=hist,
+               closed_loop=loop)       # 'persistent': ONE launch (ssa_env_closed_loop_f64); 'per_step': step + select launches
     K = 25
     rs = np.random.RandomState(5)
     fallback = rs.randint(0, 37, size=K + 1)
@@ -396,6 +398,7 @@ def test_closed_loop_on_device_equals_host_loop(envs, agent_name, lim, hist):
         acts.append(a)
         rews.append(r)
     obs, dacts, drews, ddones = dev.run_agent(agent_name, K, fallback_actions=fallback)
+    assert (getattr(dev._engine, "_loop_ws", None) is not None) == (loop == 'persistent')     # the path under test really ran
     assert list(dacts) == acts, (list(dacts), acts)
     np.testing.assert_array_equal(drews, np.array(rews))
     assert dev.i == host.i == K and not ddones.any()
@@ -519,3 +522,42 @@ def test_cowell_acceleration_hook(envs):
         resolve_perturbation(dict(base, fx=D.fx_xyz_cowell.with_ad(lambda t, u, k: 0)))
     with pytest.raises(NotImplementedError):       # an acceleration next to the analytic two-body propagator has no kernel
         kernel_consts(dict(base, ad=D.ad_j2), env.Q, env.R, 20.0, 0.0, env.obs_lla)
+
+
+@pytest.mark.parametrize("m,agent_name,reward", [(4100, "agent_visible_greedy", 'trinary'), (20000, "agent_visible_greedy", 'trinary'),
+                                                 (20000, "agent_shannon", 'trinary'), (20160, "agent_pos_error_greedy", 'trinary'),
+                                                 (2000, "agent_vel_error_greedy", 'jones')])
+def test_persistent_closed_loop_equals_per_step_launches_at_size(envs, m, agent_name, reward):
+    """ssa_env_closed_loop_f64 at sizes where the decision really crosses wavefront groups (4 100 objects: 1 025 wavefronts = 16
+    groups + one wavefront; 20 000: 79 groups over all eight XCDs; 20 160: with the 80 service wavefronts every resident slot taken): same actions, bit-identical
+    states and statistics as the step + select launches, through run_agent.  'jones': an episode that ends inside the run."""
+    cfg = dict(envs.env_config)
+    K = 40 if reward == 'trinary' else 190      # ('jones': max delta_pos crosses 5e6 m after ~150 predict-mostly steps)
+    cfg.update(rso_count=m, steps=K + 20, reward_type=reward, obs_returned='flatten', seed=3, obs_limit=10.0,
+               history=(2 if reward == 'trinary' else 'full'), device_rng=True)
+    fallback = np.random.RandomState(9).randint(0, m, size=K + 1)
+    out = {}
+    for loop in ('persistent', 'per_step'):
+        env = envs.make(config=dict(cfg, closed_loop=loop))
+        obs, acts, rews, dones = env.run_agent(agent_name, K, fallback_actions=fallback)
+        assert (getattr(env._engine, "_loop_ws", None) is not None) == (loop == 'persistent')
+        out[loop] = (obs, acts, rews, dones, env.i, env.x_filter[env.i], env.P_filter[env.i], env.x_true[env.i],
+                     env._engine.status.cpu().numpy(), env.obs_taken.copy(), env._y.copy())
+    a, b = out['persistent'], out['per_step']
+    assert list(a[1]) == list(b[1]) and len(set(a[1].tolist())) > 1
+    np.testing.assert_array_equal(a[2], b[2])
+    np.testing.assert_array_equal(a[3], b[3])
+    assert a[4] == b[4] and (a[4] == K if reward == 'trinary' else (a[3][-1] and a[4] < K))
+    for k in (0, 5, 6, 7, 8, 9):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    np.testing.assert_array_equal(a[10], b[10])
+
+
+def test_closed_loop_beyond_the_resident_capacity_takes_the_per_step_launches(envs):
+    """more objects than the resident wavefronts (minus the service wavefronts) x 4: the library declines (SSA_E_UNSUPPORTED) and run_agent issues the
+    step + select launches instead -- same API, same results, no deadlock-prone partial grid"""
+    cfg = dict(envs.env_config)
+    cfg.update(rso_count=20484, steps=20, reward_type='trinary', obs_returned='aer', seed=3, obs_limit=10.0, history=2, device_rng=True)
+    env = envs.make(config=cfg)
+    obs, acts, rews, dones = env.run_agent("agent_visible_greedy", 6)
+    assert len(acts) == 6 and env.i == 6 and obs.shape == (4 * 20484,) and np.isfinite(rews).all()
