@@ -11,6 +11,7 @@
 // DPP row reduction; the covariance outer products run from LDS.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstddef>
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
@@ -282,18 +283,25 @@ constexpr double X_FAILED_POS = 1e20, X_FAILED_VEL = 1e12;  // ssa_tasker_simple
 // doubles [d_i[0..5], 1.0, 0.0]: the layout the matrix unit reads its operands from (below); the object blocks start at
 // {0, 100, 208, 308} doubles so that the 32 lanes of one ds_read_b64 half hit 32 different 8-byte bank slots.
 struct alignas(16) Tiles {
-    double P[OBJ_PER_WAVE * 36];       // P_in, later P_out
-    double X[OBJ_PER_WAVE * 6];        // x_in, then sigma_0', then x_out
-    double T[OBJ_PER_WAVE * 6];        // x_true_in, later x_true_out
+    // The first 1 984 bytes are laid out for the tile's LDS-DMA loads (tile_dma_issue): a global_load_lds_dwordx4 writes
+    // LDS at (wave-uniform base) + lane x 16, so one of them with base &P[0] fills P[0..128) from all 64 lanes, and three masked
+    // ones with base &P[128] put lanes 0-7 on the tail of P, lanes 32-43 on X (byte 1024 + 32 x 16 = 1536) and lanes 48-59 on T
+    // (byte 1024 + 48 x 16 = 1792).  The small members live in the gaps.
+    double P[OBJ_PER_WAVE * 36];       // @0     P_in, later P_out
+    double Q[36];                      // @1152  process noise (read per covariance entry with a lane-dependent index)
+    double Z[8];                       // @1440  six zeros: the "factor row" of the lanes that add nothing (sigma_0, truth, idle)
+    int St[OBJ_PER_WAVE];              // @1504
+    int pad0[4];                       // @1520
+    double X[OBJ_PER_WAVE * 6];        // @1536  x_in, then sigma_0', then x_out
+    double pad1[8];                    // @1728
+    double T[OBJ_PER_WAVE * 6];        // @1792  x_true_in, later x_true_out
     double UA[OBJ_PER_WAVE * 36];      // Cholesky factor rows [4][36] (the transform's moment sums stay in registers)
     double D[408];                     // centred propagated sigma points (see above); scratch of the update
     double M[OBJ_PER_WAVE * 12];       // s = Wi sum d_i | m' = mean - sigma_0'
-    double Q[36];                      // process noise (read per covariance entry with a lane-dependent index)
     double Obs[OBJ_PER_WAVE * 12];     // until the update has run: its prefetched inputs (GCRS->ITRS matrix [9] | measurement noise [3]) per object
     double Met[OBJ_PER_WAVE * 4];
-    double Z[8];                       // six zeros: the "factor row" of the lanes that add nothing (sigma_0, truth, idle)
-    int St[OBJ_PER_WAVE];
 };
+static_assert(offsetof(Tiles, P) == 0 && offsetof(Tiles, X) == 1536 && offsetof(Tiles, T) == 1792, "LDS-DMA image of the tile (tile_dma_issue)");
 SSA_DEV int dbase(int g) { return g * 96 + (g & 1) * 4 + (g >> 1) * 16; }   // 0, 100, 208, 308
 static_assert(sizeof(Tiles) <= 7680, "Tiles must fit 20 wavefronts per CU (see above)");
 
@@ -305,7 +313,7 @@ static_assert(sizeof(Tiles) <= 7680, "Tiles must fit 20 wavefronts per CU (see a
 //   tile_issue : 16-byte wave-contiguous loads into 8 VGPRs.  `main` = P entries [2 lane, 2 lane + 2);
 //                `aux` by lane: 0-7 the tail of P | 32-43 x_filter | 48-59 x_true | 60-63 status (bits)
 //   tile_commit: registers -> LDS tiles (rows beyond `cnt` are zero / marked failed)
-struct TileRegs { double2 main, aux; int st; };   // (the status word travels in its own register: packing it into `aux` put a wait for
+struct TileRegs { double2 main, aux; int st; bool dma; };   // (the status word travels in its own register: packing it into `aux` put a wait for
                                                  // EVERY outstanding load right behind the tile's loads)
 // one 16-byte lane of a tile load (plain: marking the inputs streaming was measured slower, 45.4 k vs 46.5 k)
 SSA_DEV double2 load16(const double* src) { return *reinterpret_cast<const double2*>(src); }
@@ -316,6 +324,7 @@ SSA_DEV void tile_issue_from(TileRegs& r, const double* P_in, const double* x_in
     r.main = zero;
     r.aux = zero;
     r.st = SSA_ST_PREDICT_NAN;
+    r.dma = false;
     if (cnt <= 0) return;
     const double* Pin = P_in + base * 36;
     if (lane < cnt * 18) r.main = load16(Pin + 2 * lane);
@@ -340,6 +349,38 @@ SSA_DEV void tile_commit(Tiles& t, const TileRegs& r, int lane)
     const int i = lane - (sT ? 48 : sX ? 32 : 0);
     double* dst = sT ? t.T : sX ? t.X : t.P + 128;
     if (i < (sX ? 12 : 8)) reinterpret_cast<double2*>(dst)[i] = r.aux;
+    if (lane >= 60) t.St[lane - 60] = r.st;
+}
+// The one-tile kernels' load: the tile travels global -> LDS directly (LDS-DMA, no VGPR staging, no ds_write pass, the source
+// addresses in scalar-base + lane-offset form: four instructions and a handful of scalar ones where the register path spends
+// ~80 vector instructions on lane-range selects, 64-bit address arithmetic and the commit).  A ragged last tile (cnt < 4) takes
+// the register path, which zero-fills what it does not load.  Completion: s_waitcnt vmcnt(0) (tile_dma_wait) -- the compiler
+// does not know these loads write LDS.
+typedef const __attribute__((address_space(1))) void* GlobalVoidPtr;
+typedef __attribute__((address_space(3))) void* LdsVoidPtr;
+SSA_DEV void glds16(const double* src, double* lds_base)
+{
+    __builtin_amdgcn_global_load_lds((GlobalVoidPtr)src, (LdsVoidPtr)lds_base, 16, 0, 0);
+}
+SSA_DEV void tile_dma_issue(Tiles& t, TileRegs& r, const double* P_in, const double* x_in, const double* x_true_in, const int32_t* status,
+                            int lane, int64_t base, int cnt)
+{
+    r.dma = cnt == OBJ_PER_WAVE;
+    if (!r.dma) {
+        tile_issue_from(r, P_in, x_in, x_true_in, status, lane, base, cnt);
+        return;
+    }
+    r.st = SSA_ST_PREDICT_NAN;
+    const double* Pin = P_in + base * 36;
+    glds16(Pin + 2 * lane, t.P);                                                           // P[0 .. 128)
+    if (lane < 8) glds16(Pin + 128 + 2 * lane, t.P + 128);                                 // P[128 .. 144)
+    if (lane >= 32 && lane < 44) glds16(x_in + base * 6 - 64 + 2 * lane, t.P + 128);       // -> X: entries 2 (lane - 32) ..
+    if (lane >= 48 && lane < 60) glds16(x_true_in + base * 6 - 96 + 2 * lane, t.P + 128);  // -> T: entries 2 (lane - 48) ..
+    if (lane >= 60) r.st = status[base + (lane - 60)];
+}
+SSA_DEV void tile_dma_wait(Tiles& t, const TileRegs& r, int lane)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane >= 60) t.St[lane - 60] = r.st;
 }
 typedef double v2d __attribute__((ext_vector_type(2)));
@@ -369,6 +410,47 @@ SSA_DEV void store_tile(const Tiles& t, const ssa_step_params& p, int lane, int6
 #else
 #define SSA_SKIP(b) 0
 #endif
+    if (cnt == OBJ_PER_WAVE) {
+        // A whole tile (wave-uniform; every tile of a launch but a ragged last one).  Every group of lanes stores from
+        // (uniform pointer) + lane x 16 bytes on both sides -- the global address in scalar-base + lane-offset form, the LDS address
+        // one shared register plus an immediate -- instead of selecting 64-bit destination and source pointers per lane range
+        // (that was 58 vector + 60 scalar instructions per wavefront).  The observation rows [x, diag P] (results.py:61) are read
+        // from the state / covariance tiles by the lanes that store them: no staging copy.
+        if (!SSA_SKIP(1)) {
+            store16<NT>(p.P_out + base * 36 + 2 * lane, t.P + 2 * lane);
+            if (lane < 8) store16<NT>(p.P_out + base * 36 + 128 + 2 * lane, t.P + 128 + 2 * lane);
+        }
+        if (!SSA_SKIP(4)) {
+            if ((unsigned)(lane - 8) < 12u) store16<NT>(p.x_out + base * 6 - 16 + 2 * lane, t.X - 16 + 2 * lane);
+            if ((unsigned)(lane - 20) < 12u) store16<NT>(p.x_true_out + base * 6 - 40 + 2 * lane, t.T - 40 + 2 * lane);
+        }
+        if (!SSA_SKIP(2) && lane >= 32 && lane < 56) {   // obs: 24 lanes x 16 bytes; lane i = entries [2 i, 2 i + 2) of the tile's 48
+            const int i = lane - 32;
+            const int jj = (i * 43) >> 8;                // i / 6: the object
+            const int r = 2 * i - 12 * jj;               // 0, 2, 4: x | 6, 8, 10: diag P
+            double* dst = p.obs + base * 12 - 64 + 2 * lane;
+            if (r < 6) store16<NT>(dst, t.X + jj * 6 + r);
+            else {
+                const double* d = t.P + jj * 36 + 7 * (r - 6);
+                const v2d pair = {d[0], d[7]};
+                if (NT) __builtin_nontemporal_store(pair, reinterpret_cast<v2d*>(dst));
+                else *reinterpret_cast<v2d*>(dst) = pair;
+            }
+        }
+        if (!SSA_SKIP(16) && lane >= 56 && lane < 60) p.status[base - 56 + lane] = t.St[lane - 56];
+        if (!SSA_SKIP(8) && lane < 16) {   // metrics [E][4][m]: four 32-byte runs per tile
+            const int kk = lane >> 2, jj = lane & 3;
+            const int64_t obj = base + jj;
+            if (p.n_env == 1) {   // (scalar row stride, one 64-bit multiply-add per lane)
+                p.metrics[(int64_t)kk * p.n_obj + obj] = t.Met[jj * 4 + kk];
+            } else {
+                const int64_t e = (int64_t)((uint32_t)obj / (uint32_t)p.n_obj), j = obj - e * p.n_obj;
+                p.metrics[(e * 4 + kk) * p.n_obj + j] = t.Met[jj * 4 + kk];
+            }
+        }
+        return;
+    }
+    // ragged last tile: the general form (the observation rows were staged in t.Obs by observe_rows)
     if (!SSA_SKIP(1) && lane < cnt * 18) store16<NT>(p.P_out + base * 36 + 2 * lane, t.P + 2 * lane);
     {   // lanes [0, 12): x | [16, 28): x_true | [32, 40): the tail of P | [40, 64): obs -- one 16-byte store per lane, destination and
         // LDS source selected by lane range (see tile_issue_from)
@@ -399,9 +481,10 @@ SSA_DEV void store_tile(const Tiles& t, const ssa_step_params& p, int lane, int6
 }
 
 // O1/O2 for the row's object from the tiles (results.py:61, :37)
-SSA_DEV void observe_rows(Tiles& t, int g, int l)
+SSA_DEV void observe_rows(Tiles& t, int g, int l, bool stage_obs)
 {
-    if (l < 12) t.Obs[g * 12 + l] = (l < 6) ? t.X[g * 6 + l] : t.P[g * 36 + 7 * (l - 6)];
+    // (a whole tile's observation rows leave straight from the state / covariance tiles: store_tile)
+    if (stage_obs && l < 12) t.Obs[g * 12 + l] = (l < 6) ? t.X[g * 6 + l] : t.P[g * 36 + 7 * (l - 6)];
     if (l < 4) {
         const int off = (l & 1) * 3;  // 0: position block, 1: velocity block
         double v;
@@ -958,7 +1041,8 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     }
 #endif
 
-    if (TILE != 2) tile_commit(t, pf, lane);            // TILE 1: requested one tile ago (or by the kernel prologue)
+    if (TILE == 0 && pf.dma) tile_dma_wait(t, pf, lane);   // (the one-tile kernels: the tile came by LDS-DMA)
+    else if (TILE != 2) tile_commit(t, pf, lane);        // TILE 1: requested one tile ago (or by the kernel prologue)
     if (lane < 8) t.Z[lane] = 0.0;
     if (TILE != 2 && lane < 36) t.Q[lane] = C.Q[lane];   // (a rollout's later steps find it in place)
     wave_lds_sync();
@@ -1362,7 +1446,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     if (l == 0) t.St[g] = st_new;
     wave_lds_sync();
 #if !(defined(SSA_ABLATE) && (SSA_ABLATE & 16))
-    observe_rows(t, g, l);
+    observe_rows(t, g, l, cnt != OBJ_PER_WAVE);
 #endif
     // O4 in the epilogue (atomics-statistics path): the (az, el, range, trace P) block of the NEW state -- the 'aer'
     // observation mode and the multi-GPU all-gather payload -- from the tiles, so that no second pass over x / P (the
@@ -1380,18 +1464,21 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         // integers, so NaN wins exactly as in np.max), trinary counts (packed in one word), failures
         const bool one_env = p.n_env == 1 || ((uint32_t)base / (uint32_t)p.n_obj == (uint32_t)(base + cnt - 1) / (uint32_t)p.n_obj);
         if (p.stat_shards && one_env) {
-            // common case, the tile lies in one env: every lane takes its row's values, two cross-row DPP steps
-            // (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) leave the tile's totals in row 3
+            // common case, the tile lies in one env.  Every lane of a row reads its row's delta_pos, so the COUNTS are ballots:
+            // one bit per row (lanes 0, 16, 32, 48) of the comparison's mask, counted by the scalar unit -- no packing into
+            // words, no cross-row adds.  The maximum crosses rows by two DPP steps (row_bcast:15 into rows 1 and 3, row_bcast:31
+            // into rows 2 and 3) and ends in row 3.
             const double dp = t.Met[g * 4 + 0];
             const bool rv = g < cnt;
+            const unsigned long long rowbit = 0x0001000100010001ull;
+            const unsigned c4 = (unsigned)__popcll(__ballot(rv && dp < 1e4) & rowbit);
+            const unsigned c7 = (unsigned)__popcll(__ballot(rv && dp < 1e7) & rowbit);
+            const unsigned nfl = (unsigned)__popcll(__ballot(rv && t.St[g] != 0) & rowbit);
             unsigned long long mx = rv ? ((unsigned long long)__double_as_longlong(dp) & 0x7fffffffffffffffull) : 0ull;
-            // counts of the row, one 32-bit word while they cross rows: [< 1e4] | [< 1e7] << 8 | [failed] << 16  (each <= 4 per tile)
-            unsigned cw = rv ? ((unsigned)(dp < 1e4) | ((unsigned)(dp < 1e7) << 8) | ((unsigned)(t.St[g] != 0) << 16)) : 0u;
 #define SSA_XROW(CTRL, ROWMASK)                                                                                          \
             {                                                                                                            \
                 const unsigned long long m2 = ((unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(0, (int)(mx >> 32), CTRL, ROWMASK, 0xF, false) << 32) | \
                                               (unsigned)__builtin_amdgcn_update_dpp(0, (int)(mx & 0xffffffffull), CTRL, ROWMASK, 0xF, false);                 \
-                cw += (unsigned)__builtin_amdgcn_update_dpp(0, (int)cw, CTRL, ROWMASK, 0xF, false);                      \
                 mx = m2 > mx ? m2 : mx;                                                                                  \
             }
             SSA_XROW(0x142, 0xA)   // row_bcast:15
@@ -1400,10 +1487,9 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
             if (lane == 63) {
                 const int64_t e_tile = (p.n_env > 1) ? (int64_t)((uint32_t)base / (uint32_t)p.n_obj) : 0;
                 unsigned long long* sh = (unsigned long long*)p.stat_shards + ((e_tile * SSA_STAT_SHARDS) + (tile & (SSA_STAT_SHARDS - 1))) * SSA_STAT_SHARD_WORDS;
-                const unsigned nfl = cw >> 16;
 #ifndef SSA_NO_ATOMICS   // (diagnostic builds only)
                 atomicMax(sh, mx);
-                atomicAdd(sh + 1, (unsigned long long)(cw & 0xffu) | ((unsigned long long)((cw >> 8) & 0xffu) << 32));
+                atomicAdd(sh + 1, (unsigned long long)c4 | ((unsigned long long)c7 << 32));
                 if (nfl) atomicAdd(sh + 2, (unsigned long long)nfl);
 #endif
             }
@@ -1523,7 +1609,7 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(int ntile
     if (!MULTI) {
         const int64_t base = (int64_t)tile * OBJ_PER_WAVE;
         const int cnt = (int)((total - base) < OBJ_PER_WAVE ? (total - base) : OBJ_PER_WAVE);
-        tile_issue_from(pf, pre_P_in, pre_x_in, pre_x_true_in, pre_status, lane, base, cnt);
+        tile_dma_issue(t, pf, pre_P_in, pre_x_in, pre_x_true_in, pre_status, lane, base, cnt);
         ActEarly early;
         process_wave<PROP, 0>(t, k_arg.c, k_arg.p, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, pf, 0, 0, tile, early);
         return;
