@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SSA_ABI_VERSION 16
+#define SSA_ABI_VERSION 17
 
 /* error codes */
 #define SSA_OK 0
@@ -169,7 +169,14 @@ typedef struct ssa_step_params {
     int32_t aer_cols;          /* columns of aer_out per object: 0 or 4 = (az, el, range, trace P); 1 = trace P only, [E*m] --
                                   the "per-object covariance-trace observation" of the sharded 160 000-object configuration:
                                   a quarter of the all-gather payload and no inverse trigonometry in the epilogue */
-    int32_t reserved1;
+    int32_t action0;           /* with SSA_LAUNCH_INLINE_ACTION in launch_mask (one env): the env's action BY VALUE -- `actions` is then not
+                                  read and may be NULL.  For callers whose action is born on the host every step (a gym env): a word
+                                  in host-mapped memory would be fetched over PCIe by every wavefront of the launch (5 000 reads at
+                                  20 000 objects: the step took 28 us instead of 16), a host-to-device copy costs a copy-engine pass */
+    double *obs_mirror;        /* [E*m][12] or NULL: a SECOND destination of the observation rows (O1), written by the same lanes as
+                                  `obs`.  Meant for host-mapped pinned memory: the 'flatten' observation of a gym-style caller then
+                                  reaches the host from inside the kernel, overlapped with the other wavefronts' arithmetic, instead
+                                  of through a copy-engine pass after it (1.92 MB at 20 000 objects: 44 us) */
 } ssa_step_params;
 
 /* ---------------------------------------------------------------- fused hot path
@@ -189,6 +196,7 @@ int ssa_env_step_f64(const ssa_consts *c_host, const ssa_step_params *p_host, vo
  * call would add the queue latency of the records, ~10 us). */
 #define SSA_PROFILE_SLOTS 1024
 #define SSA_LAUNCH_DEFER_FOLD 8u
+#define SSA_LAUNCH_INLINE_ACTION 16u /* the env's action is ssa_step_params.action0 (n_env == 1) */
 int ssa_env_step_profiled_f64(const ssa_consts *c_host, const ssa_step_params *p_host, void *stream, int32_t slot);
 /* waits for slot's kernel and writes its duration in milliseconds */
 int ssa_env_step_profile_ms(int32_t slot, float *kernel_ms);

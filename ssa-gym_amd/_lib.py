@@ -33,7 +33,7 @@ class ssa_step_params(C.Structure):
         ("zn_stride_env", C.c_int64), ("zn_stride_time", C.c_int64), ("zn_stride_obj", C.c_int64),
         ("n_time", C.c_int32), ("launch_mask", C.c_uint32), ("stats", c_dp), ("work", c_dp), ("stat_ws", c_dp),
         ("stat_shards", c_dp), ("stat_shards_prev", c_dp), ("stats_prev", c_dp), ("aer_out", c_dp),
-        ("stat_shards_clear", c_dp), ("aer_cols", C.c_int32), ("reserved1", C.c_int32),
+        ("stat_shards_clear", c_dp), ("aer_cols", C.c_int32), ("action0", C.c_int32), ("obs_mirror", c_dp),
     ]
 
 
@@ -56,7 +56,7 @@ class ssa_closed_loop_params(C.Structure):
 
 # constants of include/ssa_hip.h
 E_INVALID, E_LAUNCH, E_UNSUPPORTED = -1, -2, -3
-ABI_VERSION = 16
+ABI_VERSION = 17
 ST_OK, ST_PREDICT_NAN, ST_PREDICT_LINALG, ST_UPDATE_NAN, ST_UPDATE_LINALG = range(5)
 OBS_AER, OBS_XYZ = 0, 1
 PROP_ELEMENTS, PROP_FG, PROP_J2_RK4 = 0, 1, 2
@@ -67,6 +67,7 @@ STAT_SHARDS = 128
 STAT_SHARD_WORDS = 16
 PROFILE_SLOTS = 1024
 LAUNCH_DEFER_FOLD = 8
+LAUNCH_INLINE_ACTION = 16
 AGENT_NAIVE_GREEDY, AGENT_VISIBLE_GREEDY, AGENT_SHANNON, AGENT_POS_ERROR, AGENT_VEL_ERROR = range(5)
 STAT_STRIDE, STAT_MAX_DPOS, STAT_CNT_LT_1E4, STAT_CNT_LT_1E7, STAT_ARGMAX_SPOS, STAT_N_FAILED, STAT_MAX_SPOS = 8, 0, 1, 2, 3, 4, 5
 

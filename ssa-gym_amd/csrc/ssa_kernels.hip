@@ -429,13 +429,15 @@ SSA_DEV void store_tile(const Tiles& t, const ssa_step_params& p, int lane, int6
             const int jj = (i * 43) >> 8;                // i / 6: the object
             const int r = 2 * i - 12 * jj;               // 0, 2, 4: x | 6, 8, 10: diag P
             double* dst = p.obs + base * 12 - 64 + 2 * lane;
-            if (r < 6) store16<NT>(dst, t.X + jj * 6 + r);
+            v2d pair;
+            if (r < 6) pair = *reinterpret_cast<const v2d*>(t.X + jj * 6 + r);
             else {
                 const double* d = t.P + jj * 36 + 7 * (r - 6);
-                const v2d pair = {d[0], d[7]};
-                if (NT) __builtin_nontemporal_store(pair, reinterpret_cast<v2d*>(dst));
-                else *reinterpret_cast<v2d*>(dst) = pair;
+                pair = v2d{d[0], d[7]};
             }
+            if (NT) __builtin_nontemporal_store(pair, reinterpret_cast<v2d*>(dst));
+            else *reinterpret_cast<v2d*>(dst) = pair;
+            if (p.obs_mirror) *reinterpret_cast<v2d*>(p.obs_mirror + base * 12 - 64 + 2 * lane) = pair;   // (e.g. host-mapped memory)
         }
         if (!SSA_SKIP(16) && lane >= 56 && lane < 60) p.status[base - 56 + lane] = t.St[lane - 56];
         if (!SSA_SKIP(8) && lane < 16) {   // metrics [E][4][m]: four 32-byte runs per tile
@@ -461,6 +463,7 @@ SSA_DEV void store_tile(const Tiles& t, const ssa_step_params& p, int lane, int6
         const double* src = sO ? t.Obs : sP ? t.P + 128 : sT ? t.T : t.X;
         const bool skip = sO ? SSA_SKIP(2) : sP ? SSA_SKIP(1) : SSA_SKIP(4);
         if (!skip && i < lim) store16<NT>(dst + 2 * i, src + 2 * i);
+        if (sO && p.obs_mirror && i < lim) store16<false>(p.obs_mirror + base * 12 + 2 * i, src + 2 * i);
     }
     if (!SSA_SKIP(16) && lane >= 12 && lane < 16) {
         const int i = lane - 12;
@@ -803,6 +806,8 @@ SSA_DEV int robust_chol_row_lds(Tiles& t, double scale, int g, int l)
     return rung;
 }
 
+// the action of env e: the word in memory, or the value in the parameter block (SSA_LAUNCH_INLINE_ACTION, one env)
+SSA_DEV int env_action(const ssa_step_params& p, int e) { return (p.launch_mask & SSA_LAUNCH_INLINE_ACTION) ? p.action0 : p.actions[e]; }
 // tix % n_time, the division (a ~25-instruction sequence on the vector unit) only when the index has actually wrapped
 SSA_DEV int time_row(int tix, int n_time)
 {
@@ -1009,7 +1014,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         act = valid ? p.actions[e] : -1;
         tix = valid ? p.env_time[e] + p.time_offset : 0;
     } else {
-        const int a0 = p.actions[0], t0 = p.env_time[0];
+        const int a0 = (p.launch_mask & SSA_LAUNCH_INLINE_ACTION) ? p.action0 : p.actions[0], t0 = p.env_time[0];
         act = valid ? a0 : -1;
         tix = valid ? t0 + p.time_offset : 0;
     }
@@ -1405,7 +1410,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     if (my_update && rec && l == 0) {
         rec[SSA_UPD_OBS_TAKEN] = taken ? 1.0 : 0.0;
         rec[SSA_UPD_VISIBLE] = visible ? 1.0 : 0.0;
-        rec[SSA_UPD_ACTION] = attempted ? (double)(ACT::late ? act : p.actions[e]) : -1.0;   // (my_update: the env's action IS this object)
+        rec[SSA_UPD_ACTION] = attempted ? (double)(ACT::late ? act : env_action(p, e)) : -1.0;   // (my_update: the env's action IS this object)
     }
     // The update is the register-pressure peak behind the propagator and only ONE wavefront of a launch runs it: whatever is
     // live across it would be spilled by EVERY wavefront.  So the values that are cheap to get again are got again behind
@@ -1419,7 +1424,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     }   // wavefronts holding a selected object
     // envs whose action selects nobody still get a cleared record (written by object 0's row)
     if (valid && p.upd && obj == (int64_t)e * p.n_obj && l == 0) {   // (object 0 of an env: one lane per env)
-      const int a_env = ACT::late ? act : p.actions[e];
+      const int a_env = ACT::late ? act : env_action(p, e);
       if (!(a_env >= 0 && interval_ok && (int64_t)a_env < p.n_obj)) {
         double* rec = p.upd + (int64_t)e * SSA_UPD_STRIDE;
         rec[SSA_UPD_OBS_TAKEN] = 0.0;
@@ -2850,8 +2855,11 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
 {
     if (!c || !p || p->n_obj <= 0 || p->n_env <= 0) return SSA_E_INVALID;
     if (!p->x_true_in || !p->x_true_out || !p->x_in || !p->x_out || !p->P_in || !p->P_out || !p->status ||
-        !p->obs || !p->metrics || !p->trans || !p->env_time || !p->actions || !p->z_noise || !p->stat_ws)
+        !p->obs || !p->metrics || !p->trans || !p->env_time || !p->z_noise || !p->stat_ws)
         return SSA_E_INVALID;
+    if (p->launch_mask & SSA_LAUNCH_INLINE_ACTION) {
+        if (p->n_env != 1) return SSA_E_INVALID;
+    } else if (!p->actions) return SSA_E_INVALID;
     if (c->obs_type != SSA_OBS_AER && c->obs_type != SSA_OBS_XYZ) return SSA_E_INVALID;
     if (p->aer_cols != 0 && p->aer_cols != 1 && p->aer_cols != 4) return SSA_E_INVALID;
     StepK k;

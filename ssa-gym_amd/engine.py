@@ -51,8 +51,12 @@ class HotPathEngine:
         # default strides for z_noise[E][n_time][m][3]
         self.zn_stride_time = self.m * 3 if zn_stride_time is None else int(zn_stride_time)
         self.zn_stride_env = self.n_time * self.m * 3 if zn_stride_env is None else int(zn_stride_env)
-        self.env_time0 = torch.zeros(self.E, dtype=torch.int32, device=d)   # per-env time origin
-        self.actions = torch.full((self.E,), -1, dtype=torch.int32, device=d)
+        # per-env time origin and action words: two views of ONE device buffer, so that a caller that refreshes both every step
+        # (the vector env) needs a single host-to-device copy
+        self.time_actions = torch.zeros(2 * self.E, dtype=torch.int32, device=d)
+        self.time_actions[self.E:] = -1
+        self.env_time0 = self.time_actions[:self.E]
+        self.actions = self.time_actions[self.E:]
         self._p = _lib.ssa_step_params()
         self._p.n_obj, self._p.n_env = self.m, self.E
         self._p.status = self.status.data_ptr()
@@ -134,11 +138,11 @@ class HotPathEngine:
         self.status.zero_()
 
     # ------------------------------------------------------------------ one step
-    def _step_params(self, slot_in, slot_out, aer_out, stats_out, upd_out, shard_set, shards_out=0, shards_clear=0, aer_cols=4):
+    def _step_params(self, slot_in, slot_out, aer_out, stats_out, upd_out, shard_set, shards_out=0, shards_clear=0, aer_cols=4, obs_mirror=0):
         """parameter block of a step between two history slots: everything but the time index, the action pointer and the
         deferred-fold hand-over is fixed per (slot pair, outputs, shard set), so the blocks are built once and cached -- a
         step then costs a handful of field stores on the host instead of twenty"""
-        key = (slot_in, slot_out, aer_out, stats_out, upd_out, shard_set, shards_out, shards_clear, aer_cols)
+        key = (slot_in, slot_out, aer_out, stats_out, upd_out, shard_set, shards_out, shards_clear, aer_cols, obs_mirror)
         ent = self._pcache.get(key)
         if ent is None:
             p = _lib.ssa_step_params()
@@ -155,6 +159,7 @@ class HotPathEngine:
             p.stat_shards_prev, p.stats_prev, p.launch_mask = 0, 0, 0
             p.stat_shards_clear = 0
             p.aer_cols = int(aer_cols)
+            p.obs_mirror = obs_mirror
             if shards_out:      # raw-shard consumer (include/ssa_hip.h: stat_shards_clear): no fold, no `stats`
                 p.stat_shards, p.stats, p.stat_shards_clear = shards_out, 0, shards_clear
             ent = (p, C.byref(p), int(p.stats or 0))
@@ -164,10 +169,13 @@ class HotPathEngine:
         return ent
 
     def launch_step(self, slot_in, slot_out, time_offset, actions_ptr=None, stream=None, aer_out=0, stats_out=0, upd_out=0,
-                    fast_stats=False, defer_fold=False, profile_slot=None, shards_out=0, shards_clear=0, aer_cols=4):
+                    fast_stats=False, defer_fold=False, profile_slot=None, shards_out=0, shards_clear=0, aer_cols=4, action=None,
+                    obs_mirror=0):
         """enqueue the step; asynchronous, no host sync.  fast_stats: statistics by the step kernel's atomics (two
         launches, no arg-max of sigma_pos).  defer_fold (with fast_stats): ONE launch -- this step's
-        statistics are folded by extra wavefronts of the NEXT deferred step, or by flush_stats()."""
+        statistics are folded by extra wavefronts of the NEXT deferred step, or by flush_stats().  action (one env): the
+        action by value in the parameter block (SSA_LAUNCH_INLINE_ACTION) instead of a word in memory; obs_mirror: a second
+        destination of the observation rows (host-mapped pinned memory: the observation reaches the host from inside the kernel)."""
         s = torch.cuda.current_stream().cuda_stream if stream is None else stream
         if shards_out:
             fast_stats, defer_fold = True, False
@@ -175,15 +183,18 @@ class HotPathEngine:
         if not defer and self._fold_pending is not None:
             self.flush_stats(s)       # a deferred step is followed by an immediate one: fold it first (same stream, in order)
         p, pref, stats_ptr = self._step_params(slot_in, slot_out, aer_out, stats_out, upd_out, self._shard_cur if fast_stats else -1,
-                                               shards_out, shards_clear, aer_cols)
+                                               shards_out, shards_clear, aer_cols, obs_mirror)
         p.time_offset = int(time_offset)
         p.actions = self._actions_ptr if actions_ptr is None else actions_ptr
+        inline = 0
+        if action is not None:
+            p.action0, inline = int(action), _lib.LAUNCH_INLINE_ACTION
         if defer and self._fold_pending is not None:
-            p.launch_mask = _lib.LAUNCH_DEFER_FOLD
+            p.launch_mask = _lib.LAUNCH_DEFER_FOLD | inline
             p.stat_shards_prev = self._shard_ptr[self._fold_pending[0]]
             p.stats_prev = self._fold_pending[1]
         else:
-            p.launch_mask = _lib.LAUNCH_DEFER_FOLD if defer else 0
+            p.launch_mask = (_lib.LAUNCH_DEFER_FOLD if defer else 0) | inline
             p.stat_shards_prev, p.stats_prev = 0, 0
         if profile_slot is None:
             rc = self._lib.ssa_env_step_f64(self._cref, pref, s)

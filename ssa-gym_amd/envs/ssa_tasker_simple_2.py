@@ -181,6 +181,10 @@ class SSA_Tasker_Env(Env):
         self._consts, _ = kernel_consts(config, self.Q, self.R, self.dt, self.obs_limit, self.obs_lla)
         self._engine = None
         self._device_rng = bool(config.get('device_rng', False))
+        self._obs_buffers = config.get('obs_buffers', 2)
+        # config['obs_device'] = True (opt-in, for policies that live on the GPU): step() returns the observation as a CUDA tensor
+        # -- a view of the device-resident history slot ('aer': of the persistent (4 m,) block) -- and nothing crosses PCIe
+        self._obs_device = bool(config.get('obs_device', False))
         # run_agent(): the persistent closed-loop kernel (one launch per chunk) unless config['closed_loop'] == 'per_step'
         self._closed_loop_persistent = config.get('closed_loop', 'persistent') != 'per_step'
         self.np_random = None
@@ -203,19 +207,26 @@ class SSA_Tasker_Env(Env):
         # host-mapped mailboxes (pinned memory is addressable from the GPU): the kernels read the action
         # from / write statistics and the update record to host memory directly, so a step needs one
         # stream synchronisation and one observation copy instead of four blocking transfers
-        self._act_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self._stats_host = torch.zeros(_lib.STAT_STRIDE, dtype=torch.float64).pin_memory()
         self._upd_host = torch.zeros(_lib.UPD_STRIDE, dtype=torch.float64).pin_memory()
-        nobs = self.m * (4 if self.obs_returned == 'aer' else 12)
-        self._obs_host = torch.zeros(nobs, dtype=torch.float64).pin_memory()
+        # The observation reaches the host FROM INSIDE the step kernel: its epilogue writes the (az, el, range, trace P) block
+        # ('aer') or a second copy of the observation rows (other modes) straight into host-mapped pinned memory, overlapped
+        # with the other wavefronts' arithmetic -- no copy-engine pass behind the kernel (1.92 MB 'flatten' vector: 44 us).
+        # 'aer' hands out ONE persistent array refreshed in place, as the reference does (:362-363); the other modes alternate
+        # between TWO pinned arrays, so the observation returned by step i stays intact until step i + 2 is taken (the reference
+        # returns a fresh copy per step; copy it if you keep it longer).  config['obs_buffers'] = k >= 2 deepens that ring.
+        aer = self.obs_returned == 'aer'
+        nobs = self.m * (4 if aer else 12)
+        nbuf = 1 if aer else max(2, int(self._obs_buffers))
+        self._obs_ring = [torch.zeros(nobs, dtype=torch.float64).pin_memory() for _ in range(nbuf)]
+        shape = (nobs,) if self.obs_returned in ('aer', 'flatten') else (self.m, 12)
+        self._obs_ring_np = [b.numpy().reshape(shape) for b in self._obs_ring]
+        self._obs_ring_ptr = [b.data_ptr() for b in self._obs_ring]
         # (numpy views and raw pointers of the mailboxes, taken once: each .numpy() / .data_ptr() costs the step a microsecond)
-        self._act_np, self._upd_np, self._stats_np = self._act_host.numpy(), self._upd_host.numpy(), self._stats_host.numpy()
-        self._act_ptr, self._upd_ptr, self._stats_ptr = self._act_host.data_ptr(), self._upd_host.data_ptr(), self._stats_host.data_ptr()
-        self._aer_ptr = self._aer_dev.data_ptr()
-        if self.obs_returned == 'aer':
-            # the reference hands out ONE persistent array, refreshed in place every step (:362-363); here that array is the
-            # pinned buffer the copy engine writes the device's (az, el, range, trace P) block into -- no host-side copy
-            self.observation = self._obs_host.numpy()
+        self._upd_np, self._stats_np = self._upd_host.numpy(), self._stats_host.numpy()
+        self._upd_ptr, self._stats_ptr = self._upd_host.data_ptr(), self._stats_host.data_ptr()
+        if aer:
+            self.observation = self._obs_ring_np[0]
         self.x_true = _History(self, e.x_true, self.m, (6,))
         self.x_filter = _History(self, e.x_filter, self.m, (6,))
         self.P_filter = _History(self, e.P_filter, self.m, (6, 6))
@@ -279,15 +290,12 @@ class SSA_Tasker_Env(Env):
         self._argmax_sigma = int(self._stats[_lib.STAT_ARGMAX_SPOS])
 
     def _obs_out(self, reset=False):
+        """the observation of the current step through the slow path (reset(), rollout(), run_agent()): a device-to-host copy"""
         e, slot = self._engine, self.i % self._engine.H
         if self.obs_returned == 'flatten':
             return e.obs[slot].cpu().numpy().reshape(-1)
         elif self.obs_returned == 'aer':
-            if reset:
-                self.aer_obs(self.observation)
-            else:
-                self.observation[:] = self._aer_dev.cpu().numpy()
-            return self.observation
+            return self.aer_obs(self.observation)
         return e.obs[slot].cpu().numpy()
 
     def step(self, a):
@@ -300,22 +308,25 @@ class SSA_Tasker_Env(Env):
         e = self._engine
         s = time.time()
         self.runtime['step prep'] += s - step_s
-        # propagate + predict + update + observations/metrics + statistics: two launches (:265-322)
+        # propagate + predict + update + observations/metrics + statistics: two launches (:265-322).  The action travels by value
+        # in the parameter block; statistics, update record and the observation are written by the kernels straight into
+        # host-mapped pinned memory: ONE stream synchronisation, no copy
         import torch
-        self._act_np[0] = int(a)
         cur = torch.cuda.current_stream()     # (looked up once per step: launch and synchronisation share it)
-        # 'aer' observations come out of the step kernel's epilogue (no extra launch)
-        e.launch_step((i - 1) % e.H, i % e.H, i, actions_ptr=self._act_ptr,
-                      aer_out=self._aer_ptr if self.obs_returned == 'aer' else 0,
-                      stats_out=self._stats_ptr, upd_out=self._upd_ptr, stream=cur.cuda_stream,
-                      fast_stats=(self.reward_type != 'shaped'))   # only 'shaped' needs argmax(sigma_pos) (:346)
         aer = self.obs_returned == 'aer'
-        src = self._aer_dev if aer else e.obs[i % e.H].reshape(-1)
-        big = (not aer) and src.numel() * 8 > (1 << 19)   # large fresh vectors: one pageable D2H beats pinned copy + host memcpy
-        if not big:
-            self._obs_host.copy_(src, non_blocking=True)    # ('aer': straight into self.observation's storage)
+        k = 0 if aer else i % len(self._obs_ring)
+        if self._obs_device:
+            e.launch_step((i - 1) % e.H, i % e.H, i, action=int(a), aer_out=self._aer_dev.data_ptr() if aer else 0,
+                          stats_out=self._stats_ptr, upd_out=self._upd_ptr, stream=cur.cuda_stream,
+                          fast_stats=(self.reward_type != 'shaped'))
+            obs_np = self._aer_dev if aer else (e.obs[i % e.H].reshape(-1) if self.obs_returned == 'flatten' else e.obs[i % e.H])
+        else:
+            e.launch_step((i - 1) % e.H, i % e.H, i, action=int(a),
+                          aer_out=self._obs_ring_ptr[0] if aer else 0, obs_mirror=0 if aer else self._obs_ring_ptr[k],
+                          stats_out=self._stats_ptr, upd_out=self._upd_ptr, stream=cur.cuda_stream,
+                          fast_stats=(self.reward_type != 'shaped'))   # only 'shaped' needs argmax(sigma_pos) (:346)
+            obs_np = self._obs_ring_np[k]
         cur.synchronize()
-        obs_np = self.observation if aer else (src.cpu().numpy() if big else self._obs_host.numpy().copy())
         rec = self._upd_np
         self._stats = self._stats_np.copy()
         self._argmax_sigma = int(self._stats[_lib.STAT_ARGMAX_SPOS])
@@ -329,10 +340,6 @@ class SSA_Tasker_Env(Env):
         if i + 1 >= self.n:
             done = True
         obs = obs_np
-        if self.obs_returned == 'aer':
-            obs = self.observation
-        elif self.obs_returned != 'flatten':
-            obs = obs.reshape(self.m, 12)
         e_t = time.time()
         self.runtime['Observations and Reward'] += e_t - t_dev
         self.runtime['step'] += e_t - step_s

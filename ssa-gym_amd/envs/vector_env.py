@@ -47,7 +47,19 @@ class SSA_Tasker_VecEnv:
         self.single_observation_space = spaces.Box(low=np.full(shp, -np.inf), high=np.full(shp, np.inf), dtype=np.float64)
         self.num_envs = self.E
         self._aer = torch.zeros((self.E * self.m, 4), dtype=torch.float64, device="cuda")
-        self._time = torch.zeros(self.E, dtype=torch.int32)
+        # host side of a step: time indices and actions leave from pinned staging (asynchronous copies), the statistics and the
+        # observation vectors arrive in host-mapped pinned memory written by the kernels themselves (the 'aer' block by the step
+        # kernel's epilogue, the observation rows as its second destination): one stream synchronisation per vector step, no
+        # device-to-host copy pass.  Two observation buffers alternate: what step k returned stays intact until step k + 2.
+        self._ta_host = torch.zeros(2 * self.E, dtype=torch.int32).pin_memory()      # [time indices | actions]: one copy per step
+        self._time_np, self._act_np = self._ta_host.numpy()[:self.E], self._ta_host.numpy()[self.E:]
+        self._stats_host = torch.zeros((self.E, _lib.STAT_STRIDE), dtype=torch.float64).pin_memory()
+        self._stats_np = self._stats_host.numpy()
+        per = self.m * (4 if self.obs_returned == 'aer' else 12)
+        oshape = (self.E, self.m, 12) if self.obs_returned not in ('aer', 'flatten') else (self.E, per)
+        self._obs_ring = [torch.zeros(self.E * per, dtype=torch.float64).pin_memory() for _ in range(2)]
+        self._obs_ring_np = [b.numpy().reshape(oshape) for b in self._obs_ring]
+        self._obs_ring_ptr = [b.data_ptr() for b in self._obs_ring]
         self.i = np.zeros(self.E, dtype=np.int64)       # per-env step index
         self.tick = 0
         self.rewards_sum = np.zeros(self.E)
@@ -109,13 +121,18 @@ class SSA_Tasker_VecEnv:
         argmax_prev = self._argmax_prev
         self.i += 1
         self.tick += 1
-        self._time[:] = torch.as_tensor(self.i.astype(np.int32))
-        e.env_time0.copy_(self._time)
-        e.set_actions(actions)
+        self._time_np[:] = self.i
+        self._act_np[:] = actions
+        e.time_actions.copy_(self._ta_host, non_blocking=True)
         sin, sout = (self.tick - 1) % 2, self.tick % 2
-        e.launch_step(sin, sout, 0, aer_out=self._aer.data_ptr() if self.obs_returned == 'aer' else 0,
-                      fast_stats=(self.reward_type != 'shaped'))
-        st = self._refresh_stats(sout)
+        aer = self.obs_returned == 'aer'
+        k = self.tick % 2
+        cur = torch.cuda.current_stream()
+        e.launch_step(sin, sout, 0, aer_out=self._obs_ring_ptr[k] if aer else 0, obs_mirror=0 if aer else self._obs_ring_ptr[k],
+                      stats_out=self._stats_host.data_ptr(), stream=cur.cuda_stream, fast_stats=(self.reward_type != 'shaped'))
+        cur.synchronize()
+        st = self._stats_np.copy()
+        self._argmax_prev = st[:, _lib.STAT_ARGMAX_SPOS].astype(np.int64)
         mx = st[:, _lib.STAT_MAX_DPOS]
         rewards = np.zeros(self.E)
         dones = np.zeros(self.E, dtype=bool)
@@ -135,13 +152,14 @@ class SSA_Tasker_VecEnv:
             rewards[lost] = 0.0
             dones = lost | won | last
         self.rewards_sum += rewards
-        obs = self._obs(sout)
+        obs = self._obs_ring_np[k]
         infos = [{} for _ in range(self.E)]
         if dones.any():   # auto-reset in place; the returned observation of a finished env is its new first one
-            for k in np.where(dones)[0]:
-                infos[k]['terminal_observation'] = obs[k].copy()
-                self._reset_env(int(k), sout)
-            self._refresh_stats(sout)
+            for d in np.where(dones)[0]:
+                infos[d]['terminal_observation'] = obs[d].copy()
+                self._reset_env(int(d), sout)
+            st_dev = self._eng.stats[sout].cpu().numpy()          # (the reset wrote the new envs' statistics on the device)
+            self._argmax_prev[dones] = st_dev[dones, _lib.STAT_ARGMAX_SPOS].astype(np.int64)
             obs = self._obs(sout, reset=(self.obs_returned == 'aer'))
         if self.obs_returned != 'flatten':
             rewards = np.where(np.isfinite(rewards), rewards, 0.5)

@@ -561,3 +561,28 @@ def test_closed_loop_beyond_the_resident_capacity_takes_the_per_step_launches(en
     env = envs.make(config=cfg)
     obs, acts, rews, dones = env.run_agent("agent_visible_greedy", 6)
     assert len(acts) == 6 and env.i == 6 and obs.shape == (4 * 20484,) and np.isfinite(rews).all()
+
+
+@pytest.mark.parametrize("mode", ['flatten', 'aer', 'matrix'])
+def test_observation_paths_agree(envs, mode):
+    """the observation step() returns -- written by the step kernel into host-mapped pinned memory (two alternating arrays; 'aer':
+    the one persistent array of the reference, :362-363) -- equals the device-resident history, the opt-in CUDA-tensor form
+    (config['obs_device']) equals both, and an observation stays intact for one more step."""
+    import torch
+    cfg = dict(envs.env_config)
+    cfg.update(rso_count=203, steps=30, reward_type='trinary', obs_returned=mode, seed=6, history='full')     # (203: a ragged last tile)
+    host = envs.make(config=cfg)
+    dev = envs.make(config=dict(cfg, obs_device=True))
+    prev = None
+    for k in range(1, 9):
+        o, r, d, _ = host.step(k)
+        od, rd, dd, _ = dev.step(k)
+        assert isinstance(od, torch.Tensor) and od.is_cuda and isinstance(o, np.ndarray)
+        want = host.obs[k].reshape(-1) if mode == 'flatten' else (host.aer_obs(np.zeros(4 * 203)) if mode == 'aer' else host.obs[k])
+        assert o.shape == want.shape and np.array_equal(o, want)
+        assert np.array_equal(od.cpu().numpy().reshape(want.shape), want) and r == rd and d == dd
+        if prev is not None and mode != 'aer':
+            assert np.array_equal(prev[0], prev[1])          # the previous step's array has not been touched by this step
+        prev = (o, o.copy())
+    if mode == 'aer':
+        assert o is host.observation
