@@ -380,7 +380,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--objects", type=int, default=20000, help="objects per GPU")
-    ap.add_argument("--propagator", default="fg", choices=["fg", "elements", "j2"],
+    ap.add_argument("--propagator", default="fg", choices=["fg", "elements", "j2", "hybrid"],
                     help="fg / elements: two-body Farnocchia (parity-checked); j2: J2+RK4 extension (no reference counterpart)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rollout", type=int, default=60,
@@ -545,7 +545,7 @@ def main():
             except Exception:  # noqa: BLE001
                 traffic = None
         fp64_tflops = FP64_FLOP_PER_OBJECT_STEP * m / (kern_ms * 1e-3) / 1e12
-        roof = {"bound": "hbm", "kernel": "ssa::step_fast_kernel<%d>" % {"elements": 0, "fg": 1, "j2": 2}[args.propagator],
+        roof = {"bound": "hbm", "kernel": "ssa::step_fast_kernel<%d>" % {"elements": 0, "fg": 1, "j2": 2, "hybrid": 3}[args.propagator],
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "kernel_ms": round(kern_ms, 5), "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": nl,
@@ -588,7 +588,7 @@ def main():
     legs = {}
     if rank == 0 and world == 1 and not use_dist and not args.no_legs:
         Kl, Wl = min(max(K, 200), 1000), min(max(W, 50), 100)   # (legs: at least 200 steps per timed block)
-        for name, kw in (("j2", dict(propagator="j2")), ("elements", dict(propagator="elements")),
+        for name, kw in (("j2", dict(propagator="j2")), ("elements", dict(propagator="elements")), ("hybrid", dict(propagator="hybrid")),
                          ("resample", dict(propagator=args.propagator, resample=True))):
             if name == args.propagator:
                 continue
@@ -621,7 +621,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "ssa_tasker_simple-v2 hot path: %d objects/GPU x %d GPU, %s + "
                                    "UKF predict (13 sigma points) + 1 az-el-range update/step%s" %
-                                   (m, world, {"fg": "two-body Farnocchia (fg)", "elements": "two-body Farnocchia (elements)",
+                                   (m, world, {"fg": "two-body Farnocchia (fg)", "elements": "two-body Farnocchia (elements)", "hybrid": "two-body Farnocchia (hybrid)",
                                                "j2": "two-body + J2 RK4 propagator (EXTENSION, no reference counterpart; 4 sub-steps)"}[args.propagator],
                                     (", sharded env with one RCCL all-gather per step of %s + reward statistics" % ("per-object trace P (BASELINE config 4)" if obs_cols == 1 else "the (az,el,range,trP) observation block")) if use_dist else ""),
                        "objects_per_gpu": m, "objects_total": m * world, "alpha": 1e-4, "dt_s": 20.0,

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SSA_ABI_VERSION 17
+#define SSA_ABI_VERSION 18
 
 /* error codes */
 #define SSA_OK 0
@@ -54,11 +54,20 @@ extern "C" {
 #define SSA_OBS_XYZ 1 /* hx_xyz + mean_xyz + residual_xyz/np.subtract (dynamics.py:207,276,271) */
 
 /* two-body propagator variant; both evaluate envs/farnocchia.py:1010 farnocchia() */
-#define SSA_PROP_ELEMENTS 0 /* rv2coe -> delta_t_from_nu -> nu_from_delta_t -> coe2rv, operation by operation */
-#define SSA_PROP_FG 1       /* the same branches reduced algebraically to Lagrange f,g (elliptic / hyperbolic
-                               anomaly difference; universal variables in the near-parabolic band) */
+#define SSA_PROP_ELEMENTS 0 /* rv2coe -> delta_t_from_nu -> nu_from_delta_t -> coe2rv, operation by operation; with
+                               SSA_FLAG_REFERENCE_COV the BEHAVIOUR-FAITHFUL variant (the reference's episode-level filter failures) */
+#define SSA_PROP_FG 1       /* every conic branch of farnocchia() through ONE equation: Kepler's equation in universal variables
+                               (Stumpff series + Halley steps; closed-form Stumpff functions + Laguerre-Conway iterations for
+                               long steps), state by the Lagrange coefficients f, g.  More accurate than the reference's chain on
+                               diverged (hyperbolic) states, which is why its filters do not fail where the reference's do */
 #define SSA_PROP_J2_RK4 2   /* EXTENSION without reference counterpart: two-body + J2 zonal
                                acceleration, classical RK4 with ssa_consts.rk4_substeps sub-steps per dt */
+
+#define SSA_PROP_HYBRID 3   /* the behaviour-faithful variant at speed: the universal-variable series solver of SSA_PROP_FG on
+                               strong-elliptic states (ecc < 1 - 1e-2, farnocchia.py:871: there the reference's chain agrees with it
+                               to 1e-14), the reference's own formulas -- branch by branch, NaN by NaN -- on every other state, which
+                               is where its filters go wrong.  With SSA_FLAG_REFERENCE_COV the same episode-level failure statistics
+                               as SSA_PROP_ELEMENTS and the oracle (tests/test_episode_failures.py) */
 
 /* flags of ssa_step_params.flags */
 #define SSA_FLAG_RESAMPLE 1u /* predict() ends by redrawing the sigma points from the prior, for every filter (the

@@ -56,10 +56,10 @@ class ssa_closed_loop_params(C.Structure):
 
 # constants of include/ssa_hip.h
 E_INVALID, E_LAUNCH, E_UNSUPPORTED = -1, -2, -3
-ABI_VERSION = 17
+ABI_VERSION = 18
 ST_OK, ST_PREDICT_NAN, ST_PREDICT_LINALG, ST_UPDATE_NAN, ST_UPDATE_LINALG = range(5)
 OBS_AER, OBS_XYZ = 0, 1
-PROP_ELEMENTS, PROP_FG, PROP_J2_RK4 = 0, 1, 2
+PROP_ELEMENTS, PROP_FG, PROP_J2_RK4, PROP_HYBRID = 0, 1, 2, 3
 FLAG_RESAMPLE = 1
 FLAG_REFERENCE_COV = 2
 UPD_STRIDE, UPD_OBS_TAKEN, UPD_Z_TRUE, UPD_Y, UPD_S, UPD_SIGMAS_H, UPD_VISIBLE, UPD_ACTION = 64, 0, 1, 4, 7, 16, 55, 56

@@ -101,7 +101,7 @@ __device__ static double nu_to_E(double nu, double ecc) { return 2.0 * atan(sqrt
 __device__ static double F_to_nu(double F, double ecc) { return 2.0 * atan(sqrt((ecc + 1.0) / (ecc - 1.0)) * tanh(F / 2.0)); }
 __device__ static double nu_to_F(double nu, double ecc) { return 2.0 * atanh(sqrt((ecc - 1.0) / (ecc + 1.0)) * tan(nu / 2.0)); }
 
-__device__ static double delta_t_from_nu(double nu, double ecc, double k, double q)
+__device__ __forceinline__ static double delta_t_from_nu(double nu, double ecc, double k, double q)
 {
     const double delta = 1e-2;
     double M, n;
@@ -148,7 +148,7 @@ __device__ static double M_to_E(double M, double ecc)
     double E0 = (ecc < 0.8) ? M : PI * ((M > 0.0) - (M < 0.0));
     return newton(false, E0, M, ecc, 50);
 }
-__device__ static double nu_from_delta_t(double delta_t, double ecc, double k, double q)
+__device__ __forceinline__ static double nu_from_delta_t(double delta_t, double ecc, double k, double q)
 {
     const double delta = 1e-2;
     double q3 = q * q * q;
@@ -255,6 +255,152 @@ __device__ __noinline__ Vec6 kepler_general_tagged(Vec6 x, double tof)
     kepler_general_impl(x.v, tof, o.v, nullptr);
     return o;
 }
+// ------------------------------------------------------------------------------------------
+// SSA_PROP_HYBRID: the reference's BRANCHES where they matter, at a fraction of their cost.
+// What makes the reference lose filters late in an episode is (a) the cancellation in its covariance sum
+// (SSA_FLAG_REFERENCE_COV) acting on (b) priors that have left the strong-elliptic regime, which farnocchia() then propagates
+// through its hyperbolic / near-parabolic formulas -- tens of metres off for such states.  On strong-elliptic
+// states its chain and the universal-variable solver agree to 1e-14, so there the hybrid runs the series solver of
+// SSA_PROP_FG; every other sigma point goes through the reference's formulas, branch by branch and NaN by NaN as
+// kepler_general_impl above, but with this file's fast primitives (atan2_fast, sincos_fast, one exponential for sinh AND
+// cosh in the hyperbolic Newton loop) instead of libm -- the complete restatement costs ~3 000 vector instructions per
+// call, four times the whole SSA_PROP_FG step, and late in an episode most wavefronts hold a diverged sigma point.
+// Episode-level failure statistics: as SSA_PROP_ELEMENTS / the oracle (tests/test_episode_failures.py).
+namespace genf {
+__device__ static double F_to_nu(double F, double ecc)
+{
+    double sh, chm1;
+    sinh_coshm1(F, sh, chm1);
+    return 2.0 * atan2_fast(sqrt_fast(div_fast(ecc + 1.0, ecc - 1.0)) * div_fast(sh, chm1 + 2.0), 1.0);   // tanh(F/2) = sinh F / (cosh F + 1)
+}
+__device__ static double nu_to_F(double nu, double ecc)
+{
+    double s, c;
+    sincos_fast(nu, s, c);
+    const double x = sqrt_fast(div_fast(ecc - 1.0, ecc + 1.0)) * div_fast(s, 1.0 + c);     // tan(nu/2) = sin nu / (1 + cos nu)
+    return log(div_fast(1.0 + x, 1.0 - x));                                                  // 2 atanh(x)
+}
+// newton() on e sinh F - F - M (farnocchia.py:337-353: step tolerance 1.48e-8, 100 iterations, NaN when it gives up)
+__device__ static double newton_hyp(double x0, double M, double ecc)
+{
+    double p0 = x0, res = __builtin_nan("");
+    bool done = false;
+    for (int i = 0; i < 100; ++i) {
+        double sh, chm1;
+        sinh_coshm1(p0, sh, chm1);
+        const double fval = (ecc * sh - p0) - M;
+        const double fder = ecc * (chm1 + 1.0) - 1.0;
+        const double p = p0 - div_fast(fval, fder);
+        if (!done && fabs(p - p0) < NEWTON_TOL) { res = p; done = true; }
+        p0 = p;
+        if (!(fabs(p0) <= 1.79769313486231570e308)) done = true;      // (inf / NaN iterate: it will never converge)
+        if (__ballot(!done) == 0ull) break;
+    }
+    return res;
+}
+}  // namespace genf
+// (the rare bands -- near-parabolic, parabolic, elliptic beyond the series -- as a call of their own: inlined they pushed
+// the whole function past the step kernels' 96 registers)
+template <int TAG>
+__device__ __noinline__ double kepler_band_nu(double nu, double ecc, double q, double tof)
+{
+    const double dt0 = gen::delta_t_from_nu(nu, ecc, MU, q);
+    return gen::nu_from_delta_t(dt0 + tof, ecc, MU, q);
+}
+template <int TAG>
+SSA_DEV Vec6 kepler_general_fast_impl(Vec6 xin, double tof)
+{
+    const double tol = 1e-8;
+    const double* r = xin.v;
+    const double* v = xin.v + 3;
+    Vec6 outv;
+    double h[3] = {r[1] * v[2] - r[2] * v[1], r[2] * v[0] - r[0] * v[2], r[0] * v[1] - r[1] * v[0]};
+    double n[3] = {-h[1], h[0], 0.0};
+    const double inv_mu = 1.0 / MU;
+    double rn = sqrt_fast(dot3(r, r)), vv = dot3(v, v), rv = dot3(r, v);
+    double c1 = vv - div_fast(MU, rn);
+    double e[3] = {(c1 * r[0] - rv * v[0]) * inv_mu, (c1 * r[1] - rv * v[1]) * inv_mu, (c1 * r[2] - rv * v[2]) * inv_mu};
+    double ecc = sqrt_fast(dot3(e, e));
+    double p = dot3(h, h) * inv_mu;
+    double hn = sqrt(dot3(h, h));
+    const double inv_hn = rcp_nr(hn);
+    double inc = acos(h[2] / hn);        // (as rv2coe_elliptic: the equatorial test needs the correctly rounded quotient)
+    bool circular = ecc < tol, equatorial = fabs(inc) < tol;
+    double raan, argp, nu;
+    if (equatorial && !circular) {
+        raan = 0.0;
+        argp = mod_2pi(atan2_fast(e[1], e[0]));
+        double t[3] = {e[1] * r[2] - e[2] * r[1], e[2] * r[0] - e[0] * r[2], e[0] * r[1] - e[1] * r[0]};
+        nu = atan2_fast(dot3(h, t) * inv_hn, dot3(r, e));
+    } else if (!equatorial && circular) {
+        raan = mod_2pi(atan2_fast(n[1], n[0]));
+        argp = 0.0;
+        double t[3] = {h[1] * n[2] - h[2] * n[1], h[2] * n[0] - h[0] * n[2], h[0] * n[1] - h[1] * n[0]};
+        nu = atan2_fast(dot3(r, t) * inv_hn, dot3(r, n));
+    } else if (equatorial && circular) {
+        raan = 0.0;
+        argp = 0.0;
+        nu = mod_2pi(atan2_fast(r[1], r[0]));
+    } else {
+        double a = div_fast(p, 1.0 - ecc * ecc);
+        double ka = MU * a;
+        if (a > 0.0) {
+            double e_se = rv * rsqrt_nr(ka);
+            double e_ce = rn * vv * inv_mu - 1.0;
+            double sh, ch;
+            sincos_fast(0.5 * atan2_fast(e_se, e_ce), sh, ch);
+            nu = 2.0 * atan2_fast(sqrt_fast(div_fast(1.0 + ecc, 1.0 - ecc)) * div_fast(sh, ch), 1.0);
+        } else {
+            double e_sh = rv * rsqrt_nr(-ka);
+            double e_ch = rn * vv * inv_mu - 1.0;
+            nu = genf::F_to_nu(0.5 * log(div_fast(e_ch + e_sh, e_ch - e_sh)), ecc);
+        }
+        raan = mod_2pi(atan2_fast(n[1], n[0]));
+        double t[3] = {h[1] * n[2] - h[2] * n[1], h[2] * n[0] - h[0] * n[2], h[0] * n[1] - h[1] * n[0]};
+        double px = dot3(r, n), py = dot3(r, t) * inv_hn;
+        argp = mod_2pi(atan2_fast(py, px) - nu);
+    }
+    nu = wrap_pi(nu);
+    double q = div_fast(p, 1.0 + ecc);
+    double nu1;
+    if (ecc > 1.0 + 1e-2) {   // the strong-hyperbolic branch (farnocchia.py:909-912, :1001-1004): where a diverged filter lives
+        double sn, cn;
+        sincos_fast(nu, sn, cn);
+        if (1.0 + ecc * cn < 0.0) nu1 = __builtin_nan("");          // (:885-888: beyond the asymptote)
+        else {
+            const double F0 = genf::nu_to_F(nu, ecc);
+            double sh, chm1;
+            sinh_coshm1(F0, sh, chm1);
+            const double M0 = ecc * sh - F0;
+            const double em1 = ecc - 1.0;
+            const double nmm = sqrt_fast(div_fast(MU * em1 * em1 * em1, q * q * q));
+            const double M = nmm * (div_fast(M0, nmm) + tof);
+            const double me = div_fast(M, ecc);
+            const double F = genf::newton_hyp(log(me + sqrt_fast(me * me + 1.0)), M, ecc);   // asinh(M / e)
+            nu1 = genf::F_to_nu(F, ecc);
+        }
+    } else {                  // elliptic / parabolic / near-parabolic bands: the complete restatement
+        nu1 = kepler_band_nu<TAG>(nu, ecc, q, tof);
+    }
+    coe2rv(p, ecc, inc, raan, argp, nu1, outv.v);
+    return outv;
+}
+__device__ __noinline__ Vec6 kepler_general_fast_v(Vec6 x, double tof) { return kepler_general_fast_impl<0>(x, tof); }
+// the step kernels' own instance (inherits their register budget, see kepler_general_tagged)
+template <int TAG>
+__device__ __noinline__ Vec6 kepler_general_fast_tagged(Vec6 x, double tof) { return kepler_general_fast_impl<TAG>(x, tof); }
+// the hybrid's lane-level choice: true = the series solver's result stands (strong-elliptic state inside its domain)
+SSA_DEV bool kepler_hybrid_fast(const double* s, double tof, double* o)
+{
+    const double rr = dot3(s, s), vv = dot3(s + 3, s + 3), rv = dot3(s, s + 3);
+    const double c1 = vv - MU * rsqrt_nr(rr);
+    const double ex = c1 * s[0] - rv * s[3], ey = c1 * s[1] - rv * s[4], ez = c1 * s[2] - rv * s[5];
+    const double e2 = (ex * ex + ey * ey + ez * ez) * (1.0 / (MU * MU));
+    bool handled;
+    const bool ok = kepler_uv_fast(s, tof, o, handled);
+    return ok && (e2 < (1.0 - 1e-2) * (1.0 - 1e-2));          // (farnocchia.py:871: ecc < 1 - delta)
+}
+
 __device__ __noinline__ Vec8 kepler_general_diag_v(Vec6 x, double tof, Vec6* out)
 {
     Vec8 d;
@@ -877,7 +1023,9 @@ __device__ unsigned long long g_cl_trace[8192 * 16];
 #endif
 #ifdef SSA_TRACE   // diagnostic build only (build_ablate/wave_timeline.py): per-wave phase timestamps, 100 MHz wall clock
 __device__ unsigned long long g_trace[16384 * 16];
-#define SSA_TR(k) do { if (lane == 0 && tile < 16384) g_trace[tile * 16 + (k)] = wall_clock64(); } while (0)
+// (the FIRST ACTIVE lane stamps: markers 10-14 sit inside the update's row-divergent code, where lane 0 is active only when the
+// selected object is the tile's first)
+#define SSA_TR(k) do { if (lane == __builtin_amdgcn_readfirstlane(lane) && tile < 16384) g_trace[tile * 16 + (k)] = wall_clock64(); } while (0)
 #elif defined(SSA_TRUNC)   // diagnostic build only (build_ablate/trunc_counters.sh): the wave ends at marker SSA_TRUNC, so that the
 #define SSA_TR(k) do { if ((k) == SSA_TRUNC) return; } while (0)   // PMC instruction counts of successive builds difference into stages
 #else
@@ -1095,10 +1243,24 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
             const J2Params jq = {C.j2, C.r_eq, C.rk4_substeps};
             kep_ok = propagate_j2_rk4(s, C.dt, jq, o);
         } else {
+            if (PROP == 3) kep_ok = kepler_hybrid_fast(s, C.dt, o);
+            else
             kep_ok = kepler_step_fast<PROP == 2 ? 1 : PROP, 1>(s, C.dt, o);
         }
 #endif
-        if (PROP != 0) {
+        if (PROP == 3) {
+            if (__any(!kep_ok)) {   // sigma points outside the strong-elliptic regime: the reference's branches (whole-wave branch)
+                __builtin_amdgcn_s_setprio(3);
+                if (!kep_ok) {
+                    Vec6 si;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) si.v[c] = s[c];
+                    Vec6 oo = kepler_general_fast_tagged<1>(si, C.dt);
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) o[c] = oo.v[c];
+                }
+            }
+        } else if (PROP != 0) {
             // SSA_PROP_FG / J2: the solvers cover every conic; they decline only NaN / degenerate input or a
             // non-converging iteration, which IS a NaN result (farnocchia.py:353) -> 'predict returned nan'
             if (__any(!kep_ok)) {   // (whole-wave branch: twelve selects on the common path otherwise)
@@ -1877,6 +2039,30 @@ __global__ void propagate_kernel(const double* __restrict__ xin, double* __restr
 #pragma unroll
     for (int c = 0; c < 6; ++c) x[c] = xin[ii * 6 + c];
     kepler_step<PROP>(x, dt, o);
+    if (ok) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) xout[i * 6 + c] = o[c];
+    }
+}
+__global__ void propagate_hybrid_kernel(const double* __restrict__ xin, double* __restrict__ xout, int64_t n, double dt)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool ok = i < n;
+    int64_t ii = ok ? i : 0;  // keep the wave convergent for the __all() in the solver loops
+    double x[6], o[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) x[c] = xin[ii * 6 + c];
+    const bool fast = kepler_hybrid_fast(x, dt, o);
+    if (__any(!fast)) {
+        if (!fast) {
+            Vec6 si;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) si.v[c] = x[c];
+            Vec6 oo = kepler_general_fast_v(si, dt);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) o[c] = oo.v[c];
+        }
+    }
     if (ok) {
 #pragma unroll
         for (int c = 0; c < 6; ++c) xout[i * 6 + c] = o[c];
@@ -2885,7 +3071,7 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
     StatAcc* parts = (StatAcc*)p->stat_ws;
     hipStream_t s = (hipStream_t)stream;
     const unsigned mask = (p->launch_mask & 7u) ? (p->launch_mask & 7u) : 7u;   // diagnostic: time one launch alone
-    if (c->propagator != SSA_PROP_FG && c->propagator != SSA_PROP_ELEMENTS && c->propagator != SSA_PROP_J2_RK4) return SSA_E_INVALID;
+    if (c->propagator != SSA_PROP_FG && c->propagator != SSA_PROP_ELEMENTS && c->propagator != SSA_PROP_J2_RK4 && c->propagator != SSA_PROP_HYBRID) return SSA_E_INVALID;
     if (c->propagator == SSA_PROP_J2_RK4 && (c->rk4_substeps < 1 || c->rk4_substeps > 4096)) return SSA_E_INVALID;
     const int prop = c->propagator;
     if (mask & 1u) {   // (ev0, ev1: dispatch timestamps of this kernel for ssa_env_step_profiled_f64, else null)
@@ -2893,10 +3079,12 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
         if (per_wave == 1) {
             if (prop == SSA_PROP_FG) hipExtLaunchKernelGGL((step_fast_kernel<1, false>), grid, block, 0, s, ev0, ev1, 0, nt, nwork, p->P_in, p->x_in, p->x_true_in, p->status, k);
             else if (prop == SSA_PROP_ELEMENTS) hipExtLaunchKernelGGL((step_fast_kernel<0, false>), grid, block, 0, s, ev0, ev1, 0, nt, nwork, p->P_in, p->x_in, p->x_true_in, p->status, k);
+            else if (prop == SSA_PROP_HYBRID) hipExtLaunchKernelGGL((step_fast_kernel<3, false>), grid, block, 0, s, ev0, ev1, 0, nt, nwork, p->P_in, p->x_in, p->x_true_in, p->status, k);
             else hipExtLaunchKernelGGL((step_fast_kernel<2, false>), grid, block, 0, s, ev0, ev1, 0, nt, nwork, p->P_in, p->x_in, p->x_true_in, p->status, k);
         } else {
             if (prop == SSA_PROP_FG) hipExtLaunchKernelGGL((step_fast_kernel<1, true>), grid, block, 0, s, ev0, ev1, 0, nt, nwork, p->P_in, p->x_in, p->x_true_in, p->status, k);
             else if (prop == SSA_PROP_ELEMENTS) hipExtLaunchKernelGGL((step_fast_kernel<0, true>), grid, block, 0, s, ev0, ev1, 0, nt, nwork, p->P_in, p->x_in, p->x_true_in, p->status, k);
+            else if (prop == SSA_PROP_HYBRID) hipExtLaunchKernelGGL((step_fast_kernel<3, true>), grid, block, 0, s, ev0, ev1, 0, nt, nwork, p->P_in, p->x_in, p->x_true_in, p->status, k);
             else hipExtLaunchKernelGGL((step_fast_kernel<2, true>), grid, block, 0, s, ev0, ev1, 0, nt, nwork, p->P_in, p->x_in, p->x_true_in, p->status, k);
         }
     }
@@ -2909,6 +3097,7 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
     if (mask & 2u) {
         if (prop == SSA_PROP_FG) hipLaunchKernelGGL(step_post_kernel<1>, dim3(nparts, p->n_env), dim3(POST_T), 0, s, k, parts, nparts);
         else if (prop == SSA_PROP_ELEMENTS) hipLaunchKernelGGL(step_post_kernel<0>, dim3(nparts, p->n_env), dim3(POST_T), 0, s, k, parts, nparts);
+        else if (prop == SSA_PROP_HYBRID) hipLaunchKernelGGL(step_post_kernel<3>, dim3(nparts, p->n_env), dim3(POST_T), 0, s, k, parts, nparts);
         else hipLaunchKernelGGL(step_post_kernel<2>, dim3(nparts, p->n_env), dim3(POST_T), 0, s, k, parts, nparts);
     }
     // folds the per-block statistics
@@ -2948,7 +3137,7 @@ int ssa_env_rollout_f64(const ssa_consts* c, const ssa_step_params* p, const ssa
         return SSA_E_INVALID;
     if (!p->status || !p->trans || !p->env_time || !p->z_noise) return SSA_E_INVALID;
     if (c->obs_type != SSA_OBS_AER && c->obs_type != SSA_OBS_XYZ) return SSA_E_INVALID;
-    if (c->propagator != SSA_PROP_FG && c->propagator != SSA_PROP_ELEMENTS && c->propagator != SSA_PROP_J2_RK4) return SSA_E_INVALID;
+    if (c->propagator != SSA_PROP_FG && c->propagator != SSA_PROP_ELEMENTS && c->propagator != SSA_PROP_J2_RK4 && c->propagator != SSA_PROP_HYBRID) return SSA_E_INVALID;
     if (c->propagator == SSA_PROP_J2_RK4 && (c->rk4_substeps < 1 || c->rk4_substeps > 4096)) return SSA_E_INVALID;
     const int64_t total = (int64_t)p->n_env * p->n_obj;
     if (total >= ((int64_t)1 << 31)) return SSA_E_INVALID;
@@ -2964,6 +3153,7 @@ int ssa_env_rollout_f64(const ssa_consts* c, const ssa_step_params* p, const ssa
     hipStream_t s = (hipStream_t)stream;
     if (c->propagator == SSA_PROP_FG) hipLaunchKernelGGL(rollout_kernel<1>, dim3(nwork), dim3(64), 0, s, rk, (int)ntiles, nwork);
     else if (c->propagator == SSA_PROP_ELEMENTS) hipLaunchKernelGGL(rollout_kernel<0>, dim3(nwork), dim3(64), 0, s, rk, (int)ntiles, nwork);
+    else if (c->propagator == SSA_PROP_HYBRID) hipLaunchKernelGGL(rollout_kernel<3>, dim3(nwork), dim3(64), 0, s, rk, (int)ntiles, nwork);
     else hipLaunchKernelGGL(rollout_kernel<2>, dim3(nwork), dim3(64), 0, s, rk, (int)ntiles, nwork);
     hipLaunchKernelGGL(rollout_fold_kernel, dim3(r->n_steps, p->n_env), dim3(64), 0, s, (unsigned long long*)r->stat_shards, r->stats_ring,
                        p->n_env, r->n_steps, r->slot_out, r->history);
@@ -2979,12 +3169,13 @@ int64_t ssa_closed_loop_workspace_bytes(int64_t n_obj, int32_t n_env)
 // wavefronts of closed_loop_kernel<prop> the device holds at once (the runtime's occupancy figure x compute units)
 static int64_t closed_loop_capacity(int prop)
 {
-    static int64_t cached[3] = {0, 0, 0};
+    static int64_t cached[4] = {0, 0, 0, 0};
     if (cached[prop] <= 0) {
         int per_cu = 0;
         hipError_t e;
         if (prop == SSA_PROP_FG) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, closed_loop_kernel<1>, 64, 0);
         else if (prop == SSA_PROP_ELEMENTS) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, closed_loop_kernel<0>, 64, 0);
+        else if (prop == SSA_PROP_HYBRID) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, closed_loop_kernel<3>, 64, 0);
         else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, closed_loop_kernel<2>, 64, 0);
         if (e != hipSuccess || per_cu <= 0) return 0;
         cached[prop] = (int64_t)per_cu * device_cu_count();
@@ -3000,7 +3191,7 @@ int ssa_env_closed_loop_f64(const ssa_consts* c, const ssa_step_params* p, const
     if (!p->status || !p->trans || !p->env_time || !p->z_noise) return SSA_E_INVALID;
     if (r->agent < SSA_AGENT_NAIVE_GREEDY || r->agent > SSA_AGENT_VEL_ERROR) return SSA_E_INVALID;
     if (c->obs_type != SSA_OBS_AER && c->obs_type != SSA_OBS_XYZ) return SSA_E_INVALID;
-    if (c->propagator != SSA_PROP_FG && c->propagator != SSA_PROP_ELEMENTS && c->propagator != SSA_PROP_J2_RK4) return SSA_E_INVALID;
+    if (c->propagator != SSA_PROP_FG && c->propagator != SSA_PROP_ELEMENTS && c->propagator != SSA_PROP_J2_RK4 && c->propagator != SSA_PROP_HYBRID) return SSA_E_INVALID;
     if (c->propagator == SSA_PROP_J2_RK4 && (c->rk4_substeps < 1 || c->rk4_substeps > 4096)) return SSA_E_INVALID;
     if (p->n_env != 1) return SSA_E_UNSUPPORTED;
     const int64_t ntiles = (p->n_obj + OBJ_PER_WAVE - 1) / OBJ_PER_WAVE;
@@ -3020,6 +3211,7 @@ int ssa_env_closed_loop_f64(const ssa_consts* c, const ssa_step_params* p, const
     const dim3 grid((unsigned)(nwork + L.ng + 1));
     if (c->propagator == SSA_PROP_FG) hipLaunchKernelGGL(closed_loop_kernel<1>, grid, dim3(64), 0, s, lk, nwork, nwork);
     else if (c->propagator == SSA_PROP_ELEMENTS) hipLaunchKernelGGL(closed_loop_kernel<0>, grid, dim3(64), 0, s, lk, nwork, nwork);
+    else if (c->propagator == SSA_PROP_HYBRID) hipLaunchKernelGGL(closed_loop_kernel<3>, grid, dim3(64), 0, s, lk, nwork, nwork);
     else hipLaunchKernelGGL(closed_loop_kernel<2>, grid, dim3(64), 0, s, lk, nwork, nwork);
     return launch_status();
 }
@@ -3059,6 +3251,7 @@ int ssa_propagate_f64(const double* x_in, double* x_out, int64_t n, double dt, i
     hipStream_t s = (hipStream_t)stream;
     if (propagator == SSA_PROP_FG) hipLaunchKernelGGL(propagate_kernel<1>, dim3(nblk(n, 64)), dim3(64), 0, s, x_in, x_out, n, dt);
     else if (propagator == SSA_PROP_ELEMENTS) hipLaunchKernelGGL(propagate_kernel<0>, dim3(nblk(n, 64)), dim3(64), 0, s, x_in, x_out, n, dt);
+    else if (propagator == SSA_PROP_HYBRID) hipLaunchKernelGGL(propagate_hybrid_kernel, dim3(nblk(n, 64)), dim3(64), 0, s, x_in, x_out, n, dt);
     else return SSA_E_INVALID;
     return launch_status();
 }

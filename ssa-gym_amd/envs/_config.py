@@ -23,7 +23,7 @@ def resolve_kernel_variant(config):
     if fx_id != ("fx", "farnocchia"):
         raise NotImplementedError("fx %r has no fused kernel" % (config['fx'],))
     propagator = config.get('propagator', getattr(dynamics.unwrap_partial(config['fx']), 'propagator', 'fg'))
-    if propagator not in ('fg', 'elements', 'j2'):
+    if propagator not in ('fg', 'elements', 'j2', 'hybrid'):
         raise NotImplementedError("unknown propagator %r" % (propagator,))
     return model, propagator
 

@@ -40,7 +40,7 @@ class _FxFarnocchia(_Operator):
         if self.propagator == 'j2':
             nsub = max(1, int(np.ceil(abs(dt) / 5.0)))
             return device.propagate_j2(xd, float(dt), host.J2_EARTH, host.R_EQ_EARTH, nsub).cpu().numpy().reshape(6)
-        prop = {'elements': _lib.PROP_ELEMENTS, 'fg': _lib.PROP_FG}[self.propagator]
+        prop = {'elements': _lib.PROP_ELEMENTS, 'fg': _lib.PROP_FG, 'hybrid': _lib.PROP_HYBRID}[self.propagator]
         return device.propagate(xd, float(dt), prop).cpu().numpy().reshape(6)
 
 
@@ -180,6 +180,7 @@ class _FxCowell(_FxFarnocchia):
 
 fx_xyz_farnocchia = _FxFarnocchia('fg')            # default: reduced strong-elliptic form (SSA_PROP_FG)
 fx_xyz_farnocchia_elements = _FxFarnocchia('elements')  # operation-by-operation variant (SSA_PROP_ELEMENTS)
+fx_xyz_farnocchia_hybrid = _FxFarnocchia('hybrid')  # series solver on strong-elliptic states, the reference's branches elsewhere (SSA_PROP_HYBRID)
 fx_xyz_j2_rk4 = _FxFarnocchia('j2')                # EXTENSION: two-body + J2, RK4 (no reference counterpart)
 fx_xyz_cowell = _FxCowell()                        # envs/dynamics.py:168: Cowell with a pluggable acceleration (default ad_none)
 hx_aer_erfa = _HxAer()

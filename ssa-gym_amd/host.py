@@ -83,7 +83,7 @@ def make_consts(Q, R, alpha, beta, kappa, dt, obs_limit_rad, obs_lla, obs_type='
 
     covariance: 'reference' = the prior covariance in the reference's own arithmetic (SSA_FLAG_REFERENCE_COV: reproduces the
     reference's episode-level filter failures), 'centred' = the cancellation-free expansion; None = 'reference' with the
-    'elements' propagator (the behaviour-faithful variant), 'centred' otherwise."""
+    'elements' and 'hybrid' propagators (the behaviour-faithful variants), 'centred' otherwise."""
     Wm, Wc, scale = merwe_weights(alpha, beta, kappa)
     sm, sc = exact_weight_sums(Wm, Wc)
     c = _lib.ssa_consts()
@@ -96,12 +96,12 @@ def make_consts(Q, R, alpha, beta, kappa, dt, obs_limit_rad, obs_lla, obs_type='
     c.enu[:] = enu_matrix(obs_lla).reshape(9)
     c.obs_itrs[:] = lla2ecef(obs_lla)
     c.obs_type = {'aer': _lib.OBS_AER, 'xyz': _lib.OBS_XYZ}[obs_type]
-    c.propagator = {'elements': _lib.PROP_ELEMENTS, 'fg': _lib.PROP_FG, 'j2': _lib.PROP_J2_RK4}[propagator]
+    c.propagator = {'elements': _lib.PROP_ELEMENTS, 'fg': _lib.PROP_FG, 'j2': _lib.PROP_J2_RK4, 'hybrid': _lib.PROP_HYBRID}[propagator]
     c.j2, c.r_eq = float(j2), float(r_eq)
     # RK4 sub-step <= 5 s: local error (n h)^5/120 |r| < 1e-6 m even in LEO
     c.rk4_substeps = int(rk4_substeps) if rk4_substeps else max(1, int(np.ceil(abs(dt) / 5.0)))
     if covariance is None:
-        covariance = 'reference' if propagator == 'elements' else 'centred'
+        covariance = 'reference' if propagator in ('elements', 'hybrid') else 'centred'
     if covariance not in ('reference', 'centred'):
         raise ValueError("covariance must be 'reference' or 'centred', got %r" % (covariance,))
     c.flags = (_lib.FLAG_RESAMPLE if resample else 0) | (_lib.FLAG_REFERENCE_COV if covariance == 'reference' else 0)

@@ -193,8 +193,8 @@ def test_step_kernels_keep_their_register_budget(tmp_path):
             offs = [int(v) for v in re.findall(r"\.offset:\s+(\d+)\s+\.size:\s+\d+\s+\.value_kind:\s+by_value", blk)]
             kinds = re.findall(r"\.value_kind:\s+(\w+)", blk)
             assert kinds[:6] == ["by_value"] * 2 + ["global_buffer"] * 4 and 40 in offs, (kinds[:7], offs)
-    hot = [k for k in kern if "step_fast_kernel" in k or "rollout_kernel" in k]
-    assert len(hot) == 9, hot                      # 3 propagators x {one tile, multi tile} + 3 rollout instances
+    hot = [k for k in kern if "step_fast_kernel" in k or "rollout_kernel" in k or "closed_loop_kernel" in k]
+    assert len(hot) == 16, hot                     # 4 propagators x {one tile, multi tile, rollout, closed loop}
     for k in hot:
         assert kern[k]["vgpr_count"] <= 96, (k, kern[k])
         assert kern[k]["private_segment_fixed_size"] <= 128, (k, kern[k])     # the callees' frames only
@@ -203,7 +203,7 @@ def test_step_kernels_keep_their_register_budget(tmp_path):
     bodies = re.split(r"\n[0-9a-f]+ <([^>]+)>:\n", dis)
     checked = 0
     for name, body in zip(bodies[1::2], bodies[2::2]):
-        if not ("step_fast_kernel" in name or "rollout_kernel" in name):
+        if not ("step_fast_kernel" in name or "rollout_kernel" in name or "closed_loop_kernel" in name):
             continue
         ins = [ln.split()[0] for ln in body.splitlines() if ln.strip() and not ln.strip().startswith(("//", ";"))]
         calls = [i for i, op in enumerate(ins) if op == "s_swappc_b64"]
@@ -212,10 +212,10 @@ def test_step_kernels_keep_their_register_budget(tmp_path):
         # EVERY wavefront (24 bytes per lane and tile: 61 MB of scratch writes per 160 000-object step, found as write
         # traffic 1.58x the algorithmic bytes)
         assert not stray, (name, stray[:8], "scratch access away from any call: a spill on the common path")
-        if "ILi0E" not in name:     # FG / J2 instances make no out-of-line call: no scratch at all
+        if "ILi0E" not in name and "ILi3E" not in name:     # FG / J2 instances make no out-of-line call: no scratch at all
             assert kern[name]["private_segment_fixed_size"] == 0 and kern[name]["vgpr_spill_count"] == 0, (name, kern[name])
         checked += 1
-    assert checked == 9
+    assert checked == 16
 
 
 def test_acceleration_tokens_and_covariance_form_resolve_on_the_host(pkg):

@@ -116,7 +116,10 @@ def test_episode_vs_composite_golden(envs, name):
             d = np.linalg.norm((xf - ep["x_filter"][k])[:, :3], axis=1)
             sig = np.sqrt(np.trace(ep["P_filter"][k][:, :3, :3], axis1=1, axis2=2))
             if i <= m:
-                assert np.all(d < 0.02 * sig + 40.0), (i, d.max())
+                print("[episode %s] step %d: max |x - golden| %.3f m = %.2e sigma_pos" % (name, i, d.max(), (d / sig).max()))
+                # (measured floor: 15.2 m / 2.7e-3 sigma_pos -- the summation-order noise of the reference's weighted mean at
+                # alpha = 1e-4 between the golden's numpy restatement and the kernel)
+                assert np.all(d < 1e-3 * sig + 25.0), (i, d.max())
             ratios.append(np.median(d / sig))
     assert np.array_equal(env.obs_taken[1:], ep["obs_taken"][1:])
     assert not env.failed_filters_id
@@ -579,8 +582,9 @@ def test_observation_paths_agree(envs, mode):
         od, rd, dd, _ = dev.step(k)
         assert isinstance(od, torch.Tensor) and od.is_cuda and isinstance(o, np.ndarray)
         want = host.obs[k].reshape(-1) if mode == 'flatten' else (host.aer_obs(np.zeros(4 * 203)) if mode == 'aer' else host.obs[k])
-        assert o.shape == want.shape and np.array_equal(o, want)
-        assert np.array_equal(od.cpu().numpy().reshape(want.shape), want) and r == rd and d == dd
+        same = (lambda a, b: np.allclose(a, b, rtol=1e-12, atol=1e-12)) if mode == 'aer' else np.array_equal   # ('aer': the epilogue's
+        assert o.shape == want.shape and same(o, want)                                                       #  two-lane atan2 vs aer_obs_kernel)
+        assert np.array_equal(od.cpu().numpy().reshape(want.shape), o) and r == rd and d == dd
         if prev is not None and mode != 'aer':
             assert np.array_equal(prev[0], prev[1])          # the previous step's array has not been touched by this step
         prev = (o, o.copy())

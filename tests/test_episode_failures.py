@@ -9,6 +9,8 @@ sum_i Wc_i y_i y_i^T carries Wc_0 ~ -2e8, and for a diverged (hyperbolic) prior 
 Measured on the oracle (reference order of operations) and on the HIP path, same inputs:
   * SSA_PROP_ELEMENTS + SSA_FLAG_REFERENCE_COV (what config['propagator'] = 'elements' selects): the BEHAVIOUR-FAITHFUL variant --
     failure counts per 60-step window, status-code mix and the 'jones' termination step within the stated band of the oracle;
+  * SSA_PROP_HYBRID + SSA_FLAG_REFERENCE_COV ('hybrid'): the same statistics at more than twice the speed -- the series solver on
+    strong-elliptic states, the reference's formulas (fast primitives) on every other state;
   * SSA_PROP_FG (the default, the headline of bench.py): more accurate than the reference on diverged states, its filters
     survive -- zero failures, asserted as exactly that: a documented behavioural difference.
 """
@@ -72,6 +74,7 @@ def test_elements_variant_reproduces_the_reference_failures_fg_does_not(workload
     hip.torch, hip.lib, hip.dev, hip.host, hip.engine = torch, _lib, device, host, engine
     ro = oracle_runs["reference_order"]
     runs = {"elements (reference covariance: the env's 'elements')": ew.run_hip(hip, workload, "elements"),
+            "hybrid (reference covariance: the env's 'hybrid')": ew.run_hip(hip, workload, "hybrid"),
             "elements + centred covariance": ew.run_hip(hip, workload, "elements", covariance="centred"),
             "fg (default)": ew.run_hip(hip, workload, "fg"),
             "fg + reference covariance": ew.run_hip(hip, workload, "fg", covariance="reference")}
@@ -88,6 +91,12 @@ def test_elements_variant_reproduces_the_reference_failures_fg_does_not(workload
     assert el["status_mix"][_lib.ST_UPDATE_NAN] == 0 and el["status_mix"][_lib.ST_UPDATE_LINALG] == 0
     assert abs(el["jones_done_step"] - ro["jones_done_step"]) <= 1
     assert el["first_failure_step"] is not None and 150 <= el["first_failure_step"] <= 400
+    # ---- SSA_PROP_HYBRID (series solver on strong-elliptic states, the reference's formulas elsewhere): the same statistics at speed
+    hy = runs["hybrid (reference covariance: the env's 'hybrid')"]
+    for w in ew.WINDOWS:
+        assert band(hy["failed_at"][w], ro["failed_at"][w]), (w, hy["failed_at"], ro["failed_at"])
+    assert hy["failed_at"][479] >= 30 and hy["status_mix"][_lib.ST_PREDICT_LINALG] >= 0.8 * hy["failed_at"][479]
+    assert abs(hy["jones_done_step"] - ro["jones_done_step"]) <= 1
     # ---- the default: NOT the reference's failure behaviour (more accurate on diverged states; nothing fails), stated as such
     fg = runs["fg (default)"]
     assert all(v == 0 for v in fg["failed_at"].values()), fg

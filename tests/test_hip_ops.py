@@ -42,7 +42,7 @@ def default_consts(host, alpha=1e-4, obs_type='aer', propagator='fg', resample=F
 
 
 # ------------------------------------------------------------------ P1-P5
-@pytest.mark.parametrize("prop", [0, 1])
+@pytest.mark.parametrize("prop", [0, 1, 3])
 @pytest.mark.parametrize("idt", range(5))
 def test_propagate_vs_reference_golden(hip, prop, idt):
     g = golden("kepler_golden.npz")
@@ -59,7 +59,7 @@ def test_propagate_vs_reference_golden(hip, prop, idt):
     assert relnorm(y, ref, slice(3, 6)).max() < 2e-9
 
 
-@pytest.mark.parametrize("prop", [0, 1])
+@pytest.mark.parametrize("prop", [0, 1, 3])
 def test_propagate_full_size_properties(hip, oracle, prop):
     """20 000-object catalogue-shaped batch: two-body invariants (energy, angular momentum),
     group property f(f(x, a), b) == f(x, a + b), time reversal, and spot parity vs the oracle."""
