@@ -139,6 +139,55 @@ def cpu_baseline(m, budget_s=15.0, all_cores=False):
                       % (steps, m, cores, " -fopenmp" if all_cores else "", el)}
 
 
+EPISODE_M, EPISODE_WINDOWS = 2000, (240, 300, 360, 420, 479)
+
+
+def episode_failures_hip(propagator):
+    """failed filters over ONE 479-step round-robin episode of 2 000 objects (env defaults, alpha = 1e-4, an update every step) on
+    the HIP path: counts at steps 240 .. 479 and the status-code mix.  The reference loses 2-3 % of its filters this way
+    (LinAlgError from an exhausted robust_cholesky ladder on a diverged prior: ssa_tasker_simple_2.py:271-285, dynamics.py:402-417)."""
+    import torch
+    from ssa_gym_amd import _lib, engine, host
+    m = EPISODE_M
+    pb = build_problem(m, seed=7)
+    consts = host.make_consts(pb["Q"], pb["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, pb["obs_lla"], obs_type='aer', propagator=propagator)
+    zn = np.random.RandomState(1).normal(size=(480, m, 3)) * pb["z_sigma"]
+    eng = engine.HotPathEngine(consts, m, 1, pb["trans"], zn[None], history=480)
+    eng.load_state(0, pb["x_true"], pb["x"], np.broadcast_to(pb["P0"], (m, 6, 6)))
+    sched = torch.as_tensor((np.arange(479) % m).astype(np.int32)).cuda()
+    for i in range(1, 480):
+        eng.launch_step(i - 1, i, i, actions_ptr=sched.data_ptr() + 4 * (i - 1), fast_stats=True)
+    torch.cuda.synchronize()
+    nf = eng.stats[1:480, 0, _lib.STAT_N_FAILED].cpu().numpy().astype(int)
+    st = eng.status.cpu().numpy()
+    return {"failed_at_step": {str(w): int(nf[w - 1]) for w in EPISODE_WINDOWS}, "linalg": int((st == _lib.ST_PREDICT_LINALG).sum()),
+            "nan": int((st == _lib.ST_PREDICT_NAN).sum())}
+
+
+def episode_failures_oracle():
+    """the same episode on the CPU oracle (reference order of operations; part of the cpu_baseline leg)"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    orc.build()
+    o = orc.Oracle(omp=True)
+    o.lib.orc_omp_threads(host_cpu_share())
+    m = EPISODE_M
+    pb = build_problem(m, seed=7)
+    Wm, Wc, scale = orc.merwe_weights(1e-4, 2.0, -3)
+    zn = np.random.RandomState(1).normal(size=(480, m, 3)) * pb["z_sigma"]
+    xt, x, P = pb["x_true"], pb["x"], np.tile(pb["P0"], (m, 1, 1))
+    st = np.zeros(m, dtype=np.int32)
+    obs_itrs = o.lla2ecef(pb["obs_lla"])
+    nf = []
+    for i in range(1, 480):
+        a = (i - 1) % m
+        r = o.env_step(xt, x, P, st, 20.0, pb["Q"], pb["R"], Wm, Wc, scale, a, pb["trans"][i], pb["obs_lla"], obs_itrs, -np.pi / 2, zn[i, a])
+        xt, x, P = r["x_true"], r["x"], r["P"]
+        nf.append(int((st != 0).sum()))
+    return {"failed_at_step": {str(w): nf[w - 1] for w in EPISODE_WINDOWS}, "linalg": int((st == orc.ST_PREDICT_LINALG).sum()),
+            "nan": int((st == orc.ST_PREDICT_NAN).sum())}
+
+
 def local_variant_rate(m, K, W, propagator, resample=False, seed=100):
     """the N=1 measurement of `value` for another kernel variant on the same workload: K timed per-step launches (one
     launch per step, deferred statistics fold, episodes of 480 steps with device-side resets) after W warm-up steps"""
@@ -390,6 +439,8 @@ def main():
     ap.add_argument("--payload", default="trace", choices=["trace", "aer"],
                     help="sharded runs: what the per-step all-gather carries per object -- trace P (BASELINE config 4: \"all-gather of per-object "
                          "covariance-trace obs\") or the four-column (az, el, range, trace P) block of the 'aer' observation mode")
+    ap.add_argument("--eager-sharded", action="store_true",
+                    help="sharded runs: enqueue every step from the host (default: hipGraph replay of whole units of steps)")
     ap.add_argument("--no-legs", action="store_true", help="skip the additional N=1 legs (j2, elements, resample, gym_api, closed_loop)")
     args = ap.parse_args()
 
@@ -469,6 +520,11 @@ def main():
         else:
             local.step(-1, profile_slot=profile_slot)   # action comes from the pre-staged schedule
 
+    def max_over_ranks_early(v):
+        t = torch.tensor([v], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     def fence():
         local.flush()
         if sharded is not None:
@@ -483,7 +539,61 @@ def main():
     # agent needs), or on a communication stream so that RCCL moves step k's payload over xGMI while step k+1
     # computes (legitimate for this protocol's pre-staged round-robin schedule; the global observation is then
     # complete one step later).  Either way every step's payload is gathered inside the timed region.
-    if sharded is not None and W >= 40:
+    # ---- sharded runs: the steps of a timed block are replayed from a captured hipGraph (parallel.GraphedShardedSteps): the
+    # host enqueues one graph per `unit` steps instead of 13-34 us of launches and event bookkeeping per step.  Episodes are
+    # whole units (the env is reset when the next unit would cross step 479).  Which stream the all-gather runs in is again
+    # decided by measurement (a few units of each form), identically on every rank.
+    graphed = None
+    divs = [K] if K <= 120 else [d for d in range(2, 121) if K % d == 0]
+    if sharded is not None and not args.eager_sharded and divs:
+        unit = max(divs)
+        cyc = np.arange(plan.m_total)
+        probe, best = {}, None
+        for ov in ((False, True) if (world > 1 or os.environ.get("SSA_BENCH_PROBE_OVERLAP")) else (False,)):
+            local.reset_episode(snap, ep_len)
+            gs = parallel.GraphedShardedSteps(sharded, unit, cyc, overlap=ov)
+            gs.rewind()
+            done_steps = 0
+            for _ in range(3):          # (captures: one per phase seen)
+                if done_steps + unit > ep_len - 1:
+                    local.reset_episode(snap, ep_len)
+                    gs.rewind()
+                    done_steps = 0
+                gs.run_unit()
+                done_steps += unit
+            fence()
+            reps = max(3, 60 // unit)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                if done_steps + unit > ep_len - 1:
+                    local.reset_episode(snap, ep_len)
+                    gs.rewind()
+                    done_steps = 0
+                gs.run_unit()
+                done_steps += unit
+            fence()
+            probe[ov] = max_over_ranks_early((time.perf_counter() - t0) / (reps * unit))
+            if best is None or probe[ov] < 0.97 * probe[best[0]]:
+                best = (ov, gs)
+        graphed = best[1]
+        state["overlap"] = best[0]
+        allgather_probe = {"graph_unit": unit, "in_stream_ms": round(1e3 * probe[False], 5),
+                           "comm_stream_ms": round(1e3 * probe[True], 5) if True in probe else None}
+        local.reset_episode(snap, ep_len)
+        graphed.rewind()
+        state["i"] = 0
+
+        def timed_block_graph():
+            for _ in range(K // unit):
+                if state["i"] + unit > ep_len - 1:
+                    local.reset_episode(snap, ep_len)
+                    graphed.rewind()
+                    state["i"] = 0
+                graphed.run_unit()
+                state["i"] += unit
+        for _ in range(max(1, W // K)):     # (untimed: every phase's graph exists before the timed blocks)
+            timed_block_graph()
+    elif sharded is not None and W >= 40:
         h = W // 2
         times = []
         for mode, lo, hi in ((False, 0, h), (True, h, W)):
@@ -515,7 +625,7 @@ def main():
     def timed_block():
         for k in range(W, W + K):
             one_step(k)
-    elapsed, el_min, el_max, repeats = timed_repeats(timed_block, fence, agree=max_over_ranks)
+    elapsed, el_min, el_max, repeats = timed_repeats(timed_block_graph if graphed is not None else timed_block, fence, agree=max_over_ranks)
 
     # sanity: nothing diverged during the run
     n_failed = int((eng.status != 0).sum().item())
@@ -604,10 +714,18 @@ def main():
         if m == 20000:
             legs["vec_env"] = vec_env_rate(m)
 
-    cpu, cpu_all = None, None
+    cpu, cpu_all, ep_fail = None, None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N=1 only
         cpu = cpu_baseline(m)
         cpu_all = cpu_baseline(m, budget_s=8.0, all_cores=True)
+        if not args.no_legs:
+            # behaviour over a whole episode, next to the rates: which variants lose filters the way the reference does
+            ep_fail = {"workload": "%d objects, 479 round-robin steps, env defaults (alpha 1e-4, dt 20 s, an update every step), same inputs" % EPISODE_M,
+                       "oracle": episode_failures_oracle(),
+                       "elements": episode_failures_hip("elements"), "hybrid": episode_failures_hip("hybrid"), "fg": episode_failures_hip("fg"),
+                       "note": "failed filters (status != 0) at the given steps.  oracle = CPU restatement in the reference's order of operations; "
+                               "elements / hybrid (with the reference's covariance arithmetic, their default) are the BEHAVIOUR-FAITHFUL variants; "
+                               "fg (the default, `value`) is more accurate on diverged states and its filters survive (tests/test_episode_failures.py)"}
 
     if rank == 0:
         steps_per_s = K / elapsed
@@ -632,13 +750,18 @@ def main():
                                           if sharded._rccl is not None else "torch.distributed.all_gather_into_tensor")
                                          if sharded is not None else None),
                        "allgather_warmup_probe": allgather_probe,
+                       "sharded_enqueue": (("hipGraph replay, %d steps per graph (episodes of whole units)" % graphed.U) if graphed is not None
+                                           else ("per step from the host" if use_dist else None)),
                        "allgather_bytes_per_rank": (sharded.width * 8 if sharded is not None else None),
                        "rccl_ranks": (sharded._rccl.count() if (sharded is not None and sharded._rccl is not None)
                                       else (dist.get_world_size() if use_dist else None)),
-                       "ukf_variant": "keep propagated sigma points for update() (default; PARITY-UNPINNED, see `resample`)"},
+                       "ukf_variant": "keep propagated sigma points for update() (default; PARITY-UNPINNED, see `resample`)",
+                       "behaviour": ("fg: per-step parity within the north_star tolerance; does NOT reproduce the reference's episode-level filter "
+                                     "failures (see `episode_failures`; the behaviour-faithful variants are `elements` and `hybrid`)"
+                                     if args.propagator in ("fg", "j2") else "behaviour-faithful variant (the reference's episode-level failures)")},
             "object_steps_per_sec": round(steps_per_s * m * world, 1),
             "failed_filters": n_failed,
-            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "rollout": roll,
+            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "episode_failures": ep_fail, "rollout": roll,
         }
         out.update(legs)
         if cpu:

@@ -195,6 +195,16 @@ class ShardedStepper:
         rows = self._latest().view(p.world, self.width)
         return torch.cat([rows[r, :self.cols * p.sizes[r]] for r in range(p.world)])
 
+    def global_stats_device(self):
+        """the global statistics of the latest step as a DEVICE tensor [8], folded on the device (no host synchronisation: what a
+        consumer in the stream -- a device-side agent, the next step's bookkeeping -- reads).  Raw-shard payloads only."""
+        p = self.plan
+        if not self._raw[(self.k - 1) % self.NB]:
+            raise RuntimeError("global_stats_device: the latest payload carries folded statistics (CPU stepper); use global_stats()")
+        rows = self._latest().view(p.world, self.width)[:, self.cols * p.m_pad + STAT_STRIDE:]
+        w = rows.contiguous().view(torch.int64).view(p.world * STAT_SHARDS, STAT_SHARD_WORDS)
+        return fold_raw_statistics(w)
+
     def global_stats(self):
         """reduce the per-rank statistics exactly as the single-GPU kernel would have produced them."""
         p = self.plan
@@ -224,6 +234,122 @@ class ShardedStepper:
         out[STAT_MAX_SPOS] = sp[r]
         out[STAT_ARGMAX_SPOS] = p.offsets[r] + st[r, STAT_ARGMAX_SPOS]
         return out
+
+
+class GraphedShardedSteps:
+    """U consecutive sharded steps -- U x [step kernel, all-gather] -- captured ONCE into a hipGraph and replayed.
+
+    Enqueueing a sharded step costs the host 13-14 us (parameter block, two ctypes calls, event bookkeeping): as much as the
+    step kernel runs, so the eager loop is host-bound, and with the all-gather overlapped on a communication stream (two
+    cross-stream event waits per step) the host needs 34 us per step.  Replaying a captured unit costs one launch per U steps.
+    Everything a step reads that changes from replay to replay lives in device memory the graph itself advances:
+      * time: the kernels read env_time0 (device) + their position in the unit; the unit's last node adds U to it;
+      * actions: a window of U action words, gathered at the unit's start from the rank's (cyclic) schedule at a device-side
+        cursor that the unit then advances.
+    History slots and payload buffers are addressed by position (slot = (phase + j) % 2, buffer = j % 3), so a unit is captured
+    per starting phase (at most 6 graphs, captured on first use).  overlap: the all-gather of step j runs on the communication
+    stream while the step kernel of step j + 1 runs -- a fork / join inside the captured graph.
+    The caller keeps the episode bookkeeping: reset the env between units (`rewind()` sets the time index back to 0)."""
+
+    def __init__(self, sharded, unit, schedule_global, overlap=False):
+        self.sh, self.U, self.overlap = sharded, int(unit), bool(overlap)
+        self.local = sharded.local
+        self.eng = self.local.engine
+        if self.eng.E != 1 or self.eng.H != 2:
+            raise ValueError("graphed sharded steps: one env, history depth 2")
+        if not self.sh._gpu or not getattr(self.local, "raw_shards", False):
+            raise ValueError("graphed sharded steps need the HIP stepper")
+        plan = sharded.plan
+        sched = np.asarray([plan.local_action(int(a)) for a in schedule_global], dtype=np.int32)
+        dev = self.eng.dev
+        self.sched = torch.as_tensor(sched).to(dev)                      # the rank's local action per global step (cyclic)
+        self.cursor = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._ar = torch.arange(self.U, dtype=torch.int64, device=dev)
+        self._idx = torch.zeros(self.U, dtype=torch.int64, device=dev)
+        self.window = torch.full((self.U,), -1, dtype=torch.int32, device=dev)
+        self._graphs = {}
+        self.eng.env_time0.zero_()
+        self._stream = torch.cuda.Stream(device=dev)                     # capture / replay stream
+
+    def rewind(self):
+        """new episode: the next unit starts at time index 1 (the caller has restored the state)"""
+        self.eng.flush_stats()
+        self.eng.env_time0.zero_()
+
+    def _enqueue_unit(self, tick0, k0):
+        sh, local, eng, U = self.sh, self.local, self.eng, self.U
+        cur = torch.cuda.current_stream()
+        n = self.sched.numel()
+        torch.remainder(self.cursor + self._ar, n, out=self._idx)
+        torch.index_select(self.sched, 0, self._idx, out=self.window)
+        wptr = self.window.data_ptr()
+        done = []
+        for j in range(U):
+            b, bn = (k0 + j) % sh.NB, (k0 + j + 1) % sh.NB
+            if self.overlap and j >= 2:
+                cur.wait_event(done[j - 2])          # buffer bn's all-gather (two steps ago) has left before this step zeroes its words
+            t = tick0 + j + 1
+            eng.launch_step((t - 1) % 2, t % 2, j + 1, actions_ptr=wptr + 4 * j, aer_out=sh._v_obs[b].data_ptr(), fast_stats=True,
+                            shards_out=sh._v_shards[b].data_ptr(), shards_clear=sh._v_shards[bn].data_ptr(), aer_cols=sh.cols,
+                            stream=cur.cuda_stream)
+            sh._raw[b] = True
+            if self.overlap:
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                sh.comm.wait_event(ev)
+                sh._all_gather(sh.recv[b], sh.send[b], sh.comm)
+                dn = torch.cuda.Event()
+                dn.record(sh.comm)
+                done.append(dn)
+            else:
+                sh._all_gather(sh.recv[b], sh.send[b], cur)
+        if self.overlap:
+            for dn in done[-2:]:
+                cur.wait_event(dn)                   # join: the unit ends when its last all-gathers have
+        eng.env_time0.add_(U)
+        self.cursor.add_(U)
+
+    def run_unit(self):
+        """replay (capture on first use) the unit for the current phase; returns nothing, synchronises nothing"""
+        sh, local = self.sh, self.local
+        key = (local.tick % 2, sh.k % sh.NB)
+        g = self._graphs.get(key)
+        cur = torch.cuda.current_stream()
+        if g is None:
+            # warm the path once eagerly on the capture stream (RCCL sets up its channels on first use), then capture
+            # first use of this phase: the unit runs ONCE eagerly on the capture stream (RCCL sets up its channels on first use,
+            # and this run IS the unit the caller asked for), then the same enqueue sequence is captured for the replays to
+            # come -- the capture itself executes nothing
+            self._stream.wait_stream(cur)
+            with torch.cuda.stream(self._stream):
+                self._enqueue_unit(local.tick, sh.k)
+                self._stream.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self._stream):
+                self._enqueue_unit(local.tick, sh.k)
+            self._graphs[key] = g
+            cur.wait_stream(self._stream)
+            local.tick += self.U
+            sh.k += self.U
+            return
+        g.replay()
+        local.tick += self.U
+        sh.k += self.U
+
+
+def fold_raw_statistics(rows_words):
+    """device-side fold of raw statistics shard words [n_shards][>= 3] (int64 bit patterns) -> float64[8] on the same device,
+    as reward_fold_kernel / ShardedStepper.global_stats() do: max delta_pos by its ordered bits (NaN on top), the two trinary
+    counts, the failures; arg-max of sigma_pos is not part of the raw form (-1 / NaN)."""
+    w = rows_words
+    out = torch.zeros(STAT_STRIDE, dtype=torch.float64, device=w.device)
+    out[STAT_MAX_DPOS] = w[:, 0].max().view(torch.float64)          # (non-negative doubles and NaN order like integers)
+    out[STAT_CNT_LT_1E4] = (w[:, 1] & 0xffffffff).sum().to(torch.float64)
+    out[STAT_CNT_LT_1E7] = (w[:, 1] >> 32).sum().to(torch.float64)
+    out[STAT_N_FAILED] = w[:, 2].sum().to(torch.float64)
+    out[STAT_ARGMAX_SPOS] = -1.0
+    out[STAT_MAX_SPOS] = float("nan")
+    return out
 
 
 class HipLocalStepper:

@@ -66,8 +66,35 @@ class Communicator:
         if int(ok.item()) != 1:
             raise RuntimeError("direct RCCL communicator: library load / unique id failed on at least one rank (%s)" % (err,))
         C.memmove(C.byref(uid), bytes(buf.cpu().tolist()), NCCL_UNIQUE_ID_BYTES)
-        # (created on the process's current device, as set by the launcher)
-        self._check(self.lib.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
+        # (created on the process's current device, as set by the launcher).  ncclCommInitRank is itself a collective: if it fails
+        # or never starts on ONE rank the others would sit in it forever.  It runs in a helper thread with a deadline
+        # (SSA_RCCL_INIT_TIMEOUT seconds, default 60), and the ranks agree on the outcome (all-reduce MIN over the process group)
+        # before anybody uses the communicator: a one-sided failure makes EVERY rank raise here -- parallel._direct_communicator
+        # then falls back to torch.distributed's all-gather on all ranks alike.  (A rank whose helper thread is still blocked
+        # abandons it: the thread is a daemon and the communicator is never used.)
+        import threading
+        res = {}
+
+        def _init():
+            try:
+                torch.cuda.set_device(dev)
+                res["rc"] = self.lib.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank)
+            except Exception as exc:  # noqa: BLE001
+                res["exc"] = exc
+        th = threading.Thread(target=_init, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("SSA_RCCL_INIT_TIMEOUT", "60")))
+        mine = (not th.is_alive()) and res.get("rc", -1) == 0
+        ok = torch.tensor([1 if mine else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) != 1:
+            why = ("timed out" if th.is_alive() else "raised %r" % (res["exc"],) if "exc" in res else
+                   ("failed: %s" % self.lib.ncclGetErrorString(res["rc"]).decode()) if res.get("rc", 0) != 0 else "failed on another rank")
+            if mine:
+                self.close()
+            else:
+                self.comm = C.c_void_p()
+            raise RuntimeError("direct RCCL communicator: ncclCommInitRank %s" % why)
 
     def count(self):
         """number of ranks of the communicator as RCCL itself reports it (ncclCommCount)"""

@@ -965,6 +965,63 @@ def test_160000_objects_single_launch_and_8x20000_vector(hip, oracle, oracle_ld)
     check_parity(gpu_s, f64s, ld, exact_bound=True, well_frac=0.5, min_well=0.86, tag=" 160000-object sample")
 
 
+def test_graphed_sharded_steps_equal_eager_steps(hip):
+    """parallel.GraphedShardedSteps: units of sharded steps (step kernel + all-gather each) captured into a hipGraph and
+    replayed -- with the all-gather in the compute stream and forked onto the communication stream inside the graph -- leave
+    the same states, payloads and statistics as the same steps enqueued one by one from the host.  One rank (RCCL's
+    ncclAllGather is captured too); the device-side statistics fold equals the host one."""
+    import torch.distributed as dist
+    torch = hip.torch
+    from ssa_gym_amd import parallel
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+    try:
+        m, U, NU = 2003, 4, 6
+        xt, x, P, g = make_batch(m, seed=15)
+        consts = hip.host.make_consts(g["Q"], g["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, g["obs_lla"])
+        n_time = c2t().shape[0]
+        zn_h = np.random.RandomState(3).normal(size=(n_time, m, 3)) * np.array([4.8e-6, 4.8e-6, 1e3])
+        plan = parallel.ShardPlan(m, 1, 0)
+        sched = (np.arange(4 * U * NU) * 37 + 5) % m            # global actions of consecutive steps (cyclic)
+
+        def fresh():
+            eng = hip.engine.HotPathEngine(consts, m, 1, c2t(), torch.as_tensor(zn_h).cuda()[None].contiguous(), history=2)
+            eng.load_state(0, xt, x, P)
+            local = parallel.HipLocalStepper(eng, consts, fast_stats=True)
+            return eng, local, parallel.ShardedStepper(plan, local, obs_cols=1)
+        eng, local, sh = fresh()
+        for k in range(U * NU):
+            sh.step(int(sched[k]))
+        sh.wait()
+        torch.cuda.synchronize()
+        want = (eng.x_filter[local.tick % 2].cpu().numpy(), eng.P_filter[local.tick % 2].cpu().numpy(), eng.x_true[local.tick % 2].cpu().numpy(),
+                eng.status.cpu().numpy(), sh.global_obs().cpu().numpy(), sh.global_stats())
+        assert np.isfinite(want[4]).all() and want[5][hip.lib.STAT_CNT_LT_1E7] == m
+        sh.close()
+        for overlap in (False, True):
+            eng, local, sh = fresh()
+            gs = parallel.GraphedShardedSteps(sh, U, sched, overlap=overlap)
+            gs.rewind()
+            for _ in range(NU):
+                gs.run_unit()
+            sh.wait()
+            torch.cuda.synchronize()
+            assert len(gs._graphs) == 3 and local.tick == U * NU          # (one capture per phase, the other three units were replays)
+            got = (eng.x_filter[local.tick % 2].cpu().numpy(), eng.P_filter[local.tick % 2].cpu().numpy(), eng.x_true[local.tick % 2].cpu().numpy(),
+                   eng.status.cpu().numpy(), sh.global_obs().cpu().numpy(), sh.global_stats())
+            for a, b in zip(got, want):
+                assert np.array_equal(a, b, equal_nan=True), overlap
+            dev_stats = sh.global_stats_device().cpu().numpy()
+            assert np.array_equal(dev_stats[:3], want[5][:3]) and dev_stats[hip.lib.STAT_N_FAILED] == want[5][hip.lib.STAT_N_FAILED]
+            assert int(eng.env_time0.item()) == U * NU and int(gs.cursor.item()) == U * NU
+            sh.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("resample", [False, True])
 def test_resample_variant_fails_in_the_predict_that_draws_the_points(hip, oracle, resample):
     """The two published predict() variants differ in WHEN an exhausted robust_cholesky ladder is seen: the variant that
