@@ -28,6 +28,7 @@ for seed in (7, 8):
         out[tag] = {"oracle": ew.run_oracle(w, resample=rs), "oracle_centred": ew.run_oracle(w, centred=True, resample=rs),
                     "elements_refcov": ew.run_hip(hip, w, "elements", resample=rs, covariance='reference'),
                     "elements_centred": ew.run_hip(hip, w, "elements", resample=rs, covariance='centred'),
+                    "hybrid_refcov": ew.run_hip(hip, w, "hybrid", resample=rs, covariance='reference'),
                     "fg_refcov": ew.run_hip(hip, w, "fg", resample=rs, covariance='reference'),
                     "fg_centred": ew.run_hip(hip, w, "fg", resample=rs, covariance='centred')}
         for k, v in out[tag].items():

@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/${TAG}_more
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for cfg in "fg 160000" "j2 20000" "elements 20000"; do
+for cfg in "fg 160000" "j2 20000" "elements 20000" "hybrid 20000"; do
   set -- $cfg; export PROP=$1 M=$2
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${PROP}_${M}_$c -- python3 $R/profiles/pmc_workload.py > $OUT/pmc_${PROP}_${M}_$c.log 2>&1
@@ -18,7 +18,7 @@ for cfg in "fg 160000" "j2 20000" "elements 20000"; do
   echo "traffic $PROP $M done"
 done
 unset PROP M
-for prop in elements j2; do
+for prop in elements j2 hybrid; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$prop -- python3 $R/bench.py --propagator $prop --steps 958 --warmup 0 --no-cpu-baseline --no-legs --rollout 60 > $OUT/prof_$prop.json 2> $OUT/prof_$prop.err
   find $OUT/prof_$prop -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_$prop.csv \;
   head -3 $OUT/kernel_stats_$prop.csv
@@ -28,5 +28,10 @@ bash build_ablate/trunc_counters.sh > $OUT/trunc_healthy.log 2>&1; cp gpurun_out
 python3 build_ablate/episode_profile.py > $OUT/episode_profile.txt 2>&1; tail -12 $OUT/episode_profile.txt
 FAST=1 PROPS=fg python3 build_ablate/time_variants.py > $OUT/variants_20k.txt 2>&1; cat $OUT/variants_20k.txt
 FAST=1 M=2000 PROPS=fg python3 build_ablate/time_variants.py > $OUT/variants_2k.txt 2>&1; cat $OUT/variants_2k.txt
+# round 3: the closed loop's timeline (two consecutive steps of closed_loop_kernel), the host-path probe, episode-level failures
+python3 build_ablate/closed_loop_timeline.py > $OUT/closed_loop_timeline.txt 2>&1; tail -30 $OUT/closed_loop_timeline.txt
+python3 build_ablate/host_path_probe.py > $OUT/host_path_probe.txt 2>&1; cat $OUT/host_path_probe.txt
+python3 build_ablate/episode_failures.py > $OUT/episode_failures.txt 2>&1; tail -12 $OUT/episode_failures.txt
+build_ablate/probe/atomic_rtt > $OUT/atomic_rtt.txt 2>&1
 cat profiles/traffic.json | tail -30
 cp $R/profiles/traffic.json $OUT/traffic_merged.json

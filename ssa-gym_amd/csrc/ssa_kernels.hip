@@ -2736,12 +2736,16 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) closed_loop_kernel(const L
         // microseconds the others spent on the next predict, and if it stays behind it is the last to announce its part of
         // the NEXT step too, with every wavefront waiting for it.  It catches up at top priority.
         if (boost) __builtin_amdgcn_s_setprio(3);
+#ifdef SSA_CL_NOROT   // diagnostic: no rotation of the issue priority
+        else __builtin_amdgcn_s_setprio(1);
+#else
         else switch ((wave_slot + (unsigned)kk) & 3u) {
             case 0: __builtin_amdgcn_s_setprio(0); break;
             case 1: __builtin_amdgcn_s_setprio(1); break;
             case 2: __builtin_amdgcn_s_setprio(2); break;
             default: __builtin_amdgcn_s_setprio(3); break;
         }
+#endif
         asm volatile("" : "+s"(kp));
         asm volatile("" : "+v"(lane));
         const StepK& k = ((const LoopK*)kp)->k;
