@@ -707,8 +707,12 @@ def main():
             legs["j2"].update(note="EXTENSION without reference counterpart (SURVEY section 0): two-body + J2, RK4, 4 sub-steps")
         legs["resample"].update(note="predict() redraws the sigma points from the prior (SSA_FLAG_RESAMPLE); `value` keeps the "
                                      "propagated points; which of the two the reference's unpinned filterpy does is unverifiable offline")
-        legs["closed_loop"] = closed_loop_rate(m, max(Kl, 480), Wl)
         legs["closed_loop_per_step_launches"] = closed_loop_rate(m, Kl, Wl, persistent=False)
+        if m <= 20160:      # (one wavefront per four objects + the service wavefronts must all be resident: ssa_env_closed_loop_f64)
+            legs["closed_loop"] = closed_loop_rate(m, max(Kl, 480), Wl)
+        else:
+            legs["closed_loop"] = dict(legs["closed_loop_per_step_launches"], note="more than 20 160 objects: ssa_env_closed_loop_f64 declines "
+                                       "(SSA_E_UNSUPPORTED), the closed loop runs as step + ssa_agent_select_f64 launches")
         legs["gym_api"] = {"flatten": gym_api_rate(m, 'flatten'), "aer": gym_api_rate(m, 'aer'),
                            "note": "SSA_Tasker_Env.step() per call, host in the loop, PCIe + one sync inclusive (20 000 objects)"}
         if m == 20000:

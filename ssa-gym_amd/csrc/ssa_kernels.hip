@@ -1277,7 +1277,9 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                 Vec6 si;
 #pragma unroll
                 for (int c = 0; c < 6; ++c) si.v[c] = s[c];
-                Vec6 oo = kepler_general_tagged<1>(si, C.dt);
+                // (the reference's formulas branch by branch with this file's fast primitives, as SSA_PROP_HYBRID: the libm
+                // restatement kepler_general_tagged costs three times as much per call and late in an episode most wavefronts call it)
+                Vec6 oo = kepler_general_fast_tagged<2>(si, C.dt);
 #pragma unroll
                 for (int c = 0; c < 6; ++c) o[c] = oo.v[c];
             }
