@@ -2254,9 +2254,12 @@ SSA_DEV double logdet_chol(const double (&A)[21])
     double U[21];
     double ld = __builtin_nan("");
     if (chol6_upper(A, 0.0, U)) {
-        ld = 0.0;
+        // det P = (prod U_ii)^2: ONE logarithm of the product (as the reference: np.log(np.linalg.det(P)), agents.py:24) instead of
+        // six of the factors -- the diagonal of the factor is sqrt-sized (1e-3 .. 1e6), its product far from over- / underflow
+        double pr = U[tri(0, 0)];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) ld += 2.0 * log(U[tri(c, c)]);
+        for (int c = 1; c < 6; ++c) pr *= U[tri(c, c)];
+        ld = 2.0 * log(pr);
     }
     return ld;
 }
