@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SSA_ABI_VERSION 18
+#define SSA_ABI_VERSION 19
 
 /* error codes */
 #define SSA_OK 0
@@ -206,6 +206,10 @@ int ssa_env_step_f64(const ssa_consts *c_host, const ssa_step_params *p_host, vo
 #define SSA_PROFILE_SLOTS 1024
 #define SSA_LAUNCH_DEFER_FOLD 8u
 #define SSA_LAUNCH_INLINE_ACTION 16u /* the env's action is ssa_step_params.action0 (n_env == 1) */
+#define SSA_LAUNCH_FOLD_INSIDE 32u   /* with stat_shards + stats, one env, no deferral: the statistics are folded by the step kernel's LAST
+                                        wavefront (it counts the tiles behind the shards' sums, words 3 / 4 of the shard lines) instead of by
+                                        a fold kernel launched behind the step: ONE launch per step with the statistics available when it
+                                        completes -- for callers that read them on the host after every step */
 int ssa_env_step_profiled_f64(const ssa_consts *c_host, const ssa_step_params *p_host, void *stream, int32_t slot);
 /* waits for slot's kernel and writes its duration in milliseconds */
 int ssa_env_step_profile_ms(int32_t slot, float *kernel_ms);

@@ -56,7 +56,7 @@ class ssa_closed_loop_params(C.Structure):
 
 # constants of include/ssa_hip.h
 E_INVALID, E_LAUNCH, E_UNSUPPORTED = -1, -2, -3
-ABI_VERSION = 18
+ABI_VERSION = 19
 ST_OK, ST_PREDICT_NAN, ST_PREDICT_LINALG, ST_UPDATE_NAN, ST_UPDATE_LINALG = range(5)
 OBS_AER, OBS_XYZ = 0, 1
 PROP_ELEMENTS, PROP_FG, PROP_J2_RK4, PROP_HYBRID = 0, 1, 2, 3
@@ -68,6 +68,7 @@ STAT_SHARD_WORDS = 16
 PROFILE_SLOTS = 1024
 LAUNCH_DEFER_FOLD = 8
 LAUNCH_INLINE_ACTION = 16
+LAUNCH_FOLD_INSIDE = 32
 AGENT_NAIVE_GREEDY, AGENT_VISIBLE_GREEDY, AGENT_SHANNON, AGENT_POS_ERROR, AGENT_VEL_ERROR = range(5)
 STAT_STRIDE, STAT_MAX_DPOS, STAT_CNT_LT_1E4, STAT_CNT_LT_1E7, STAT_ARGMAX_SPOS, STAT_N_FAILED, STAT_MAX_SPOS = 8, 0, 1, 2, 3, 4, 5
 

@@ -1032,6 +1032,47 @@ __device__ unsigned long long g_trace[16384 * 16];
 #define SSA_TR(k) do { } while (0)
 #endif
 
+// SSA_LAUNCH_FOLD_INSIDE: the statistics of the step are folded by the LAST wavefront of the launch to finish its atomics instead
+// of by a fold kernel behind it (a caller that needs them on the host right after the step -- the gym env -- saves a dependent
+// launch, ~4 us on the GPU and 2 us of enqueueing).  Word 3 of every shard counts the tiles that have added to it, word 4 of shard 0
+// the shards that are complete; a wavefront bumps them only after its own atomics are acknowledged, so whoever completes the last
+// shard reads finished sums (agent-scope loads), writes `stats` and clears shards and counters for the next step.
+SSA_DEV void fold_stat_shards_inside(unsigned long long* __restrict__ shards, double* __restrict__ stats, int lane)
+{
+    unsigned long long* sh = shards + (int64_t)lane * SSA_STAT_SHARD_WORDS;
+    unsigned long long* sh2 = sh + 64 * SSA_STAT_SHARD_WORDS;
+    unsigned long long mx = __hip_atomic_load(sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long cn = __hip_atomic_load(sh + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long nf = __hip_atomic_load(sh + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long mb = __hip_atomic_load(sh2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long cb = __hip_atomic_load(sh2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long nb = __hip_atomic_load(sh2 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        __hip_atomic_store(sh + q, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sh2 + q, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    mx = mb > mx ? mb : mx;
+    cn += cb;
+    nf += nb;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long m2 = __shfl_down(mx, off, 64), c2 = __shfl_down(cn, off, 64), n2 = __shfl_down(nf, off, 64);
+        mx = m2 > mx ? m2 : mx;
+        cn += c2;
+        nf += n2;
+    }
+    if (lane == 0) {
+        stats[SSA_STAT_MAX_DPOS] = __longlong_as_double((long long)mx);
+        stats[SSA_STAT_CNT_LT_1E4] = (double)(cn & 0xffffffffull);
+        stats[SSA_STAT_CNT_LT_1E7] = (double)(cn >> 32);
+        stats[SSA_STAT_ARGMAX_SPOS] = -1.0;
+        stats[SSA_STAT_N_FAILED] = (double)nf;
+        stats[SSA_STAT_MAX_SPOS] = __builtin_nan("");
+        stats[6] = 0.0; stats[7] = 0.0;
+    }
+}
+
 // One wavefront advances up to 4 consecutive objects (one per 16-lane row) by one env step, complete semantics:
 // the robust_cholesky ladder is inline, conic branches beyond the strong-elliptic one are out-of-line calls taken
 // only by the lanes that need them.
@@ -1653,6 +1694,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
             SSA_XROW(0x142, 0xA)   // row_bcast:15
             SSA_XROW(0x143, 0xC)   // row_bcast:31
 #undef SSA_XROW
+            bool i_fold = false;
             if (lane == 63) {
                 const int64_t e_tile = (p.n_env > 1) ? (int64_t)((uint32_t)base / (uint32_t)p.n_obj) : 0;
                 unsigned long long* sh = (unsigned long long*)p.stat_shards + ((e_tile * SSA_STAT_SHARDS) + (tile & (SSA_STAT_SHARDS - 1))) * SSA_STAT_SHARD_WORDS;
@@ -1661,7 +1703,27 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                 atomicAdd(sh + 1, (unsigned long long)c4 | ((unsigned long long)c7 << 32));
                 if (nfl) atomicAdd(sh + 2, (unsigned long long)nfl);
 #endif
+                if (p.launch_mask & SSA_LAUNCH_FOLD_INSIDE) {   // (one env: the launcher checks)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this tile's sums are in before it is counted
+                    const int nt = (int)((p.n_obj + OBJ_PER_WAVE - 1) / OBJ_PER_WAVE);
+                    const int shard = tile & (SSA_STAT_SHARDS - 1);
+                    const unsigned expect = (unsigned)((nt - shard + SSA_STAT_SHARDS - 1) / SSA_STAT_SHARDS);   // tiles that add to this shard
+                    const unsigned old = (unsigned)__hip_atomic_fetch_add(sh + 3, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (old == expect - 1u) {
+                        __hip_atomic_store(sh + 3, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        unsigned long long* done = (unsigned long long*)p.stat_shards + 4;
+                        const unsigned used = (unsigned)(nt < SSA_STAT_SHARDS ? nt : SSA_STAT_SHARDS);
+                        const unsigned old2 = (unsigned)__hip_atomic_fetch_add(done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (old2 == used - 1u) {
+                            __hip_atomic_store(done, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            i_fold = true;
+                        }
+                    }
+                }
             }
+            if ((p.launch_mask & SSA_LAUNCH_FOLD_INSIDE) && __any(i_fold))      // the launch's last tile: every shard is complete
+                fold_stat_shards_inside((unsigned long long*)p.stat_shards, p.stats, lane);
         } else if (p.stat_shards && lane == 0) {   // a tile that straddles envs: one group of atomics per env
             int64_t e_cur = -1;
             unsigned long long mx = 0ull, cnts = 0ull, nf = 0ull;
@@ -3055,6 +3117,8 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
     if (p->launch_mask & SSA_LAUNCH_INLINE_ACTION) {
         if (p->n_env != 1) return SSA_E_INVALID;
     } else if (!p->actions) return SSA_E_INVALID;
+    if ((p->launch_mask & SSA_LAUNCH_FOLD_INSIDE) &&
+        (p->n_env != 1 || !p->stat_shards || !p->stats || (p->launch_mask & SSA_LAUNCH_DEFER_FOLD))) return SSA_E_INVALID;
     if (c->obs_type != SSA_OBS_AER && c->obs_type != SSA_OBS_XYZ) return SSA_E_INVALID;
     if (p->aer_cols != 0 && p->aer_cols != 1 && p->aer_cols != 4) return SSA_E_INVALID;
     StepK k;
@@ -3099,6 +3163,7 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
     }
     if (fast_stats) {   // (the aer_out payload, if any, was the step kernel's epilogue) a one-wave fold finishes the step
                         // (2 launches), unless deferred (1 launch)
+        if (p->launch_mask & SSA_LAUNCH_FOLD_INSIDE) return launch_status();   // (folded by the step kernel's last wavefront)
         if ((mask & 6u) && !defer && p->stats)   // (stats NULL: the caller consumes the raw shard words, see stat_shards_clear)
             hipLaunchKernelGGL(reward_fold_kernel, dim3(p->n_env), dim3(64), 0, s, (unsigned long long*)p->stat_shards, p->stats);
         return launch_status();

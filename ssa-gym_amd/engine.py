@@ -170,7 +170,7 @@ class HotPathEngine:
 
     def launch_step(self, slot_in, slot_out, time_offset, actions_ptr=None, stream=None, aer_out=0, stats_out=0, upd_out=0,
                     fast_stats=False, defer_fold=False, profile_slot=None, shards_out=0, shards_clear=0, aer_cols=4, action=None,
-                    obs_mirror=0):
+                    obs_mirror=0, fold_inside=False):
         """enqueue the step; asynchronous, no host sync.  fast_stats: statistics by the step kernel's atomics (two
         launches, no arg-max of sigma_pos).  defer_fold (with fast_stats): ONE launch -- this step's
         statistics are folded by extra wavefronts of the NEXT deferred step, or by flush_stats().  action (one env): the
@@ -189,6 +189,8 @@ class HotPathEngine:
         inline = 0
         if action is not None:
             p.action0, inline = int(action), _lib.LAUNCH_INLINE_ACTION
+        if fold_inside and fast_stats and not defer and not shards_out and self.E == 1:
+            inline |= _lib.LAUNCH_FOLD_INSIDE      # (the step kernel's last wavefront folds the statistics: no fold launch)
         if defer and self._fold_pending is not None:
             p.launch_mask = _lib.LAUNCH_DEFER_FOLD | inline
             p.stat_shards_prev = self._shard_ptr[self._fold_pending[0]]

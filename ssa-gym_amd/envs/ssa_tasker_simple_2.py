@@ -204,6 +204,7 @@ class SSA_Tasker_Env(Env):
         e = self._engine
         import torch
         self._aer_dev = torch.zeros(self.m * 4, dtype=torch.float64, device="cuda")
+        self._stream = torch.cuda.current_stream()
         # host-mapped mailboxes (pinned memory is addressable from the GPU): the kernels read the action
         # from / write statistics and the update record to host memory directly, so a step needs one
         # stream synchronisation and one observation copy instead of four blocking transfers
@@ -308,23 +309,23 @@ class SSA_Tasker_Env(Env):
         e = self._engine
         s = time.time()
         self.runtime['step prep'] += s - step_s
-        # propagate + predict + update + observations/metrics + statistics: two launches (:265-322).  The action travels by value
-        # in the parameter block; statistics, update record and the observation are written by the kernels straight into
-        # host-mapped pinned memory: ONE stream synchronisation, no copy
-        import torch
-        cur = torch.cuda.current_stream()     # (looked up once per step: launch and synchronisation share it)
+        # propagate + predict + update + observations/metrics + statistics: ONE launch (:265-322; the step kernel's last wavefront folds
+        # the statistics, SSA_LAUNCH_FOLD_INSIDE).  The action travels by value in the parameter block; statistics, update record
+        # and the observation are written by the kernel straight into host-mapped pinned memory: ONE stream synchronisation, no copy
+        cur = self._stream                    # (the stream the engine was built in; torch.cuda.current_stream() costs 3 us per call,
+        #                                        and every step ends with a synchronisation, so later work in any stream sees its results)
         aer = self.obs_returned == 'aer'
         k = 0 if aer else i % len(self._obs_ring)
         if self._obs_device:
             e.launch_step((i - 1) % e.H, i % e.H, i, action=int(a), aer_out=self._aer_dev.data_ptr() if aer else 0,
                           stats_out=self._stats_ptr, upd_out=self._upd_ptr, stream=cur.cuda_stream,
-                          fast_stats=(self.reward_type != 'shaped'))
+                          fast_stats=(self.reward_type != 'shaped'), fold_inside=True)
             obs_np = self._aer_dev if aer else (e.obs[i % e.H].reshape(-1) if self.obs_returned == 'flatten' else e.obs[i % e.H])
         else:
             e.launch_step((i - 1) % e.H, i % e.H, i, action=int(a),
                           aer_out=self._obs_ring_ptr[0] if aer else 0, obs_mirror=0 if aer else self._obs_ring_ptr[k],
                           stats_out=self._stats_ptr, upd_out=self._upd_ptr, stream=cur.cuda_stream,
-                          fast_stats=(self.reward_type != 'shaped'))   # only 'shaped' needs argmax(sigma_pos) (:346)
+                          fast_stats=(self.reward_type != 'shaped'), fold_inside=True)   # only 'shaped' needs argmax(sigma_pos) (:346)
             obs_np = self._obs_ring_np[k]
         cur.synchronize()
         rec = self._upd_np

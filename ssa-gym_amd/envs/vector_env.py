@@ -127,7 +127,7 @@ class SSA_Tasker_VecEnv:
         sin, sout = (self.tick - 1) % 2, self.tick % 2
         aer = self.obs_returned == 'aer'
         k = self.tick % 2
-        cur = torch.cuda.current_stream()
+        cur = torch.cuda.current_stream()     # (the stream the time / action copy above was enqueued in)
         e.launch_step(sin, sout, 0, aer_out=self._obs_ring_ptr[k] if aer else 0, obs_mirror=0 if aer else self._obs_ring_ptr[k],
                       stats_out=self._stats_host.data_ptr(), stream=cur.cuda_stream, fast_stats=(self.reward_type != 'shaped'))
         cur.synchronize()

@@ -495,6 +495,36 @@ def test_two_launch_statistics_path_matches_exact_path(hip, E, m, payload):
     assert np.isnan(s0[0, L.STAT_MAX_DPOS]) and s0[0, L.STAT_N_FAILED] >= 1 and s0[E - 1, L.STAT_N_FAILED] >= 1
 
 
+@pytest.mark.parametrize("m", [3, 203, 511, 513, 20000, 41003])
+def test_statistics_folded_inside_the_step_kernel(hip, m):
+    """SSA_LAUNCH_FOLD_INSIDE: the step kernel's last wavefront folds the statistics (per-shard tile counters, one more counter
+    over the shards) -- ONE launch per step with the statistics complete when it ends.  Same values as the fold-kernel path over
+    consecutive steps (the counters and shards reset themselves), for fewer tiles than shards, ragged tiles, exactly / just over
+    128 tiles, the whole 20 000-object launch and the multi-tile instance; NaN delta_pos and failed filters included."""
+    xt, x, P, g = make_batch(m, seed=43)
+    if m > 3:
+        x[1, 0] = np.nan
+        xt[2, 0] = np.nan
+        P[m - 1] = -1e18 * np.eye(6)
+    consts = hip.host.make_consts(g["Q"], g["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, g["obs_lla"])
+    outs = []
+    for inside in (False, True):
+        eng = hip.engine.HotPathEngine(consts, m, 1, c2t(), np.zeros((1, 480, m, 3)), history=2)
+        eng.load_state(0, xt, x, P)
+        stats = []
+        for k in range(4):
+            eng.launch_step(k % 2, (k + 1) % 2, k + 1, action=(7 * k + 1) % m, fast_stats=True, fold_inside=inside)
+            hip.torch.cuda.synchronize()
+            stats.append(eng.stats[(k + 1) % 2, 0].cpu().numpy().copy())
+        outs.append((np.array(stats), eng.x_filter[0].cpu().numpy(), eng.status.cpu().numpy(), eng._shard_sets.cpu().numpy()))
+    (s0, x0, st0, sh0), (s1, x1, st1, sh1) = outs
+    assert np.array_equal(s0, s1, equal_nan=True), (s0, s1)
+    assert np.array_equal(x0, x1, equal_nan=True) and np.array_equal(st0, st1)
+    assert not sh1.any()                     # sums and counters are back at zero after every launch
+    if m > 3:
+        assert np.isnan(s1[0, hip.lib.STAT_MAX_DPOS]) and s1[-1, hip.lib.STAT_N_FAILED] >= 2
+
+
 @pytest.mark.parametrize("fast", [False, True])
 def test_trace_only_payload_is_column_3_of_the_aer_block(hip, fast):
     """ssa_step_params.aer_cols = 1 (the per-object covariance-trace observation of the sharded 160 000-object configuration):
