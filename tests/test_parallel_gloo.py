@@ -86,10 +86,29 @@ def _worker(rank, world, port, q, raw=False, cols=4):
         sh.step(a)
         sh.wait()
         outs.append((sh.global_obs().numpy().copy(), sh.global_stats().copy()))
+        if raw:     # the fold of the raw shard words in torch (what GPU consumers use: no host round trip) equals the numpy one
+            dev = sh.global_stats_device().numpy()
+            ref = outs[-1][1]
+            assert np.array_equal(dev[[0, 1, 2, 4]], ref[[0, 1, 2, 4]], equal_nan=True) and dev[3] == -1.0 and np.isnan(dev[5])
     if rank == 0:
         q.put(outs)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_fold_raw_statistics_semantics():
+    """parallel.fold_raw_statistics: max by ordered bits with NaN on top (np.max), packed trinary counts, failures"""
+    from ssa_gym_amd.parallel import fold_raw_statistics, STAT_SHARD_WORDS
+    w = np.zeros((5, STAT_SHARD_WORDS), dtype=np.uint64)
+    w[0, 0] = np.array([3.5e6]).view(np.uint64)[0]
+    w[3, 0] = np.array([7.25e9]).view(np.uint64)[0]
+    w[1, 1] = np.uint64(3) | (np.uint64(11) << np.uint64(32))
+    w[4, 1] = np.uint64(2) | (np.uint64(5) << np.uint64(32))
+    w[2, 2] = 4
+    out = fold_raw_statistics(torch.as_tensor(w.view(np.int64))).numpy()
+    assert out[0] == 7.25e9 and out[1] == 5 and out[2] == 16 and out[4] == 4 and out[3] == -1.0 and np.isnan(out[5])
+    w[2, 0] = np.array([np.nan]).view(np.uint64)[0] & np.uint64(0x7fffffffffffffff)
+    assert np.isnan(fold_raw_statistics(torch.as_tensor(w.view(np.int64))).numpy()[0])
 
 
 def test_shard_plan():
