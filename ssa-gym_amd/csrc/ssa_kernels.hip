@@ -267,6 +267,25 @@ __device__ __noinline__ Vec6 kepler_general_tagged(Vec6 x, double tof)
 // call, four times the whole SSA_PROP_FG step, and late in an episode most wavefronts hold a diverged sigma point.
 // Episode-level failure statistics: as SSA_PROP_ELEMENTS / the oracle (tests/test_episode_failures.py).
 namespace genf {
+// log x for finite x > 0 (the arguments of this path: ratios and sums of positive magnitudes; anything else takes libm):
+// x = m 2^k with m in [sqrt(1/2), sqrt 2), log m = 2 atanh(s), s = (m - 1)/(m + 1), by the fdlibm kernel polynomial; < 1 ulp,
+// ~35 instructions (libm's log: ~80)
+__device__ static double log_pos(double x)
+{
+    if (!(x > 2.2250738585072014e-308 && x <= 1.79769313486231570e308)) return log(x);
+    int k;
+    double m = frexp(x, &k);                // m in [0.5, 1)
+    if (m < 0.70710678118654752440) { m += m; k -= 1; }
+    const double f = m - 1.0;
+    const double sq = div_fast(f, 2.0 + f);
+    const double z = sq * sq, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - (sq * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
 __device__ static double F_to_nu(double F, double ecc)
 {
     double sh, chm1;
@@ -278,23 +297,34 @@ __device__ static double nu_to_F(double nu, double ecc)
     double s, c;
     sincos_fast(nu, s, c);
     const double x = sqrt_fast(div_fast(ecc - 1.0, ecc + 1.0)) * div_fast(s, 1.0 + c);     // tan(nu/2) = sin nu / (1 + cos nu)
-    return log(div_fast(1.0 + x, 1.0 - x));                                                  // 2 atanh(x)
+    return log_pos(div_fast(1.0 + x, 1.0 - x));                                              // 2 atanh(x)
 }
 // newton() on e sinh F - F - M (farnocchia.py:337-353: step tolerance 1.48e-8, 100 iterations, NaN when it gives up)
 __device__ static double newton_hyp(double x0, double M, double ecc)
 {
     double p0 = x0, res = __builtin_nan("");
     bool done = false;
+    double sh, chm1;
+    sinh_coshm1(p0, sh, chm1);
     for (int i = 0; i < 100; ++i) {
-        double sh, chm1;
-        sinh_coshm1(p0, sh, chm1);
         const double fval = (ecc * sh - p0) - M;
         const double fder = ecc * (chm1 + 1.0) - 1.0;
         const double p = p0 - div_fast(fval, fder);
-        if (!done && fabs(p - p0) < NEWTON_TOL) { res = p; done = true; }
+        const double d = p - p0;
+        if (!done && fabs(d) < NEWTON_TOL) { res = p; done = true; }
         p0 = p;
         if (!(fabs(p0) <= 1.79769313486231570e308)) done = true;      // (inf / NaN iterate: it will never converge)
         if (__ballot(!done) == 0ull) break;
+        // sinh / cosh of the new iterate: by the addition formulas while every active lane's step is small (all steps after the
+        // first or second: the exponential of a fresh evaluation is four times as long), afresh otherwise
+        if (__ballot(!done && !(fabs(d) <= 0.02)) == 0ull) {
+            const double d2 = d * d;
+            const double sd = d * (1.0 + d2 * (1.0 / 6.0) * (1.0 + d2 * (1.0 / 20.0) * (1.0 + d2 * (1.0 / 42.0))));
+            const double cdm1 = d2 * 0.5 * (1.0 + d2 * (1.0 / 12.0) * (1.0 + d2 * (1.0 / 30.0) * (1.0 + d2 * (1.0 / 56.0))));
+            const double sh2 = fma(sh, cdm1, sh) + (chm1 + 1.0) * sd;
+            chm1 = fma(chm1, cdm1, chm1) + cdm1 + sh * sd;
+            sh = sh2;
+        } else sinh_coshm1(p0, sh, chm1);
     }
     return res;
 }
@@ -353,7 +383,7 @@ SSA_DEV Vec6 kepler_general_fast_impl(Vec6 xin, double tof)
         } else {
             double e_sh = rv * rsqrt_nr(-ka);
             double e_ch = rn * vv * inv_mu - 1.0;
-            nu = genf::F_to_nu(0.5 * log(div_fast(e_ch + e_sh, e_ch - e_sh)), ecc);
+            nu = genf::F_to_nu(0.5 * genf::log_pos(div_fast(e_ch + e_sh, e_ch - e_sh)), ecc);
         }
         raan = mod_2pi(atan2_fast(n[1], n[0]));
         double t[3] = {h[1] * n[2] - h[2] * n[1], h[2] * n[0] - h[0] * n[2], h[0] * n[1] - h[1] * n[0]};
@@ -376,7 +406,9 @@ SSA_DEV Vec6 kepler_general_fast_impl(Vec6 xin, double tof)
             const double nmm = sqrt_fast(div_fast(MU * em1 * em1 * em1, q * q * q));
             const double M = nmm * (div_fast(M0, nmm) + tof);
             const double me = div_fast(M, ecc);
-            const double F = genf::newton_hyp(log(me + sqrt_fast(me * me + 1.0)), M, ecc);   // asinh(M / e)
+            // asinh(M / e) = sign log(|.| + sqrt(.^2 + 1))
+            const double am = fabs(me);
+            const double F = genf::newton_hyp(copysign(genf::log_pos(am + sqrt_fast(am * am + 1.0)), me), M, ecc);
             nu1 = genf::F_to_nu(F, ecc);
         }
     } else {                  // elliptic / parabolic / near-parabolic bands: the complete restatement
