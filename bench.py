@@ -545,54 +545,70 @@ def main():
     # decided by measurement (a few units of each form), identically on every rank.
     graphed = None
     divs = [K] if K <= 120 else [d for d in range(2, 121) if K % d == 0]
+    graph_note = None
     if sharded is not None and not args.eager_sharded and divs:
         unit = max(divs)
         cyc = np.arange(plan.m_total)
-        probe, best = {}, None
-        for ov in ((False, True) if (world > 1 or os.environ.get("SSA_BENCH_PROBE_OVERLAP")) else (False,)):
+        probe, best, err = {}, None, None
+        try:
+            if os.environ.get("SSA_BENCH_FORCE_GRAPH_FAIL"):      # (rehearsal of the fallback)
+                raise RuntimeError("forced")
+            for ov in ((False, True) if (world > 1 or os.environ.get("SSA_BENCH_PROBE_OVERLAP")) else (False,)):
+                local.reset_episode(snap, ep_len)
+                gs = parallel.GraphedShardedSteps(sharded, unit, cyc, overlap=ov)
+                gs.rewind()
+                done_steps = 0
+                for _ in range(3):          # (captures: one per phase seen)
+                    if done_steps + unit > ep_len - 1:
+                        local.reset_episode(snap, ep_len)
+                        gs.rewind()
+                        done_steps = 0
+                    gs.run_unit()
+                    done_steps += unit
+                fence()
+                reps = max(3, 60 // unit)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    if done_steps + unit > ep_len - 1:
+                        local.reset_episode(snap, ep_len)
+                        gs.rewind()
+                        done_steps = 0
+                    gs.run_unit()
+                    done_steps += unit
+                fence()
+                probe[ov] = max_over_ranks_early((time.perf_counter() - t0) / (reps * unit))
+                if best is None or probe[ov] < 0.97 * probe[best[0]]:
+                    best = (ov, gs)
+        except Exception as exc:  # noqa: BLE001   (e.g. a runtime that cannot capture the collective: every rank falls back together)
+            err = exc
+        agreed = max_over_ranks_early(0.0 if (err is None and best is not None) else 1.0) == 0.0
+        if agreed:
+            graphed = best[1]
+            state["overlap"] = best[0]
+            allgather_probe = {"graph_unit": unit, "in_stream_ms": round(1e3 * probe[False], 5),
+                               "comm_stream_ms": round(1e3 * probe[True], 5) if True in probe else None}
             local.reset_episode(snap, ep_len)
-            gs = parallel.GraphedShardedSteps(sharded, unit, cyc, overlap=ov)
-            gs.rewind()
-            done_steps = 0
-            for _ in range(3):          # (captures: one per phase seen)
-                if done_steps + unit > ep_len - 1:
-                    local.reset_episode(snap, ep_len)
-                    gs.rewind()
-                    done_steps = 0
-                gs.run_unit()
-                done_steps += unit
-            fence()
-            reps = max(3, 60 // unit)
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                if done_steps + unit > ep_len - 1:
-                    local.reset_episode(snap, ep_len)
-                    gs.rewind()
-                    done_steps = 0
-                gs.run_unit()
-                done_steps += unit
-            fence()
-            probe[ov] = max_over_ranks_early((time.perf_counter() - t0) / (reps * unit))
-            if best is None or probe[ov] < 0.97 * probe[best[0]]:
-                best = (ov, gs)
-        graphed = best[1]
-        state["overlap"] = best[0]
-        allgather_probe = {"graph_unit": unit, "in_stream_ms": round(1e3 * probe[False], 5),
-                           "comm_stream_ms": round(1e3 * probe[True], 5) if True in probe else None}
-        local.reset_episode(snap, ep_len)
-        graphed.rewind()
-        state["i"] = 0
+            graphed.rewind()
+            state["i"] = 0
 
-        def timed_block_graph():
-            for _ in range(K // unit):
-                if state["i"] + unit > ep_len - 1:
-                    local.reset_episode(snap, ep_len)
-                    graphed.rewind()
-                    state["i"] = 0
-                graphed.run_unit()
-                state["i"] += unit
-        for _ in range(max(1, W // K)):     # (untimed: every phase's graph exists before the timed blocks)
-            timed_block_graph()
+            def timed_block_graph():
+                for _ in range(K // unit):
+                    if state["i"] + unit > ep_len - 1:
+                        local.reset_episode(snap, ep_len)
+                        graphed.rewind()
+                        state["i"] = 0
+                    graphed.run_unit()
+                    state["i"] += unit
+            for _ in range(max(1, W // K)):     # (untimed: every phase's graph exists before the timed blocks)
+                timed_block_graph()
+        else:
+            graph_note = "hipGraph capture of the sharded unit failed on at least one rank (%r): per-step enqueue" % (err,)
+            sys.stderr.write("bench: %s\n" % graph_note)
+            eng.env_time0.zero_()
+            local.reset_episode(snap, ep_len)
+            state["i"] = 0
+    if graphed is not None:
+        pass
     elif sharded is not None and W >= 40:
         h = W // 2
         times = []
@@ -629,6 +645,8 @@ def main():
 
     # sanity: nothing diverged during the run
     n_failed = int((eng.status != 0).sum().item())
+    if graphed is not None:
+        eng.env_time0.zero_()      # (the graphs advanced the time origin on the device; what follows enqueues steps one by one)
 
     # ---- dominant kernel, timed live with events on the launch stream: K back-to-back launches
     # of the fused step kernel alone (no statistics kernel, no collective)
@@ -755,7 +773,7 @@ def main():
                                          if sharded is not None else None),
                        "allgather_warmup_probe": allgather_probe,
                        "sharded_enqueue": (("hipGraph replay, %d steps per graph (episodes of whole units)" % graphed.U) if graphed is not None
-                                           else ("per step from the host" if use_dist else None)),
+                                           else ((graph_note or "per step from the host") if use_dist else None)),
                        "allgather_bytes_per_rank": (sharded.width * 8 if sharded is not None else None),
                        "rccl_ranks": (sharded._rccl.count() if (sharded is not None and sharded._rccl is not None)
                                       else (dist.get_world_size() if use_dist else None)),
