@@ -546,7 +546,10 @@ def main():
     graphed = None
     divs = [K] if K <= 120 else [d for d in range(2, 121) if K % d == 0]
     graph_note = None
-    if sharded is not None and not args.eager_sharded and divs:
+    # (more than one rank: opt-in with SSA_BENCH_GRAPH_SHARDED=1 -- the capture of RCCL's collective has only ever run on ONE rank here,
+    # the per-step enqueue is the form the multi-rank logic was built and tested around)
+    want_graph = not args.eager_sharded and (world == 1 or os.environ.get("SSA_BENCH_GRAPH_SHARDED") == "1")
+    if sharded is not None and want_graph and divs:
         unit = max(divs)
         cyc = np.arange(plan.m_total)
         probe, best, err = {}, None, None
