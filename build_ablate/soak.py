@@ -9,6 +9,34 @@ from ssa_gym_amd import host, engine, _lib
 m, EP = 20000, int(os.environ.get("EPISODES", "20"))
 pb = bench.build_problem(m, seed=100)
 consts = host.make_consts(pb["Q"], pb["R"], 1e-4, 2.0, -3, 20.0, np.radians(10.0), pb["obs_lla"], obs_type='aer', propagator='fg')
+def run_persistent():
+    """the closed loop through ssa_env_closed_loop_f64: one launch per 479-step episode; must hash like the per-step closed loop"""
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    zn = torch.randn((1, 480, m, 3), dtype=torch.float64, device="cuda", generator=gen) * torch.as_tensor(pb["z_sigma"], device="cuda")
+    eng = engine.HotPathEngine(consts, m, 1, pb["trans"], zn, history=2)
+    eng.load_state(0, pb["x_true"], pb["x"], np.broadcast_to(pb["P0"], (m, 6, 6)))
+    snap = eng.snapshot(0)
+    fb = torch.zeros(481, dtype=torch.int32, device="cuda")
+    log = torch.zeros(480, dtype=torch.int32, device="cuda")
+    stats = torch.zeros((479, 8), dtype=torch.float64, device="cuda")
+    h = hashlib.sha256(); tick = 0; fails = []
+    t0 = time.perf_counter()
+    for ep in range(EP):
+        tick += (-tick) % 480
+        eng.restore(tick % 2, snap)
+        eng.launch_agent_select(tick, tick, _lib.AGENT_VISIBLE_GREEDY, log.data_ptr(), fallback_ptr=fb.data_ptr())
+        assert eng.launch_closed_loop(tick % 2, tick + 1, _lib.AGENT_VISIBLE_GREEDY, log, stats, fallback=fb[:480])
+        tick += 479
+        torch.cuda.synchronize()
+        assert int(eng.loop_error[0]) == 0
+        s = tick % 2
+        eng.stats[s, 0].copy_(stats[478])
+        for tns in (eng.x_true[s], eng.x_filter[s], eng.P_filter[s], eng.stats[s], eng.status):
+            h.update(tns.cpu().numpy().tobytes())
+        fails.append(int((eng.status != 0).sum().item()))
+    return h.hexdigest(), fails, time.perf_counter() - t0
+
+
 def run(closed):
     gen = torch.Generator(device="cuda").manual_seed(7)
     zn = torch.randn((1, 480, m, 3), dtype=torch.float64, device="cuda", generator=gen) * torch.as_tensor(pb["z_sigma"], device="cuda")
@@ -43,3 +71,8 @@ for closed in (False, True):
           "run 1 == run 2 bit for bit: %s  (sha256 %s)" % ("closed loop (visible greedy, 10 deg mask)" if closed else "round-robin schedule",
           EP, a[2], EP * 479 / a[2], min(a[1]), max(a[1]), a[0] == b[0], a[0][:16]), flush=True)
     assert a[0] == b[0]
+a = run_persistent(); b = run_persistent(); c = run(True)
+print("closed loop in one persistent launch per episode: %d episodes x 479 steps, %.1f s (%.0f env-steps/s incl. resets and read-back); failed filters at "
+      "episode ends: min %d max %d; run 1 == run 2 bit for bit: %s; == the per-step closed loop bit for bit: %s  (sha256 %s)"
+      % (EP, a[2], EP * 479 / a[2], min(a[1]), max(a[1]), a[0] == b[0], a[0] == c[0], a[0][:16]), flush=True)
+assert a[0] == b[0] == c[0]
