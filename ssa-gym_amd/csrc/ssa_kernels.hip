@@ -1851,6 +1851,15 @@ SSA_DEV int xcd_tile(int b, int n)
 // MULTI = false is the one-tile-per-wavefront instance (every launch up to 20 480 objects): no loop, no staging
 // registers.
 typedef const __attribute__((address_space(4))) StepK* KernargPtr;
+// The kernarg segment of step_fast_kernel as a struct: kernel arguments are laid out in declaration order at their natural
+// alignment, exactly as the members of this mirror are (tests/test_abi_and_host.py parses the shipped code object's metadata
+// and checks the offset of the by-value block against it).
+struct StepFastArgs {
+    int ntiles, nwork;
+    const double *pre_P_in, *pre_x_in, *pre_x_true_in;
+    const int32_t* pre_status;
+    StepK k;
+};
 // The leading arguments -- the two tile counts and the pointers k_arg.p.{P_in, x_in, x_true_in, status} repeated -- are plain
 // scalars: they are PRELOADED into SGPRs at wavefront launch (-amdgpu-kernarg-preload-count, _build.py), so the tile's loads -- the first link
 // of every wavefront's dependency chain -- leave without waiting for a scalar-memory round trip to the kernarg segment.
@@ -1896,7 +1905,7 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(int ntile
         // instead of being carried around the loop in registers
         asm volatile("" : "+s"(kp));
         asm volatile("" : "+v"(lane));
-        const StepK& k = *(const StepK*)((const char*)kp + 2 * sizeof(int) + 4 * sizeof(void*));   // behind the preloaded scalar arguments
+        const StepK& k = *(const StepK*)((const char*)kp + offsetof(StepFastArgs, k));   // behind the preloaded scalar arguments
         const int64_t base = (int64_t)tile * OBJ_PER_WAVE;
         const int cnt = (int)((total - base) < OBJ_PER_WAVE ? (total - base) : OBJ_PER_WAVE);
         const int nt = tile + nwork;

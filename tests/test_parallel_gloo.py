@@ -176,3 +176,111 @@ def test_bench_self_launches_its_ranks_dry_run():
     assert len(lines) == 1, out.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["dry_run"] is True and rec["config"]["ranks"] == 2 and rec["config"]["payload_ok"] is True
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The PRODUCT's sharded path at world size 2 on one card: two processes, each with its own HIP engine for its shard of the
+# objects on cuda:0, the payload all-gather carried by gloo (RCCL refuses two ranks on one device; the collective is the
+# only piece replaced -- partition, owner-only update, raw statistics words in the payload, the step kernel writing its
+# observation block straight into the send buffer are the code bench.py --gpus N runs).
+def _hip_worker(rank, world, port, q, m, actions, cols):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    try:
+        import ssa_gym_amd
+        from ssa_gym_amd import _lib, engine, host, parallel
+        ssa_gym_amd.build()
+        _lib.load()
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        xt, x, P, g, zn, c2t = _hip_problem(m)
+        plan = parallel.ShardPlan(m, world, rank)
+        sl = slice(plan.lo, plan.hi)
+        consts = host.make_consts(g["Q"], g["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, g["obs_lla"])
+        eng = engine.HotPathEngine(consts, plan.m_local, 1, c2t, np.ascontiguousarray(zn[:, :, sl]), history=2)
+        eng.load_state(0, xt[sl], x[sl], P[sl])
+        local = parallel.HipLocalStepper(eng, consts, fast_stats=True)
+        sh = parallel.ShardedStepper(plan, local, obs_cols=cols)
+        assert sh._rccl is None and sh._local_raw
+        outs = []
+        for k, a in enumerate(actions):
+            sh.step(a, overlap=(k % 3 == 2))
+            sh.wait()
+            torch.cuda.synchronize()
+            dev = sh.global_stats_device().cpu().numpy()
+            st = sh.global_stats()
+            assert np.array_equal(dev[[0, 1, 2, 4]], st[[0, 1, 2, 4]], equal_nan=True)
+            outs.append((sh.global_obs().cpu().numpy(), st))
+        t = local.tick % 2
+        state = (eng.x_true[t].cpu().numpy(), eng.x_filter[t].cpu().numpy(), eng.P_filter[t].cpu().numpy(), eng.status.cpu().numpy())
+        q.put((rank, outs if rank == 0 else None, state))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as exc:   # (the parent must not wait for a queue item that never comes)
+        import traceback
+        q.put((rank, "error: %s\n%s" % (exc, traceback.format_exc()), None))
+        raise
+
+
+def _hip_problem(m):
+    rs = np.random.RandomState(11)
+    cat = golden("catalogue_subset.npy")
+    g = golden("ukf_step_golden.npz")
+    xt = cat[rs.randint(0, len(cat), m)]
+    x = xt + rs.normal(size=(m, 6)) * np.array([1e5] * 3 + [1e2] * 3)
+    P = np.tile(g["P0"], (m, 1, 1))
+    zn = rs.normal(size=(1, 480, m, 3)) * np.array([4.8e-6, 4.8e-6, 1e3])
+    return xt, x, P, g, zn, golden("c2t_2020-05-04_dt20_n480.npy")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cols", [4, 1])
+def test_sharded_hip_env_world2_shares_one_gpu(cols):
+    """1 003 objects split 502 + 501 over two ranks (two processes on cuda:0), 8 steps whose actions land in both shards:
+    the gathered observation vector, the folded statistics and every rank's slice of the state equal the unsharded HIP
+    engine's BIT FOR BIT (an object's arithmetic does not depend on which wavefront or rank holds it)."""
+    import ssa_gym_amd
+    from ssa_gym_amd import _lib, engine, host, parallel
+    ssa_gym_amd.build()
+    _lib.load()
+    assert torch.cuda.is_available()
+    m, world = 1003, 2
+    actions = [3, 700, 501, 502, 17, 1002, 0, 640]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + (5 if cols == 1 else 0)
+    procs = [ctx.Process(target=_hip_worker, args=(r, world, port, q, m, actions, cols)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        rank, outs, state = q.get(timeout=300)
+        assert state is not None, outs
+        got[rank] = (outs, state)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # the unsharded run of the same env on this process's engine
+    xt, x, P, g, zn, c2t = _hip_problem(m)
+    consts = host.make_consts(g["Q"], g["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, g["obs_lla"])
+    eng = engine.HotPathEngine(consts, m, 1, c2t, zn, history=2)
+    eng.load_state(0, xt, x, P)
+    local = parallel.HipLocalStepper(eng, consts, fast_stats=True)
+    sh = parallel.ShardedStepper(parallel.ShardPlan(m, 1, 0), local, obs_cols=cols)
+    k_st = [parallel.STAT_MAX_DPOS, parallel.STAT_CNT_LT_1E4, parallel.STAT_CNT_LT_1E7, parallel.STAT_N_FAILED]
+    for k, a in enumerate(actions):
+        sh.step(a)
+        torch.cuda.synchronize()
+        obs, st = sh.global_obs().cpu().numpy(), sh.global_stats()
+        assert obs.shape == (cols * m,) and np.array_equal(obs, got[0][0][k][0], equal_nan=True), k
+        assert np.array_equal(st[k_st], got[0][0][k][1][k_st], equal_nan=True), k
+    t = local.tick % 2
+    full = (eng.x_true[t].cpu().numpy(), eng.x_filter[t].cpu().numpy(), eng.P_filter[t].cpu().numpy(), eng.status.cpu().numpy())
+    for r in range(world):
+        plan = parallel.ShardPlan(m, world, r)
+        for a, b in zip(full, got[r][1]):
+            assert np.array_equal(a[plan.lo:plan.hi], b, equal_nan=True), r
+    # the updates happened (both shards): the selected objects' covariances shrank below the propagated prior's
+    trP = np.trace(full[2], axis1=1, axis2=2)
+    assert np.all(trP[[3, 700, 501, 502]] < 0.5 * np.median(trP))
