@@ -466,11 +466,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
+    # SSA_BENCH_REHEARSAL=1: functional rehearsal of the N-rank path on a box with ONE card -- every rank on cuda:0, the
+    # collectives carried by gloo (RCCL refuses two ranks on one device).  Exercises everything but RCCL itself; the ranks share
+    # the GPU, so the line it prints is marked and is never a measurement.
+    rehearsal = os.environ.get("SSA_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or "RANK" in os.environ   # under torch.distributed.run even 1 rank goes through RCCL
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if rank == 0:
         ssa_gym_amd.build()          # no-op when the in-tree libssa_hip.so is current
     if use_dist:
@@ -789,6 +798,8 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "episode_failures": ep_fail, "rollout": roll,
         }
         out.update(legs)
+        if rehearsal:
+            out["rehearsal"] = "SSA_BENCH_REHEARSAL=1: all ranks share cuda:0, collectives over gloo -- functional check only, NOT a measurement"
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(steps_per_s * world / cpu["value"], 1)
             out["speedup_vs_cpu_baseline_all_cores"] = round(steps_per_s * world / cpu_all["value"], 1)

@@ -259,6 +259,10 @@ class GraphedShardedSteps:
             raise ValueError("graphed sharded steps: one env, history depth 2")
         if not self.sh._gpu or not getattr(self.local, "raw_shards", False):
             raise ValueError("graphed sharded steps need the HIP stepper")
+        if self.sh._use_dist and self.sh._rccl is None:
+            # (a ProcessGroup collective is not captured here: gloo's runs on the host, and a capture that fails half way leaves
+            # the backend's internal streams in capture mode -- refuse BEFORE anything is captured, the caller enqueues per step)
+            raise ValueError("graphed sharded steps need the direct RCCL all-gather (rccl.py); this group has none")
         plan = sharded.plan
         sched = np.asarray([plan.local_action(int(a)) for a in schedule_global], dtype=np.int32)
         dev = self.eng.dev
@@ -309,6 +313,22 @@ class GraphedShardedSteps:
         eng.env_time0.add_(U)
         self.cursor.add_(U)
 
+    def _end_stray_capture(self):
+        """after a failed capture: no stream of ours may be left in capture mode (hipStreamIsCapturing / hipStreamEndCapture)"""
+        import ctypes
+        try:
+            hip = ctypes.CDLL("libamdhip64.so")
+        except OSError:
+            return
+        for st in (self._stream, self.sh.comm):
+            status = ctypes.c_int(0)
+            if hip.hipStreamIsCapturing(ctypes.c_void_p(st.cuda_stream), ctypes.byref(status)) == 0 and status.value != 0:
+                graph = ctypes.c_void_p()
+                hip.hipStreamEndCapture(ctypes.c_void_p(st.cuda_stream), ctypes.byref(graph))
+                if graph.value:
+                    hip.hipGraphDestroy(graph)
+        hip.hipGetLastError()     # (the sticky error of the failed capture is consumed here, not by the next launch)
+
     def run_unit(self):
         """replay (capture on first use) the unit for the current phase; returns nothing, synchronises nothing"""
         sh, local = self.sh, self.local
@@ -324,9 +344,24 @@ class GraphedShardedSteps:
             with torch.cuda.stream(self._stream):
                 self._enqueue_unit(local.tick, sh.k)
                 self._stream.synchronize()
+            # (begin / end by hand instead of `with torch.cuda.graph(...)`: when the capture fails -- a collective that cannot be
+            # captured -- the context manager's exit raises from capture_end() before it restores the current stream, and a stream
+            # left capturing makes the next allocation or copy of the process fail.  Here a failed capture is ended, every stream
+            # is checked, the current stream is restored, and the caller sees ONE exception it can fall back from.)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=self._stream):
-                self._enqueue_unit(local.tick, sh.k)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(self._stream):
+                g.capture_begin(capture_error_mode="thread_local")
+                try:
+                    self._enqueue_unit(local.tick, sh.k)
+                    g.capture_end()
+                except BaseException:
+                    try:
+                        g.capture_end()
+                    except Exception:  # noqa: BLE001  (an invalidated capture reports its error again here)
+                        pass
+                    self._end_stray_capture()
+                    raise
             self._graphs[key] = g
             cur.wait_stream(self._stream)
             local.tick += self.U

@@ -284,3 +284,24 @@ def test_sharded_hip_env_world2_shares_one_gpu(cols):
     # the updates happened (both shards): the selected objects' covariances shrank below the propagated prior's
     trP = np.trace(full[2], axis1=1, axis2=2)
     assert np.all(trP[[3, 700, 501, 502]] < 0.5 * np.median(trP))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--steps", "20", "--warmup", "5"], ["--steps", "40", "--warmup", "40", "--payload", "aer"]])
+def test_bench_two_ranks_rehearsal_on_one_gpu(extra):
+    """`python bench.py --gpus 2` end to end with the HIP engine in both ranks (SSA_BENCH_REHEARSAL=1: the ranks share cuda:0 and
+    gloo carries the collectives -- the launcher, the warm-up probe of where the all-gather runs, the timed blocks with MAX over
+    ranks, the roofline leg on rank 0 while rank 1 waits, the closing barrier).  The rate it prints is NOT a measurement."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["SSA_BENCH_REHEARSAL"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--objects", "4000"] + extra,
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and "rehearsal" in rec and rec["failed_filters"] == 0 and rec["value"] > 0
+    assert rec["config"]["objects_total"] == 8000 and rec["config"]["rccl_ranks"] == 2
+    assert rec["config"]["allgather_api"] == "torch.distributed.all_gather_into_tensor" and rec["roofline"]["kernel_ms"] > 0
