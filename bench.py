@@ -329,14 +329,14 @@ def gym_api_rate(m, mode, n=200):
             "obs_bytes_per_step": m * (12 if mode == 'flatten' else 4) * 8}
 
 
-def vec_env_rate(m, E=8, n=60):
+def vec_env_rate(m, E=8, n=60, obs_device=False):
     """BASELINE config 5's per-GPU load through the vector-env API: E envs of m objects advanced by ONE launch per
     SSA_Tasker_VecEnv.step() (per-env actions and time indices, auto-reset), host in the loop, the E 'aer' observation
     vectors returned over PCIe.  Reported in 20 000-object env-steps per second (E per call).  Never `value`."""
     from ssa_gym_amd.envs import env_config
     from ssa_gym_amd.envs.vector_env import SSA_Tasker_VecEnv
     cfg = dict(env_config)
-    cfg.update(rso_count=m, steps=480, reward_type='trinary', obs_returned='aer', seed=0, device_rng=True)
+    cfg.update(rso_count=m, steps=480, reward_type='trinary', obs_returned='aer', seed=0, device_rng=True, obs_device=obs_device)
     env = SSA_Tasker_VecEnv(cfg, num_envs=E, seed=0)
     acts = lambda k: [(k * 7 + 13 * e) % m for e in range(E)]    # noqa: E731
     for k in range(10):
@@ -351,8 +351,10 @@ def vec_env_rate(m, E=8, n=60):
     dt = el / n
     return {"value": round(E / dt * (m / 20000.0), 2), "ms_per_vector_step": round(1e3 * dt, 5), "envs": E,
             **spread(n, E * m / 20000.0, el, lo, hi, reps),
-            "obs_bytes_per_step": E * m * 4 * 8,
-            "note": "SSA_Tasker_VecEnv.step(): %d envs x %d objects per launch, host in the loop, PCIe inclusive" % (E, m)}
+            "obs_bytes_per_step": 0 if obs_device else E * m * 4 * 8,
+            "note": ("SSA_Tasker_VecEnv.step() with config['obs_device']: %d envs x %d objects per launch, host in the loop; the observations stay "
+                     "on the GPU (CUDA tensor returned, for policies that live there), rewards / dones cross PCIe" % (E, m)) if obs_device else
+                    "SSA_Tasker_VecEnv.step(): %d envs x %d objects per launch, host in the loop, PCIe inclusive" % (E, m)}
 
 
 def self_launch(argv, n):
@@ -747,6 +749,7 @@ def main():
                            "note": "SSA_Tasker_Env.step() per call, host in the loop, PCIe + one sync inclusive (20 000 objects)"}
         if m == 20000:
             legs["vec_env"] = vec_env_rate(m)
+            legs["vec_env_device_obs"] = vec_env_rate(m, obs_device=True)
 
     cpu, cpu_all, ep_fail = None, None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N=1 only

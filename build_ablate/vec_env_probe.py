@@ -45,6 +45,23 @@ def piece(aer_ptr, copy, sync=True, stats_host=True):
 
 
 env._time_np[:] = 5
+
+
+def inline_piece(aer_ptr, sync=True):
+    def f(k):
+        state["tick"] += 1
+        t = state["tick"]
+        e.launch_step((t - 1) % 2, t % 2, 0, aer_out=aer_ptr, stats_out=env._stats_host.data_ptr(), stream=cur.cuda_stream,
+                      fast_stats=True, fold_inside=True, env_words=([5] * E, acts(k)))
+        if sync:
+            cur.synchronize()
+    return f
+
+
+timeit("ONE launch (words by value, folds inside; obs -> host-mapped) + sync", inline_piece(env._obs_ring_ptr[0]))
+timeit("ONE launch (words by value, folds inside; obs -> device) + sync", inline_piece(dev_aer.data_ptr()))
+timeit("ONE launch (words by value, folds inside; obs -> host-mapped), no per-step sync", inline_piece(env._obs_ring_ptr[0], sync=False))
+timeit("ONE launch (words by value, folds inside; obs -> device), no per-step sync", inline_piece(dev_aer.data_ptr(), sync=False))
 timeit("copy + launch (obs -> host-mapped) + sync", piece(env._obs_ring_ptr[0], True))
 timeit("       launch (obs -> host-mapped) + sync", piece(env._obs_ring_ptr[0], False))
 timeit("copy + launch (obs -> device) + sync", piece(dev_aer.data_ptr(), True))

@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define SSA_ABI_VERSION 19
+#define SSA_ABI_VERSION 20
+#define SSA_INLINE_ENVS 8
 
 /* error codes */
 #define SSA_OK 0
@@ -186,6 +187,9 @@ typedef struct ssa_step_params {
                                   `obs`.  Meant for host-mapped pinned memory: the 'flatten' observation of a gym-style caller then
                                   reaches the host from inside the kernel, overlapped with the other wavefronts' arithmetic, instead
                                   of through a copy-engine pass after it (1.92 MB at 20 000 objects: 44 us) */
+    int32_t inline_time[SSA_INLINE_ENVS];   /* with SSA_LAUNCH_INLINE_ENVS (n_env <= SSA_INLINE_ENVS): env e's time index and action BY VALUE; */
+    int32_t inline_action[SSA_INLINE_ENVS]; /* `env_time` / `actions` are then not read (env_time must still be non-NULL).  A vector env whose
+                                  actions are born on the host every step saves the host-to-device copy in front of the launch */
 } ssa_step_params;
 
 /* ---------------------------------------------------------------- fused hot path
@@ -206,10 +210,14 @@ int ssa_env_step_f64(const ssa_consts *c_host, const ssa_step_params *p_host, vo
 #define SSA_PROFILE_SLOTS 1024
 #define SSA_LAUNCH_DEFER_FOLD 8u
 #define SSA_LAUNCH_INLINE_ACTION 16u /* the env's action is ssa_step_params.action0 (n_env == 1) */
-#define SSA_LAUNCH_FOLD_INSIDE 32u   /* with stat_shards + stats, one env, no deferral: the statistics are folded by the step kernel's LAST
-                                        wavefront (it counts the tiles behind the shards' sums, words 3 / 4 of the shard lines) instead of by
-                                        a fold kernel launched behind the step: ONE launch per step with the statistics available when it
-                                        completes -- for callers that read them on the host after every step */
+#define SSA_LAUNCH_FOLD_INSIDE 32u   /* with stat_shards + stats, no deferral: the statistics of env e are folded by the LAST wavefront of the
+                                        step kernel that adds to them (it counts the tiles behind the shards' sums, words 3 / 4 of the env's
+                                        shard lines) instead of by a fold kernel launched behind the step: ONE launch per step with the
+                                        statistics available when it completes -- for callers that read them on the host after every step.
+                                        Launches with more than one tile per wavefront (> 20 480 objects in all) get the fold kernel behind
+                                        the step instead: counting a tile costs such a wavefront a memory round trip per tile */
+#define SSA_LAUNCH_INLINE_ENVS 64u   /* time indices and actions of all envs are ssa_step_params.inline_time / inline_action (n_env <= 8);
+                                        time_offset is still added */
 int ssa_env_step_profiled_f64(const ssa_consts *c_host, const ssa_step_params *p_host, void *stream, int32_t slot);
 /* waits for slot's kernel and writes its duration in milliseconds */
 int ssa_env_step_profile_ms(int32_t slot, float *kernel_ms);

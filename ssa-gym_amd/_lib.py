@@ -34,6 +34,7 @@ class ssa_step_params(C.Structure):
         ("n_time", C.c_int32), ("launch_mask", C.c_uint32), ("stats", c_dp), ("work", c_dp), ("stat_ws", c_dp),
         ("stat_shards", c_dp), ("stat_shards_prev", c_dp), ("stats_prev", c_dp), ("aer_out", c_dp),
         ("stat_shards_clear", c_dp), ("aer_cols", C.c_int32), ("action0", C.c_int32), ("obs_mirror", c_dp),
+        ("inline_time", C.c_int32 * 8), ("inline_action", C.c_int32 * 8),
     ]
 
 
@@ -56,7 +57,7 @@ class ssa_closed_loop_params(C.Structure):
 
 # constants of include/ssa_hip.h
 E_INVALID, E_LAUNCH, E_UNSUPPORTED = -1, -2, -3
-ABI_VERSION = 19
+ABI_VERSION = 20
 ST_OK, ST_PREDICT_NAN, ST_PREDICT_LINALG, ST_UPDATE_NAN, ST_UPDATE_LINALG = range(5)
 OBS_AER, OBS_XYZ = 0, 1
 PROP_ELEMENTS, PROP_FG, PROP_J2_RK4, PROP_HYBRID = 0, 1, 2, 3
@@ -69,6 +70,8 @@ PROFILE_SLOTS = 1024
 LAUNCH_DEFER_FOLD = 8
 LAUNCH_INLINE_ACTION = 16
 LAUNCH_FOLD_INSIDE = 32
+LAUNCH_INLINE_ENVS = 64
+INLINE_ENVS = 8
 AGENT_NAIVE_GREEDY, AGENT_VISIBLE_GREEDY, AGENT_SHANNON, AGENT_POS_ERROR, AGENT_VEL_ERROR = range(5)
 STAT_STRIDE, STAT_MAX_DPOS, STAT_CNT_LT_1E4, STAT_CNT_LT_1E7, STAT_ARGMAX_SPOS, STAT_N_FAILED, STAT_MAX_SPOS = 8, 0, 1, 2, 3, 4, 5
 

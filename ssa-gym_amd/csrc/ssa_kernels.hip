@@ -985,7 +985,29 @@ SSA_DEV int robust_chol_row_lds(Tiles& t, double scale, int g, int l)
 }
 
 // the action of env e: the word in memory, or the value in the parameter block (SSA_LAUNCH_INLINE_ACTION, one env)
-SSA_DEV int env_action(const ssa_step_params& p, int e) { return (p.launch_mask & SSA_LAUNCH_INLINE_ACTION) ? p.action0 : p.actions[e]; }
+// (word e of an array in the parameter block, by a chain of selects over constant indices: a register-indexed read would make
+// the kernels that keep a modified copy of the block -- rollout, closed loop -- spill the whole array to scratch)
+SSA_DEV int inline_word(const int32_t (&w)[SSA_INLINE_ENVS], int e)
+{
+    int v = w[0];
+#pragma unroll
+    for (int i = 1; i < SSA_INLINE_ENVS; ++i) v = (e == i) ? w[i] : v;
+    return v;
+}
+// INL = false: the instance never sees SSA_LAUNCH_INLINE_ENVS (rollout and closed-loop kernels, whose per-step copy of the block
+// stays in scalar registers only while nothing indexes into it)
+template <bool INL = true>
+SSA_DEV int env_action(const ssa_step_params& p, int e)
+{
+    if (INL && (p.launch_mask & SSA_LAUNCH_INLINE_ENVS)) return inline_word(p.inline_action, e);
+    return (p.launch_mask & SSA_LAUNCH_INLINE_ACTION) ? p.action0 : p.actions[e];
+}
+// ... and its time index (before time_offset): the word in memory, or the parameter block's (SSA_LAUNCH_INLINE_ENVS)
+template <bool INL = true>
+SSA_DEV int env_time_of(const ssa_step_params& p, int e)
+{
+    return (INL && (p.launch_mask & SSA_LAUNCH_INLINE_ENVS)) ? inline_word(p.inline_time, e) : p.env_time[e];
+}
 // tix % n_time, the division (a ~25-instruction sequence on the vector unit) only when the index has actually wrapped
 SSA_DEV int time_row(int tix, int n_time)
 {
@@ -1001,7 +1023,7 @@ SSA_DEV void aer_obs_row(const double* x, const double* P, const ssa_step_params
         p.aer_out[obj] = (fabs(tr1) <= 1.79769313486231570e308) ? tr1 : 0.001;
         return;
     }
-    const int tix = p.env_time[e] + p.time_offset;
+    const int tix = env_time_of(p, e) + p.time_offset;
     const double* M = p.trans + (int64_t)((p.n_time > 0) ? tix % p.n_time : 0) * 9;
     double Mm[9], xx[3] = {x[0], x[1], x[2]}, z[3];
 #pragma unroll
@@ -1035,6 +1057,7 @@ SSA_DEV void aer_obs_tile_at(const Tiles& t, const ssa_step_params& p, const ssa
     const double v = (l < 2) ? a : (l == 2) ? rt : tr;
     p.aer_out[obj * 4 + l] = (fabs(v) <= 1.79769313486231570e308) ? v : 0.001;
 }
+template <bool INL>
 SSA_DEV void aer_obs_tile(const Tiles& t, const ssa_step_params& p, const ssa_consts& C, int g, int l, int e, int64_t obj)
 {
     if (p.aer_cols == 1) {   // trace P only: lane 0 of the row
@@ -1046,8 +1069,8 @@ SSA_DEV void aer_obs_tile(const Tiles& t, const ssa_step_params& p, const ssa_co
         return;
     }
     // one env: the time index is wave-uniform, so the GCRS->ITRS matrix arrives by scalar loads (nine per-lane loads otherwise)
-    if (p.n_env > 1) aer_obs_tile_at(t, p, C, g, l, obj, p.env_time[e] + p.time_offset);
-    else aer_obs_tile_at(t, p, C, g, l, obj, p.env_time[0] + p.time_offset);
+    if (p.n_env > 1) aer_obs_tile_at(t, p, C, g, l, obj, env_time_of<INL>(p, e) + p.time_offset);
+    else aer_obs_tile_at(t, p, C, g, l, obj, env_time_of<INL>(p, 0) + p.time_offset);
 }
 
 #ifdef SSA_CL_TRACE   // diagnostic build only (build_ablate/closed_loop_timeline.py): closed_loop_kernel, steps SSA_CL_TRACE and + 1
@@ -1069,6 +1092,28 @@ __device__ unsigned long long g_trace[16384 * 16];
 // launch, ~4 us on the GPU and 2 us of enqueueing).  Word 3 of every shard counts the tiles that have added to it, word 4 of shard 0
 // the shards that are complete; a wavefront bumps them only after its own atomics are acknowledged, so whoever completes the last
 // shard reads finished sums (agent-scope loads), writes `stats` and clears shards and counters for the next step.
+// (one lane, after its atomics into shard `tile & 127` of env e are acknowledged) counts the tile; true = it completed env e.
+// Tiles that add to env e: t_lo = first object / 4 ... t_hi = last object / 4 (a tile that straddles two envs counts in both).
+SSA_DEV bool stat_tile_counted(const ssa_step_params& p, int64_t e, int tile)
+{
+    const int64_t first = e * p.n_obj;
+    const int t_lo = (int)(first / OBJ_PER_WAVE), t_hi = (int)((first + p.n_obj - 1) / OBJ_PER_WAVE);
+    const int shard = tile & (SSA_STAT_SHARDS - 1);
+    // tiles of [t_lo, t_hi] congruent to `shard` modulo 128 (arithmetic shifts: floor division of the negative operands too)
+    const unsigned expect = (unsigned)(((t_hi - shard) >> 7) - ((t_lo - 1 - shard) >> 7));
+    unsigned long long* env0 = (unsigned long long*)p.stat_shards + e * SSA_STAT_SHARDS * SSA_STAT_SHARD_WORDS;
+    unsigned long long* sh = env0 + (int64_t)shard * SSA_STAT_SHARD_WORDS;
+    const unsigned old = (unsigned)__hip_atomic_fetch_add(sh + 3, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old != expect - 1u) return false;
+    __hip_atomic_store(sh + 3, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int nt = t_hi - t_lo + 1;
+    const unsigned used = (unsigned)(nt < SSA_STAT_SHARDS ? nt : SSA_STAT_SHARDS);
+    const unsigned old2 = (unsigned)__hip_atomic_fetch_add(env0 + 4, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old2 != used - 1u) return false;
+    __hip_atomic_store(env0 + 4, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
 SSA_DEV void fold_stat_shards_inside(unsigned long long* __restrict__ shards, double* __restrict__ stats, int lane)
 {
     unsigned long long* sh = shards + (int64_t)lane * SSA_STAT_SHARD_WORDS;
@@ -1208,6 +1253,11 @@ template <int PROP, int TILE, class ACT>
 SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& p, int lane, int64_t obj_in, bool valid,
                           int64_t base, int cnt, TileRegs& pf, int64_t next_base, int next_cnt, int tile, ACT& asrc)
 {
+    constexpr bool INL = (TILE != 2) && !ACT::late;   // (the per-step launches: SSA_LAUNCH_INLINE_ENVS may be set)
+    // SSA_LAUNCH_FOLD_INSIDE exists in the one-tile instance only: counting a tile means waiting for its atomics' acknowledgement
+    // and for a returning atomic -- once, at the end of a one-tile wavefront's life, but ~1.5 us per tile in the grid-stride
+    // instance (8 x 20 000 objects: 100.7 us per step instead of 89.0); the launcher sends those launches a fold kernel instead
+    constexpr bool FOLD_OK = (TILE == 0);
     int g = lane >> 4, l = lane & 15;
     int64_t obj = obj_in;
     // (TILE 0: the kernel issued the tile's loads from its preloaded pointer arguments before anything else.)  First thing here,
@@ -1232,10 +1282,10 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         act = -1;
         tix = valid ? p.env_time[0] + p.time_offset : 0;
     } else if (p.n_env > 1) {
-        act = valid ? p.actions[e] : -1;
-        tix = valid ? p.env_time[e] + p.time_offset : 0;
+        act = valid ? env_action<INL>(p, e) : -1;
+        tix = valid ? env_time_of<INL>(p, e) + p.time_offset : 0;
     } else {
-        const int a0 = (p.launch_mask & SSA_LAUNCH_INLINE_ACTION) ? p.action0 : p.actions[0], t0 = p.env_time[0];
+        const int a0 = env_action<INL>(p, 0), t0 = env_time_of<INL>(p, 0);
         act = valid ? a0 : -1;
         tix = valid ? t0 + p.time_offset : 0;
     }
@@ -1647,7 +1697,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     if (my_update && rec && l == 0) {
         rec[SSA_UPD_OBS_TAKEN] = taken ? 1.0 : 0.0;
         rec[SSA_UPD_VISIBLE] = visible ? 1.0 : 0.0;
-        rec[SSA_UPD_ACTION] = attempted ? (double)(ACT::late ? act : env_action(p, e)) : -1.0;   // (my_update: the env's action IS this object)
+        rec[SSA_UPD_ACTION] = attempted ? (double)(ACT::late ? act : env_action<INL>(p, e)) : -1.0;   // (my_update: the env's action IS this object)
     }
     // The update is the register-pressure peak behind the propagator and only ONE wavefront of a launch runs it: whatever is
     // live across it would be spilled by EVERY wavefront.  So the values that are cheap to get again are got again behind
@@ -1661,7 +1711,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     }   // wavefronts holding a selected object
     // envs whose action selects nobody still get a cleared record (written by object 0's row)
     if (valid && p.upd && obj == (int64_t)e * p.n_obj && l == 0) {   // (object 0 of an env: one lane per env)
-      const int a_env = ACT::late ? act : env_action(p, e);
+      const int a_env = ACT::late ? act : env_action<INL>(p, e);
       if (!(a_env >= 0 && interval_ok && (int64_t)a_env < p.n_obj)) {
         double* rec = p.upd + (int64_t)e * SSA_UPD_STRIDE;
         rec[SSA_UPD_OBS_TAKEN] = 0.0;
@@ -1694,7 +1744,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     // observation mode and the multi-GPU all-gather payload -- from the tiles, so that no second pass over x / P (the
     // former post kernel: 6.7 MB re-read per 20 000 objects plus a launch) is needed
     if (p.aer_out && p.stat_shards) {
-        if (l < 4 && valid) aer_obs_tile(t, p, C, g, l, e, obj);
+        if (l < 4 && valid) aer_obs_tile<INL>(t, p, C, g, l, e, obj);
     }
     wave_lds_sync();
     SSA_TR(7);
@@ -1735,31 +1785,22 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                 atomicAdd(sh + 1, (unsigned long long)c4 | ((unsigned long long)c7 << 32));
                 if (nfl) atomicAdd(sh + 2, (unsigned long long)nfl);
 #endif
-                if (p.launch_mask & SSA_LAUNCH_FOLD_INSIDE) {   // (one env: the launcher checks)
+                if (FOLD_OK && (p.launch_mask & SSA_LAUNCH_FOLD_INSIDE)) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this tile's sums are in before it is counted
-                    const int nt = (int)((p.n_obj + OBJ_PER_WAVE - 1) / OBJ_PER_WAVE);
-                    const int shard = tile & (SSA_STAT_SHARDS - 1);
-                    const unsigned expect = (unsigned)((nt - shard + SSA_STAT_SHARDS - 1) / SSA_STAT_SHARDS);   // tiles that add to this shard
-                    const unsigned old = (unsigned)__hip_atomic_fetch_add(sh + 3, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (old == expect - 1u) {
-                        __hip_atomic_store(sh + 3, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        unsigned long long* done = (unsigned long long*)p.stat_shards + 4;
-                        const unsigned used = (unsigned)(nt < SSA_STAT_SHARDS ? nt : SSA_STAT_SHARDS);
-                        const unsigned old2 = (unsigned)__hip_atomic_fetch_add(done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (old2 == used - 1u) {
-                            __hip_atomic_store(done, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            i_fold = true;
-                        }
-                    }
+                    i_fold = stat_tile_counted(p, e_tile, tile);
                 }
             }
-            if ((p.launch_mask & SSA_LAUNCH_FOLD_INSIDE) && __any(i_fold))      // the launch's last tile: every shard is complete
-                fold_stat_shards_inside((unsigned long long*)p.stat_shards, p.stats, lane);
-        } else if (p.stat_shards && lane == 0) {   // a tile that straddles envs: one group of atomics per env
+            if (FOLD_OK && (p.launch_mask & SSA_LAUNCH_FOLD_INSIDE) && __any(i_fold)) {    // the env's last tile: every shard of it is complete
+                const int64_t e_tile = (p.n_env > 1) ? (int64_t)((uint32_t)base / (uint32_t)p.n_obj) : 0;
+                fold_stat_shards_inside((unsigned long long*)p.stat_shards + e_tile * SSA_STAT_SHARDS * SSA_STAT_SHARD_WORDS,
+                                        p.stats + e_tile * SSA_STAT_STRIDE, lane);
+            }
+        } else if (p.stat_shards) {   // a tile that straddles envs: one group of atomics per env (lane 0)
+          unsigned fold_envs = 0u;    // bit i: env e_first + i was completed by this tile (a tile spans at most four envs)
+          const int64_t e_first = (p.n_env > 1) ? (int64_t)((uint32_t)base / (uint32_t)p.n_obj) : 0;
+          if (lane == 0) {
             int64_t e_cur = -1;
             unsigned long long mx = 0ull, cnts = 0ull, nf = 0ull;
-            const int64_t e_first = (p.n_env > 1) ? (int64_t)((uint32_t)base / (uint32_t)p.n_obj) : 0;
             int64_t j_run = base - e_first * p.n_obj, e_run = e_first;   // (env, index) of row gg, advanced without dividing
             for (int gg = 0; gg <= cnt; ++gg) {
                 while (j_run >= p.n_obj) { j_run -= p.n_obj; ++e_run; }
@@ -1771,6 +1812,10 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                         atomicMax(sh, mx);
                         atomicAdd(sh + 1, cnts);
                         if (nf) atomicAdd(sh + 2, nf);
+                        if (FOLD_OK && (p.launch_mask & SSA_LAUNCH_FOLD_INSIDE)) {
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            if (stat_tile_counted(p, e_cur, tile)) fold_envs |= 1u << (unsigned)(e_cur - e_first);
+                        }
                     }
                     e_cur = eg; mx = 0ull; cnts = 0ull; nf = 0ull;
                 }
@@ -1782,6 +1827,14 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                     nf += t.St[gg] != 0;
                 }
             }
+          }
+          if (FOLD_OK && (p.launch_mask & SSA_LAUNCH_FOLD_INSIDE)) {
+              fold_envs = (unsigned)__builtin_amdgcn_readfirstlane((int)fold_envs);   // (lane 0's word)
+              for (int i = 0; i < OBJ_PER_WAVE; ++i)
+                  if (fold_envs & (1u << i))
+                      fold_stat_shards_inside((unsigned long long*)p.stat_shards + (e_first + i) * SSA_STAT_SHARDS * SSA_STAT_SHARD_WORDS,
+                                              p.stats + (e_first + i) * SSA_STAT_STRIDE, lane);
+          }
         }
         SSA_TR(9);
 #endif
@@ -3155,11 +3208,13 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
     if (!p->x_true_in || !p->x_true_out || !p->x_in || !p->x_out || !p->P_in || !p->P_out || !p->status ||
         !p->obs || !p->metrics || !p->trans || !p->env_time || !p->z_noise || !p->stat_ws)
         return SSA_E_INVALID;
-    if (p->launch_mask & SSA_LAUNCH_INLINE_ACTION) {
+    if (p->launch_mask & SSA_LAUNCH_INLINE_ENVS) {
+        if (p->n_env > SSA_INLINE_ENVS || (p->launch_mask & SSA_LAUNCH_INLINE_ACTION)) return SSA_E_INVALID;
+    } else if (p->launch_mask & SSA_LAUNCH_INLINE_ACTION) {
         if (p->n_env != 1) return SSA_E_INVALID;
     } else if (!p->actions) return SSA_E_INVALID;
     if ((p->launch_mask & SSA_LAUNCH_FOLD_INSIDE) &&
-        (p->n_env != 1 || !p->stat_shards || !p->stats || (p->launch_mask & SSA_LAUNCH_DEFER_FOLD))) return SSA_E_INVALID;
+        (!p->stat_shards || !p->stats || (p->launch_mask & SSA_LAUNCH_DEFER_FOLD))) return SSA_E_INVALID;
     if (c->obs_type != SSA_OBS_AER && c->obs_type != SSA_OBS_XYZ) return SSA_E_INVALID;
     if (p->aer_cols != 0 && p->aer_cols != 1 && p->aer_cols != 4) return SSA_E_INVALID;
     StepK k;
@@ -3204,7 +3259,7 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
     }
     if (fast_stats) {   // (the aer_out payload, if any, was the step kernel's epilogue) a one-wave fold finishes the step
                         // (2 launches), unless deferred (1 launch)
-        if (p->launch_mask & SSA_LAUNCH_FOLD_INSIDE) return launch_status();   // (folded by the step kernel's last wavefront)
+        if ((p->launch_mask & SSA_LAUNCH_FOLD_INSIDE) && per_wave == 1) return launch_status();   // (folded by the step kernel's last wavefronts)
         if ((mask & 6u) && !defer && p->stats)   // (stats NULL: the caller consumes the raw shard words, see stat_shards_clear)
             hipLaunchKernelGGL(reward_fold_kernel, dim3(p->n_env), dim3(64), 0, s, (unsigned long long*)p->stat_shards, p->stats);
         return launch_status();

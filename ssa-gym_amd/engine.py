@@ -170,12 +170,13 @@ class HotPathEngine:
 
     def launch_step(self, slot_in, slot_out, time_offset, actions_ptr=None, stream=None, aer_out=0, stats_out=0, upd_out=0,
                     fast_stats=False, defer_fold=False, profile_slot=None, shards_out=0, shards_clear=0, aer_cols=4, action=None,
-                    obs_mirror=0, fold_inside=False):
+                    obs_mirror=0, fold_inside=False, env_words=None):
         """enqueue the step; asynchronous, no host sync.  fast_stats: statistics by the step kernel's atomics (two
         launches, no arg-max of sigma_pos).  defer_fold (with fast_stats): ONE launch -- this step's
         statistics are folded by extra wavefronts of the NEXT deferred step, or by flush_stats().  action (one env): the
         action by value in the parameter block (SSA_LAUNCH_INLINE_ACTION) instead of a word in memory; obs_mirror: a second
-        destination of the observation rows (host-mapped pinned memory: the observation reaches the host from inside the kernel)."""
+        destination of the observation rows (host-mapped pinned memory: the observation reaches the host from inside the kernel).
+        env_words = (time indices, actions) of all envs (n_env <= 8) by value in the parameter block (SSA_LAUNCH_INLINE_ENVS)."""
         s = torch.cuda.current_stream().cuda_stream if stream is None else stream
         if shards_out:
             fast_stats, defer_fold = True, False
@@ -187,9 +188,15 @@ class HotPathEngine:
         p.time_offset = int(time_offset)
         p.actions = self._actions_ptr if actions_ptr is None else actions_ptr
         inline = 0
-        if action is not None:
+        if env_words is not None:
+            if self.E > _lib.INLINE_ENVS:
+                raise _lib.SsaHipError("env_words: at most %d envs travel in the parameter block" % _lib.INLINE_ENVS)
+            p.inline_time[:self.E] = env_words[0]
+            p.inline_action[:self.E] = env_words[1]
+            inline = _lib.LAUNCH_INLINE_ENVS
+        elif action is not None:
             p.action0, inline = int(action), _lib.LAUNCH_INLINE_ACTION
-        if fold_inside and fast_stats and not defer and not shards_out and self.E == 1:
+        if fold_inside and fast_stats and not defer and not shards_out:
             inline |= _lib.LAUNCH_FOLD_INSIDE      # (the step kernel's last wavefront folds the statistics: no fold launch)
         if defer and self._fold_pending is not None:
             p.launch_mask = _lib.LAUNCH_DEFER_FOLD | inline

@@ -53,6 +53,14 @@ class SSA_Tasker_VecEnv:
         # device-to-host copy pass.  Two observation buffers alternate: what step k returned stays intact until step k + 2.
         self._ta_host = torch.zeros(2 * self.E, dtype=torch.int32).pin_memory()      # [time indices | actions]: one copy per step
         self._time_np, self._act_np = self._ta_host.numpy()[:self.E], self._ta_host.numpy()[self.E:]
+        # up to 8 envs: time indices and actions travel BY VALUE in the launch's parameter block (no copy in front of the step, and
+        # with no torch call left in step() the stream handle is looked up once); the statistics of every env are folded by the last
+        # wavefront that adds to them (SSA_LAUNCH_FOLD_INSIDE): ONE launch per vector step
+        self._inline = self.E <= _lib.INLINE_ENVS
+        self._stream = torch.cuda.current_stream()
+        # config['obs_device'] = True (opt-in, for policies that live on the GPU): step() returns the observations as ONE CUDA tensor
+        # [E, ...] -- a view of device memory the step kernel wrote -- and nothing but the statistics crosses PCIe
+        self._obs_device = bool(config.get('obs_device', False))
         self._stats_host = torch.zeros((self.E, _lib.STAT_STRIDE), dtype=torch.float64).pin_memory()
         self._stats_np = self._stats_host.numpy()
         per = self.m * (4 if self.obs_returned == 'aer' else 12)
@@ -101,17 +109,28 @@ class SSA_Tasker_VecEnv:
 
     def _obs(self, slot, reset=False):
         e = self._eng
+        if self._obs_device:
+            if self.obs_returned == 'aer':
+                if reset:
+                    self._aer_reset_rows()
+                return self._aer.view(self.E, self.m * 4)
+            return e.obs[slot].view(self.E, self.m * 12) if self.obs_returned == 'flatten' else e.obs[slot].view(self.E, self.m, 12)
         if self.obs_returned == 'flatten':
             return e.obs[slot].cpu().numpy().reshape(self.E, self.m * 12)
         if self.obs_returned == 'aer':
             if reset:
-                from .. import device
-                for k in range(self.E):   # reset-time only
-                    sl = slice(k * self.m, (k + 1) * self.m)
-                    M = e.trans[int(self.i[k]) % e.n_time].reshape(3, 3)
-                    device.aer_obs(e.x_filter[slot, sl], e.P_filter[slot, sl], M, self._consts, out=self._aer[sl])
+                self._aer_reset_rows()
             return self._aer.cpu().numpy().reshape(self.E, self.m * 4)
         return e.obs[slot].cpu().numpy().reshape(self.E, self.m, 12)
+
+    def _aer_reset_rows(self):
+        """the 'aer' block of the CURRENT state of every env (reset time only: a step's block is the step kernel's epilogue)"""
+        from .. import device
+        e, slot = self._eng, self.tick % 2
+        for k in range(self.E):
+            sl = slice(k * self.m, (k + 1) * self.m)
+            M = e.trans[int(self.i[k]) % e.n_time].reshape(3, 3)
+            device.aer_obs(e.x_filter[slot, sl], e.P_filter[slot, sl], M, self._consts, out=self._aer[sl])
 
     def step(self, actions):
         import torch
@@ -121,29 +140,39 @@ class SSA_Tasker_VecEnv:
         argmax_prev = self._argmax_prev
         self.i += 1
         self.tick += 1
-        self._time_np[:] = self.i
-        self._act_np[:] = actions
-        e.time_actions.copy_(self._ta_host, non_blocking=True)
         sin, sout = (self.tick - 1) % 2, self.tick % 2
         aer = self.obs_returned == 'aer'
         k = self.tick % 2
-        cur = torch.cuda.current_stream()     # (the stream the time / action copy above was enqueued in)
-        e.launch_step(sin, sout, 0, aer_out=self._obs_ring_ptr[k] if aer else 0, obs_mirror=0 if aer else self._obs_ring_ptr[k],
-                      stats_out=self._stats_host.data_ptr(), stream=cur.cuda_stream, fast_stats=(self.reward_type != 'shaped'))
+        fast = self.reward_type != 'shaped'
+        if self._obs_device:
+            aer_out, mirror = (self._aer.data_ptr() if aer else 0), 0
+        else:
+            aer_out, mirror = (self._obs_ring_ptr[k] if aer else 0), (0 if aer else self._obs_ring_ptr[k])
+        if self._inline:
+            cur = self._stream
+            e.launch_step(sin, sout, 0, aer_out=aer_out, obs_mirror=mirror, stats_out=self._stats_host.data_ptr(), stream=cur.cuda_stream,
+                          fast_stats=fast, fold_inside=True, env_words=(self.i.tolist(), actions.tolist()))
+        else:
+            self._time_np[:] = self.i
+            self._act_np[:] = actions
+            e.time_actions.copy_(self._ta_host, non_blocking=True)
+            cur = torch.cuda.current_stream()     # (the stream the time / action copy above was enqueued in)
+            e.launch_step(sin, sout, 0, aer_out=aer_out, obs_mirror=mirror, stats_out=self._stats_host.data_ptr(), stream=cur.cuda_stream,
+                          fast_stats=fast, fold_inside=True)
         cur.synchronize()
-        st = self._stats_np.copy()
-        self._argmax_prev = st[:, _lib.STAT_ARGMAX_SPOS].astype(np.int64)
+        st = self._stats_np            # (host-mapped: the step kernel's folds wrote it; stable until the next launch)
+        if not fast:
+            self._argmax_prev = st[:, _lib.STAT_ARGMAX_SPOS].astype(np.int64)
         mx = st[:, _lib.STAT_MAX_DPOS]
-        rewards = np.zeros(self.E)
-        dones = np.zeros(self.E, dtype=bool)
         last = self.i + 1 >= self.n
-        if self.reward_type == 'jones':
+        if self.reward_type == 'trinary':
+            rewards = (st[:, _lib.STAT_CNT_LT_1E4] + st[:, _lib.STAT_CNT_LT_1E7]) / self.m / 2
+            dones = last
+        elif self.reward_type == 'jones':
             lost, won = mx > 5e6, mx < 3e4
             dones = lost | won | last
+            rewards = np.zeros(self.E)
             rewards[won & ~lost] = 1.0
-        elif self.reward_type == 'trinary':
-            rewards = (st[:, _lib.STAT_CNT_LT_1E4] + st[:, _lib.STAT_CNT_LT_1E7]) / self.m / 2
-            dones = last.copy()
         elif self.reward_type == 'shaped':
             lost, won = mx > 5e6, mx < 3e4
             hit = actions == argmax_prev
@@ -151,12 +180,14 @@ class SSA_Tasker_VecEnv:
             rewards[won] = 1.0 - self.rewards_sum[won]
             rewards[lost] = 0.0
             dones = lost | won | last
+        else:
+            rewards, dones = np.zeros(self.E), np.zeros(self.E, dtype=bool)
         self.rewards_sum += rewards
-        obs = self._obs_ring_np[k]
+        obs = self._obs(sout) if self._obs_device else self._obs_ring_np[k]
         infos = [{} for _ in range(self.E)]
         if dones.any():   # auto-reset in place; the returned observation of a finished env is its new first one
             for d in np.where(dones)[0]:
-                infos[d]['terminal_observation'] = obs[d].copy()
+                infos[d]['terminal_observation'] = obs[d].clone() if self._obs_device else obs[d].copy()
                 self._reset_env(int(d), sout)
             st_dev = self._eng.stats[sout].cpu().numpy()          # (the reset wrote the new envs' statistics on the device)
             self._argmax_prev[dones] = st_dev[dones, _lib.STAT_ARGMAX_SPOS].astype(np.int64)
