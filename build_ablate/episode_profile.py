@@ -5,7 +5,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.argv = ['bench.py']
 import bench
-from ssa_gym_amd import host, engine, parallel
+from ssa_gym_amd import host, engine, parallel, _build, _lib
+if os.environ.get("LIB"):     # a diagnostic build instead of the shipped library
+    _build.LIB = os.path.join(ROOT, os.environ["LIB"])
+    _lib._lib = None
+    _lib.load()
 m = 20000
 pb = bench.build_problem(m, seed=100)
 consts = host.make_consts(pb["Q"], pb["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, pb["obs_lla"], obs_type='aer',

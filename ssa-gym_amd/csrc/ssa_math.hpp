@@ -186,6 +186,15 @@ SSA_DEV void coe2rv(double p, double ecc, double inc, double raan, double argp, 
 // rv2coe (farnocchia.py:165-313), elliptic side of the general branch inline; returns false
 // when the orbit is not a strong-elliptic one (a <= 0 or ecc >= 1 - 1e-2) so that the caller
 // can take the complete restatement below.  coe = p, ecc, inc, raan, argp, nu.
+#ifdef SSA_EL_INVTRIG_FAST   // (diagnostic build: what the libm inverse trigonometry of this chain costs -- NOT for use: Test 7 moves)
+#define SSA_EL_ATAN2(y, x) atan2_fast((y), (x))
+#define SSA_EL_ATAN(v) atan2_fast((v), 1.0)
+#define SSA_EL_ACOS(c) atan2_fast(sqrt_fast(fma(-(c), (c), 1.0)), (c))
+#else
+#define SSA_EL_ATAN2(y, x) atan2((y), (x))
+#define SSA_EL_ATAN(v) atan(v)
+#define SSA_EL_ACOS(c) acos(c)
+#endif
 SSA_DEV bool rv2coe_elliptic(const double* r, const double* v, double* coe)
 {
     const double tol = 1e-8;
@@ -199,38 +208,38 @@ SSA_DEV bool rv2coe_elliptic(const double* r, const double* v, double* coe)
     double p = dot3(h, h) * inv_mu;
     double hn = sqrt(dot3(h, h));   // correctly rounded, as is h_z / |h| below: the equatorial test |inc| < 1e-8 holds only
     const double inv_hn = rcp_nr(hn);   // when that quotient is EXACTLY 1 (acos(1 - 1 ulp) = 1.5e-8), farnocchia.py:278
-    double inc = acos(h[2] / hn);   // (IEEE division: for an equatorial orbit h_z / |h| must be exactly 1, not 1 + 1 ulp -> acos NaN)
+    double inc = SSA_EL_ACOS(h[2] / hn);   // (IEEE division: for an equatorial orbit h_z / |h| must be exactly 1, not 1 + 1 ulp -> acos NaN)
     bool circular = ecc < tol, equatorial = fabs(inc) < tol;
     double raan, argp, nu;
     if (equatorial && !circular) {
         raan = 0.0;
-        argp = mod_2pi(atan2(e[1], e[0]));
+        argp = mod_2pi(SSA_EL_ATAN2(e[1], e[0]));
         double t[3] = {e[1] * r[2] - e[2] * r[1], e[2] * r[0] - e[0] * r[2], e[0] * r[1] - e[1] * r[0]};
-        nu = atan2(dot3(h, t) * inv_hn, dot3(r, e));
+        nu = SSA_EL_ATAN2(dot3(h, t) * inv_hn, dot3(r, e));
     } else if (!equatorial && circular) {
-        raan = mod_2pi(atan2(n[1], n[0]));
+        raan = mod_2pi(SSA_EL_ATAN2(n[1], n[0]));
         argp = 0.0;
         double t[3] = {h[1] * n[2] - h[2] * n[1], h[2] * n[0] - h[0] * n[2], h[0] * n[1] - h[1] * n[0]};
-        nu = atan2(dot3(r, t) * inv_hn, dot3(r, n));
+        nu = SSA_EL_ATAN2(dot3(r, t) * inv_hn, dot3(r, n));
     } else if (equatorial && circular) {
         raan = 0.0;
         argp = 0.0;
-        nu = mod_2pi(atan2(r[1], r[0]));
+        nu = mod_2pi(SSA_EL_ATAN2(r[1], r[0]));
     } else {
         double a = div_fast(p, 1.0 - ecc * ecc);
         if (!(a > 0.0)) return false;
         double e_se = rv * rsqrt_nr(MU * a);
         double e_ce = rn * vv * inv_mu - 1.0;
-        double E = atan2(e_se, e_ce);
+        double E = SSA_EL_ATAN2(e_se, e_ce);
         {
             double sh, ch;
             sincos_fast(0.5 * E, sh, ch);
-            nu = 2.0 * atan(sqrt_fast(div_fast(1.0 + ecc, 1.0 - ecc)) * div_fast(sh, ch));   // tan(E/2) = sin / cos
+            nu = 2.0 * SSA_EL_ATAN(sqrt_fast(div_fast(1.0 + ecc, 1.0 - ecc)) * div_fast(sh, ch));   // tan(E/2) = sin / cos
         }
-        raan = mod_2pi(atan2(n[1], n[0]));
+        raan = mod_2pi(SSA_EL_ATAN2(n[1], n[0]));
         double t[3] = {h[1] * n[2] - h[2] * n[1], h[2] * n[0] - h[0] * n[2], h[0] * n[1] - h[1] * n[0]};
         double px = dot3(r, n), py = dot3(r, t) * inv_hn;
-        argp = mod_2pi(atan2(py, px) - nu);
+        argp = mod_2pi(SSA_EL_ATAN2(py, px) - nu);
     }
     nu = wrap_pi(nu);
     coe[0] = p; coe[1] = ecc; coe[2] = inc; coe[3] = raan; coe[4] = argp; coe[5] = nu;
@@ -276,20 +285,36 @@ SSA_DEV void kepler_elements(const double* x, double tof, double* out, double* d
         return;
     }
     double p = coe[0], ecc = coe[1], nu0 = coe[5];
+#if defined(SSA_EL_CUT) && SSA_EL_CUT == 1   // (diagnostic builds: the chain cut behind a stage, for per-stage instruction counts)
+    for (int i = 0; i < 6; ++i) out[i] = coe[i];
+    return;
+#endif
     double q = div_fast(p, 1.0 + ecc);
     double ome = 1.0 - ecc;
     double sh, ch;
     sincos_fast(0.5 * nu0, sh, ch);
-    double E0 = 2.0 * atan(sqrt_fast(div_fast(ome, 1.0 + ecc)) * div_fast(sh, ch));
+    double E0 = 2.0 * SSA_EL_ATAN(sqrt_fast(div_fast(ome, 1.0 + ecc)) * div_fast(sh, ch));
     double sE0, cE0;
     sincos_fast(E0, sE0, cE0);
     double M0 = E0 - ecc * sE0;
     double nmm = sqrt_fast(div_fast(MU * ome * ome * ome, q * q * q));
     double dt0 = div_fast(M0, nmm);
     double M = nmm * (dt0 + tof);
+#if defined(SSA_EL_CUT) && SSA_EL_CUT == 2
+    for (int i = 0; i < 6; ++i) out[i] = coe[i] + M;
+    return;
+#endif
     double E = solve_kepler_E(wrap_pi(M), ecc);
+#if defined(SSA_EL_CUT) && SSA_EL_CUT == 3
+    for (int i = 0; i < 6; ++i) out[i] = coe[i] + E;
+    return;
+#endif
     sincos_fast(0.5 * E, sh, ch);
-    double nu = 2.0 * atan(sqrt_fast(div_fast(1.0 + ecc, ome)) * div_fast(sh, ch));
+    double nu = 2.0 * SSA_EL_ATAN(sqrt_fast(div_fast(1.0 + ecc, ome)) * div_fast(sh, ch));
+#if defined(SSA_EL_CUT) && SSA_EL_CUT == 4
+    for (int i = 0; i < 6; ++i) out[i] = coe[i] + nu;
+    return;
+#endif
     coe2rv(p, ecc, coe[2], coe[3], coe[4], nu, out);
     if (diag) {
         for (int i = 0; i < 6; ++i) diag[i] = coe[i];
