@@ -505,7 +505,7 @@ def main():
     # One launch per step on a single GPU: the statistics of step k are folded by extra wavefronts riding in step
     # k+1's launch (the last one by flush() before the closing fence), so every step's statistics exist when the
     # timed region ends.  The sharded multi-GPU step needs them in its all-gather payload and folds at once.
-    local = parallel.HipLocalStepper(eng, consts, fast_stats=True, defer_fold=True)
+    local = parallel.HipLocalStepper(eng, consts, fast_stats=True, defer_fold=True, fold_inside=os.environ.get("SSA_BENCH_FOLD") == "inside")
     # round-robin actions over the GLOBAL catalogue (BASELINE.md protocol): a_i = i mod m_total
     total_steps = W + K
     glob_actions = np.arange(total_steps) % plan.m_total

@@ -390,12 +390,15 @@ def fold_raw_statistics(rows_words):
 class HipLocalStepper:
     """LocalStepper over the HIP engine (the only one the product uses)."""
 
-    def __init__(self, engine, consts, fast_stats=False, defer_fold=False):
+    def __init__(self, engine, consts, fast_stats=False, defer_fold=False, fold_inside=False):
         self.engine, self.consts = engine, consts
+        # fold_inside (with fast_stats, instead of defer_fold): every step's statistics are folded by that step's own last
+        # wavefronts (SSA_LAUNCH_FOLD_INSIDE) -- one launch per step and nothing left to flush
+        self.fold_inside = bool(fold_inside) and bool(fast_stats)
         self.fast_stats = fast_stats   # statistics by the common-path kernel's atomics: two launches, no arg-max of sigma_pos
         # one launch per step: the statistics of step k are folded by extra wavefronts of step k+1 (flush() folds the
         # last one).  For consumers that read the statistics in bulk; a closed loop reads them every step (no deferral).
-        self.defer_fold = defer_fold
+        self.defer_fold = defer_fold and not self.fold_inside
         self.device = engine.dev
         self.raw_shards = bool(fast_stats)   # the step kernel can accumulate into caller-provided shard words (no fold launch)
         self.tick = 0
@@ -425,13 +428,14 @@ class HipLocalStepper:
             k = (self.tick - 1 - self._sched_k0) % self._sched.numel()
             e.launch_step((self.tick - 1) % e.H, self.tick % e.H, self.tick, actions_ptr=self._sched.data_ptr() + 4 * k,
                           aer_out=aer, stats_out=st, fast_stats=self.fast_stats, defer_fold=self.defer_fold and stats_out is None,
-                          profile_slot=profile_slot, shards_out=so, shards_clear=sc, aer_cols=obs_cols, stream=stream)
+                          profile_slot=profile_slot, shards_out=so, shards_clear=sc, aer_cols=obs_cols, stream=stream,
+                          fold_inside=self.fold_inside)
             return
         self._act[0] = int(local_action)
         e.actions.copy_(self._act)
         e.launch_step((self.tick - 1) % e.H, self.tick % e.H, self.tick, aer_out=aer, stats_out=st, fast_stats=self.fast_stats,
                       defer_fold=self.defer_fold and stats_out is None, profile_slot=profile_slot, shards_out=so, shards_clear=sc,
-                      aer_cols=obs_cols, stream=stream)
+                      aer_cols=obs_cols, stream=stream, fold_inside=self.fold_inside)
 
     def rollout(self, n_steps):
         """advance n_steps of the pre-staged schedule in ONE launch (open-loop actions; HotPathEngine.launch_rollout)."""
