@@ -26,6 +26,8 @@ for s in range(2):
     dec = np.median(t[:, 2])                      # decision of this step seen (most waves: at once)
     print("---- step %d: all times relative to the median 'decision seen' of this step" % s)
     for k, nme in enumerate(names):
+        if not np.any(tr[:, 8 * s + k]):      # (a marker this build never stamps: service wavefronts fold, compute wavefronts do not)
+            continue
         v = t[:, k] - dec
         print("  %-24s p1 %7.2f  p50 %7.2f  p90 %7.2f  p99 %7.2f  max %7.2f" % (nme, *np.percentile(v, [1, 50, 90, 99, 100])))
     waited = (t[:, 2] - t[:, 1])
@@ -33,7 +35,7 @@ for s in range(2):
     last = np.argsort(t[:, 4])[-6:]
     print("  last arrivers (wave, arrival, flags[1 = ran the update], wait begin, decision seen, body done):")
     for w in last:
-        print("     w%5d  %7.2f  fl %d   %7.2f %7.2f %7.2f   folds done %7.2f" % (w, t[w, 4] - dec, fl[w], t[w, 1] - dec, t[w, 2] - dec, t[w, 3] - dec, t[w, 5] - dec))
+        print("     w%5d  %7.2f  fl %d   %7.2f %7.2f %7.2f" % (w, t[w, 4] - dec, fl[w], t[w, 1] - dec, t[w, 2] - dec, t[w, 3] - dec))
     fin = np.where(fl & 2)[0]
     for w in fin:
         print("  FINAL folder w%d: arrived %.2f, folds done (decision published) %.2f" % (w, t[w, 4] - dec, t[w, 5] - dec))

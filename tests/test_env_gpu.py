@@ -230,22 +230,23 @@ def test_vector_env_matches_single_envs(envs):
     assert not done2.any() and np.all(vec.i == 1)
 
 
-@pytest.mark.parametrize("mode", ['aer', 'flatten'])
-def test_vector_env_paths_agree(envs, mode):
+@pytest.mark.parametrize("mode,m", [('aer', 7), ('flatten', 7), ('aer', 8), ('flatten', 130)])
+def test_vector_env_paths_agree(envs, mode, m):
     """The vector step in its three host forms -- (a) up to 8 envs: time indices and actions by value in the parameter block, every
     env's statistics folded by the last wavefront that adds to them (one launch); (b) more envs: one pinned copy in front of the
     launch; (c) obs_device: CUDA tensors returned -- must return identical observations, rewards and dones for the same seeds
-    and actions.  m = 7 objects per env: most tiles straddle two envs (the statistics' per-env tile counting), 9 envs."""
+    and actions.  m = 7 objects per env: most tiles straddle two envs (the statistics' per-env tile counting); m = 8: none does;
+    m = 130: 33 tiles per env, every other env boundary inside a tile."""
     import torch
     from ssa_gym_amd.envs.vector_env import SSA_Tasker_VecEnv
     cfg = dict(envs.env_config)
-    cfg.update(rso_count=7, steps=9, reward_type='trinary', obs_returned=mode)
+    cfg.update(rso_count=m, steps=9, reward_type='trinary', obs_returned=mode)
     a = SSA_Tasker_VecEnv(cfg, 8, seed=20)                       # (a)
     b = SSA_Tasker_VecEnv(cfg, 9, seed=20)                       # (b): env 0..7 have the same seeds as a's
     c = SSA_Tasker_VecEnv(dict(cfg, obs_device=True), 8, seed=20)
     assert a._inline and not b._inline and c._inline
     for k in range(1, 14):     # runs through an auto-reset (step 8) of every env
-        acts = [(3 * k + e) % 7 for e in range(9)]
+        acts = [(3 * k + e) % m for e in range(9)]
         oa, ra, da, ia = a.step(acts[:8])
         ob, rb, db, ib = b.step(acts)
         oc, rc, dc, ic = c.step(acts[:8])
@@ -257,7 +258,7 @@ def test_vector_env_paths_agree(envs, mode):
         slot = a.tick % 2
         dp = a._eng.metrics[slot, :, 0].cpu().numpy()
         if not da.any():
-            assert np.allclose(ra, ((dp < 1e4).sum(axis=1) + (dp < 1e7).sum(axis=1)) / 7 / 2)
+            assert np.allclose(ra, ((dp < 1e4).sum(axis=1) + (dp < 1e7).sum(axis=1)) / m / 2)
         for e in range(8):
             if da[e]:
                 assert 'terminal_observation' in ia[e] and np.array_equal(ia[e]['terminal_observation'], ic[e]['terminal_observation'].cpu().numpy())
