@@ -1,0 +1,54 @@
+"""what would health-sorted tiles buy the HYBRID / ELEMENTS step kernel late in an episode?  Emulation: every 30 steps the objects are
+physically re-ordered on the host (untimed) so that the objects whose filter mean has left the strong-elliptic regime share wavefronts,
+dealt round-robin over the XCDs' runs of tiles; an object's arithmetic does not depend on its position, so the kernel time is what a
+permuted-tile kernel would see (minus its gather cost)."""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+sys.argv = ['bench.py']
+import bench
+from ssa_gym_amd import host, engine, parallel
+m = 20000
+mu = 398600441800000.0
+SORT = os.environ.get("SORT", "1") == "1"
+pb = bench.build_problem(m, seed=100)
+consts = host.make_consts(pb["Q"], pb["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, pb["obs_lla"], obs_type='aer', propagator=os.environ.get("PROP", "hybrid"))
+gen = torch.Generator(device="cuda").manual_seed(1)
+z = torch.randn((1, 480, m, 3), dtype=torch.float64, device='cuda', generator=gen) * torch.as_tensor(pb["z_sigma"], device="cuda")
+eng = engine.HotPathEngine(consts, m, 1, pb["trans"], z, history=2)
+eng.load_state(0, pb["x_true"], pb["x"], np.broadcast_to(pb["P0"], (m, 6, 6)))
+local = parallel.HipLocalStepper(eng, consts, fast_stats=True, defer_fold=True)
+local.load_schedule(np.arange(479) % m)
+
+
+def resort():
+    local.flush(); torch.cuda.synchronize()
+    s = local.tick % 2
+    xt, x, P, st = eng.x_true[s].cpu().numpy(), eng.x_filter[s].cpu().numpy(), eng.P_filter[s].cpu().numpy(), eng.status.cpu().numpy()
+    r = np.linalg.norm(x[:, :3], axis=1); v2 = np.sum(x[:, 3:] ** 2, axis=1)
+    alpha = 2.0 / r - v2 / mu
+    h = np.cross(x[:, :3], x[:, 3:]); ecc = np.sqrt(np.maximum(0, 1 - np.sum(h * h, 1) * alpha / mu))
+    slow = (alpha <= 0) | (ecc >= 0.985) | ~np.isfinite(ecc) | (st != 0)
+    L = np.concatenate([np.where(slow)[0], np.where(~slow)[0]])      # slow objects first
+    nt = m // 4; q, rr = nt // 8, nt % 8
+    assert rr == 0
+    order = np.empty(m, dtype=np.int64)
+    for c in range(nt):                                              # list chunk c -> tile (c % 8) * q + c // 8 (XCD c % 8, its c // 8-th tile)
+        t = (c % 8) * q + c // 8
+        order[4 * t:4 * t + 4] = L[4 * c:4 * c + 4]
+    eng.x_true[s].copy_(torch.as_tensor(xt[order])); eng.x_filter[s].copy_(torch.as_tensor(x[order])); eng.P_filter[s].copy_(torch.as_tensor(P[order]))
+    eng.status.copy_(torch.as_tensor(st[order]))
+    torch.cuda.synchronize()
+    return float(slow.mean())
+
+
+rows = []
+for k in range(479):
+    if SORT and k >= 180 and k % 30 == 0:
+        rows.append((k, resort()))
+    local.step(-1, profile_slot=k)
+local.flush(); torch.cuda.synchronize()
+ms = np.array([eng.profile_ms(k) for k in range(479)]) * 1e3
+for lo in range(0, 479, 60):
+    print("steps %3d-%3d: kernel %.2f us (min %.2f max %.2f)" % (lo + 1, min(lo + 60, 479), ms[lo:lo + 60].mean(), ms[lo:lo + 60].min(), ms[lo:lo + 60].max()))
+print("episode mean %.2f us   failed %d   (sorted: %s; slow fraction at the re-sorts: %s)" % (ms.mean(), int((eng.status != 0).sum().item()), SORT, " ".join("%d:%.3f" % r for r in rows)))
