@@ -1,6 +1,6 @@
 """Per-wave phase timeline of step_fast_kernel (diagnostic build -DSSA_TRACE -> build_ablate/libs/trace.so).
 
-    cp build_ablate/libs/trace.so ssa-gym_amd/libssa_hip.so && python build_ablate/wave_timeline.py
+    python build_ablate/wave_timeline.py          (loads build_ablate/libs/trace.so)
 
 Each wavefront stamps the 100 MHz wall clock (s_memrealtime) at the phase boundaries of process_wave; the
 script prints when waves start/end relative to the first one, the mean time per phase, and how the 5000
@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.argv = ['bench.py']
 import bench
-from ssa_gym_amd import host, engine, parallel, _lib
+from ssa_gym_amd import host, engine, parallel, _lib, _build
+_build.LIB = os.path.join(ROOT, os.environ.get("LIB", "build_ablate/libs/trace.so"))     # the -DSSA_TRACE build
 
 m = int(os.environ.get("M", 20000))
 pb = bench.build_problem(m, seed=100)

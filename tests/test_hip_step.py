@@ -314,6 +314,50 @@ def test_second_step_from_tight_covariances(hip, oracle, oracle_ld):
     assert np.mean(gpu["status"] == f64["status"]) > 0.99
 
 
+def test_fused_ladder_picks_the_reference_rung_for_every_rung(hip, oracle_ld):
+    """The fused kernel finds an object's robust_cholesky rung in two factorisations (last rungs of the four groups, then the group):
+    the answer must be the sequential ladder's (dynamics.py:402-417) for EVERY rung -1, 0..15 and beyond (LinAlgError).  Indefinite
+    priors built so that (n + lambda) P needs a given rung (smallest eigenvalue -0.3 x that rung's jitter), mixed in wavefronts of four
+    with healthy objects and with each other; checked through the sequential ladder of the single-operator entry point, the failure
+    status, and the propagated covariance against the oracle run with that rung (a neighbouring rung changes P by 10 x the jitter)."""
+    alpha = 1e-4
+    _, _, scale = orc.merwe_weights(alpha, 2.0, -3)
+    rs = np.random.RandomState(12)
+    want = np.array([-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16] * 4)
+    rs.shuffle(want)
+    m = len(want)
+    xt, x, P, g = make_batch(m, seed=12)
+    for j, r in enumerate(want):
+        if r < 0:
+            continue
+        jit = 10.0 ** (min(r, 16) - 6)
+        lam_min = -0.3 * jit / scale if r < 16 else -30.0 * 1e9 / scale      # beyond the last rung (1e9 I): LinAlgError
+        Qm, _ = np.linalg.qr(rs.normal(size=(6, 6)))
+        lam = abs(lam_min) * np.array([-1.0, 3.0, 10.0, 100.0, 300.0, 1e3])    # (every rung's jitter is 3e-2 of the largest variance)
+        P[j] = (Qm * lam) @ Qm.T
+        P[j] = 0.5 * (P[j] + P[j].T)
+    rung_seq = hip.dev.robust_cholesky(hip.dev.as_dev(scale * P))[1].cpu().numpy()      # the sequential ladder on the device
+    rung_orc = np.array([oracle_ld.robust_cholesky(scale * Pj)[1] if r < 16 else 16 for Pj, r in zip(P, want)])
+    assert np.array_equal(rung_seq, want) and np.array_equal(rung_orc, want), (rung_seq, want)
+    gpu = run_gpu(hip, xt, x, P, g, [-1], 2, alpha)
+    ld = run_oracle(oracle_ld, xt, x, P, g, -1, 2, alpha, centred=True, z_noise3=np.zeros(3))
+    assert np.array_equal(gpu["status"] != 0, want == 16) and np.array_equal(ld["status"] != 0, want == 16)
+    ok = want < 16
+    sub = lambda d: {k: d[k][ok] for k in ("x", "P")}   # noqa: E731
+    gp, gv, gP = errs(sub(gpu), sub(ld))
+    assert gp.max() < 1e-6 and gv.max() < 1e-6 and gP.max() < 1e-4, (gp.max(), gv.max(), gP.max())   # (tight covariances: fp64 floor 1e-5)
+    # sensitivity of this check: with 9 x the rung's jitter added to (n + lambda) P -- the plain factorisation then sees nearly the NEXT
+    # rung's matrix -- the oracle's covariance moves by far more than the tolerance above, for every rung
+    P10 = P.copy()
+    for j, r in enumerate(want):
+        if 0 <= r < 15:
+            P10[j] = P[j] + (9.0 * 10.0 ** (r - 6) / scale) * np.eye(6)
+    ld10 = run_oracle(oracle_ld, xt, x, P10, g, -1, 2, alpha, centred=True, z_noise3=np.zeros(3))
+    sel = (want >= 0) & (want < 15)
+    _, _, dP = errs({k: ld10[k][sel] for k in ("x", "P")}, {k: ld[k][sel] for k in ("x", "P")})
+    assert dP.min() > 2e-3, dP.min()       # (20 x the tolerance: a rung off by one cannot hide)
+
+
 def test_visibility_gate_and_no_update_paths(hip, oracle):
     m, alpha = 64, 1e-4
     xt, x, P, g = make_batch(m, seed=6)
