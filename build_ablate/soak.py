@@ -8,7 +8,7 @@ import bench
 from ssa_gym_amd import host, engine, _lib
 m, EP = 20000, int(os.environ.get("EPISODES", "20"))
 pb = bench.build_problem(m, seed=100)
-consts = host.make_consts(pb["Q"], pb["R"], 1e-4, 2.0, -3, 20.0, np.radians(10.0), pb["obs_lla"], obs_type='aer', propagator='fg')
+consts = host.make_consts(pb["Q"], pb["R"], 1e-4, 2.0, -3, 20.0, np.radians(10.0), pb["obs_lla"], obs_type='aer', propagator=os.environ.get('PROP', 'fg'))
 def run_persistent():
     """the closed loop through ssa_env_closed_loop_f64: one launch per 479-step episode; must hash like the per-step closed loop"""
     gen = torch.Generator(device="cuda").manual_seed(7)
