@@ -304,12 +304,12 @@ def closed_loop_rate(m, K, W, seed=100, persistent=True, chunk=120, agent=None):
                     "closed loop on the device: step launch + ssa_agent_select_f64 (2 launches) per step, no host round trip"}
 
 
-def gym_api_rate(m, mode, n=200):
+def gym_api_rate(m, mode, n=200, obs_device=False):
     """env.step() through the gym API (host in the loop: action in, launch, one sync, statistics + observation out over
     PCIe): the closed-loop rate an unmodified agents.py / RLlib worker sees.  Never `value`."""
     from ssa_gym_amd.envs import env_config, make
     cfg = dict(env_config)
-    cfg.update(rso_count=m, steps=480, reward_type='trinary', obs_returned=mode, seed=0, history=2, device_rng=True)
+    cfg.update(rso_count=m, steps=480, reward_type='trinary', obs_returned=mode, seed=0, history=2, device_rng=True, obs_device=obs_device)
     env = make(config=cfg)
     for k in range(20):
         env.step(k % m)
@@ -326,7 +326,50 @@ def gym_api_rate(m, mode, n=200):
     el, lo, hi, reps = timed_repeats(block, lambda: None, prepare=prepare)
     dt = el / n
     return {"value": round(1.0 / dt * (m / 20000.0), 2), "ms_per_step": round(1e3 * dt, 5), **spread(n, m / 20000.0, el, lo, hi, reps),
-            "obs_bytes_per_step": m * (12 if mode == 'flatten' else 4) * 8}
+            "obs_bytes_per_step": 0 if obs_device else m * (12 if mode == 'flatten' else 4) * 8}
+
+
+def torch_policy_rate(m, n=200):
+    """env.run_policy(): the closed loop with a policy written in torch (here the visible-greedy rule as tensor expressions on the
+    device scores; any torch module fits) -- step launch + the policy's own kernels per step, no host round trip, one
+    synchronisation per n steps.  Never `value`."""
+    import torch
+    from ssa_gym_amd.envs import env_config, make
+    cfg = dict(env_config)
+    cfg.update(rso_count=m, steps=480, reward_type='trinary', obs_returned='flatten', seed=0, history=2, device_rng=True, obs_limit=10.0)
+    env = make(config=cfg)
+
+    def policy(view):
+        sc, mask = view.scores()
+        masked = torch.where(mask.bool(), sc[0], torch.full_like(sc[0], -float("inf")))
+        return torch.argmax(masked).to(torch.int32).reshape(1)
+    fixed = torch.zeros(1, dtype=torch.int32, device="cuda")
+    picked = []
+
+    def prepare():
+        if env.i + n >= env.n - 1:
+            env.reset()
+
+    def measure(pol):
+        for _ in range(3):          # (untimed: torch's first launches of each expression, the caching allocator)
+            prepare()
+            env.run_policy(pol, n)
+
+        def block():
+            a, _, _ = env.run_policy(pol, n)
+            picked.extend(a.tolist())
+        return timed_repeats(block, lambda: None, prepare=prepare)
+    el0, _, _, _ = measure(lambda view: fixed)     # the env's side alone: a policy that returns a preallocated tensor
+    picked.clear()
+    el, lo, hi, reps = measure(policy)
+    dt = el / n
+    return {"value": round(1.0 / dt * (m / 20000.0), 2), "ms_per_step": round(1e3 * dt, 5), **spread(n, m / 20000.0, el, lo, hi, reps),
+            "distinct_objects_selected": len(set(picked)),
+            "env_side_only": {"value": round(n / el0 * (m / 20000.0), 2), "ms_per_step": round(1e3 * el0 / n, 5),
+                              "note": "the same call with a policy that returns a preallocated tensor: what run_policy itself costs "
+                                      "(step launch + bookkeeping); the rest of `ms_per_step` is the policy's own eager torch kernels"},
+            "note": "SSA_Tasker_Env.run_policy(): %d steps per call, the policy = torch tensor expressions on the device (scores kernel + where + "
+                    "argmax), its action read by the next step's launch from device memory; bookkeeping of the %d steps on the host afterwards" % (n, n)}
 
 
 def vec_env_rate(m, E=8, n=60, obs_device=False):
@@ -750,7 +793,11 @@ def main():
             legs["closed_loop"] = dict(legs["closed_loop_per_step_launches"], note="more than 20 160 objects: ssa_env_closed_loop_f64 declines "
                                        "(SSA_E_UNSUPPORTED), the closed loop runs as step + ssa_agent_select_f64 launches")
         legs["gym_api"] = {"flatten": gym_api_rate(m, 'flatten'), "aer": gym_api_rate(m, 'aer'),
-                           "note": "SSA_Tasker_Env.step() per call, host in the loop, PCIe + one sync inclusive (20 000 objects)"}
+                           "flatten_device_obs": gym_api_rate(m, 'flatten', obs_device=True),
+                           "note": "SSA_Tasker_Env.step() per call, host in the loop, PCIe + one sync inclusive (20 000 objects); "
+                                   "flatten_device_obs: config['obs_device'] -- the observation stays on the GPU as a CUDA tensor (a policy that "
+                                   "lives there), reward / done still cross PCIe"}
+        legs["closed_loop_torch_policy"] = torch_policy_rate(m)
         if m == 20000:
             legs["vec_env"] = vec_env_rate(m)
             legs["vec_env_device_obs"] = vec_env_rate(m, obs_device=True)

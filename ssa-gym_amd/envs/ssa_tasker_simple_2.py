@@ -537,6 +537,88 @@ class SSA_Tasker_Env(Env):
             obs = e.obs[slot].cpu().numpy()
         return obs, np.asarray(actions, dtype=int), np.asarray(rewards), np.asarray(dones, dtype=bool)
 
+    # ------------------------------------------------------------------ closed loop with ANY policy that lives on the GPU
+    class PolicyView:
+        """what a device-side policy sees at decision time: CUDA tensors of the env's CURRENT state (views of the history slot --
+        valid until the next step is launched; nothing is copied, nothing crosses PCIe)."""
+
+        def __init__(self, env, i):
+            e = env._engine
+            self.env, self.i = env, i
+            cur, prev = i % e.H, (i - 1) % e.H
+            self.obs = e.obs[cur]                                            # [m, 12]: x_filter | diag P   (results.py:61)
+            self.x_filter, self.P_filter, self.x_true = e.x_filter[cur], e.P_filter[cur], e.x_true[cur]
+            self.P_filter_prev = e.P_filter[prev] if i >= 1 else None
+
+        def visible(self):
+            """uint8 CUDA mask [m]: object_visibility() of the true states (ssa_tasker_simple_2.py:427-434)"""
+            from .. import device
+            e = self.env._engine
+            return device.visible_mask(self.x_true, e.trans[self.i % e.n_time].reshape(3, 3), self.env._consts)
+
+        def scores(self):
+            """(scores[4, m], mask[m]) of the reference's heuristic agents (trace P, visible, log-det ratio, delta_pos)"""
+            return self.env.agent_scores()
+
+    def run_policy(self, policy, n_steps):
+        """Closed loop with an ARBITRARY policy evaluated on the GPU (a torch module, a hand-written rule):
+            a = policy(view)          # view: SSA_Tasker_Env.PolicyView -- CUDA tensors; returns an int32 CUDA tensor [1]
+            step(a)
+        repeated n_steps times with NO host round trip: the action never leaves the device (the step kernel reads it from the
+        tensor the policy returned), the statistics and update records go to device rings, ONE synchronisation at the end, then the
+        env's bookkeeping (actions, rewards, dones, failures, z_true / y / S records) is filled in as step() would have.  The
+        reference's loop `a = agent(obs, env); env.step(a)` (run_environment.py:26-29) for agents that are not one of the built-in
+        greedy ones (those: run_agent, one persistent launch).  Rewards 'jones' and 'trinary'; a data-dependent `done` ('jones') is
+        honoured at the bookkeeping -- the steps launched behind it are discarded (chunks of history - 1 steps, as run_agent).
+        Returns (actions[k], rewards[k], dones[k])."""
+        import torch
+        if self.reward_type == 'shaped':
+            raise NotImplementedError("run_policy: reward_type 'shaped' needs argmax(sigma_pos) per step; use step()")
+        e = self._engine
+        K = min(int(n_steps), self.n - 1 - self.i)
+        actions, rewards, dones = [], [], []
+        pos, done = 0, False
+        while pos < K and not done:
+            kk = (K - pos) if self.reward_type == 'trinary' else min(K - pos, e.H - 1)
+            i0 = self.i
+            stats_d = torch.empty((kk, _lib.STAT_STRIDE), dtype=torch.float64, device=e.dev)
+            upd_d = torch.empty((kk, _lib.UPD_STRIDE), dtype=torch.float64, device=e.dev)
+            acts_d = []
+            for k in range(kk):
+                i = i0 + k + 1
+                a = policy(self.PolicyView(self, i - 1))
+                if not (isinstance(a, torch.Tensor) and a.is_cuda and a.dtype == torch.int32 and a.numel() == 1):
+                    raise TypeError("run_policy: the policy must return a CUDA int32 tensor with one element (the action)")
+                acts_d.append(a)          # (kept alive until the launches that read it have run)
+                e.launch_step((i - 1) % e.H, i % e.H, i, actions_ptr=a.data_ptr(), fast_stats=True, defer_fold=True,
+                              stats_out=stats_d[k].data_ptr(), upd_out=upd_d[k].data_ptr())
+                self.i = i                # (the view of the next decision indexes the history by it)
+            e.flush_stats()
+            stats = stats_d.cpu().numpy()                  # synchronises the stream
+            upd = upd_d.cpu().numpy()
+            acts = torch.cat([a.reshape(1) for a in acts_d]).cpu().numpy()
+            self.i = i0
+            for k in range(kk):
+                self.i += 1
+                i, a = self.i, int(acts[k])
+                if not (0 <= a < self.m):
+                    raise ValueError("run_policy: the policy chose action %d at step %d (valid: 0 .. %d)" % (a, i, self.m - 1))
+                self.actions[i] = a
+                self._book_update(i, a, upd[k])
+                self._stats = stats[k]
+                if int(stats[k][_lib.STAT_N_FAILED]) != self._n_failed:
+                    self._record_failures(at_step=i)
+                done = self._reward_done(i, a, stats[k], -1) or (i + 1 >= self.n)
+                r = self.rewards[i]
+                actions.append(a)
+                rewards.append(r if (self.obs_returned == 'flatten' or np.isfinite(r)) else np.float64(0.5))
+                dones.append(done)
+                if done:
+                    break
+            pos += kk
+        self._argmax_sigma = -1
+        return np.asarray(actions, dtype=int), np.asarray(rewards), np.asarray(dones, dtype=bool)
+
     # ------------------------------------------------------------------ failures (:369-382)
     def _record_failures(self, at_step=None):
         """filter_error() bookkeeping (:369-382) for the filters that failed in step self.i.  Inside a rollout launch

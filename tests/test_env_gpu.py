@@ -453,6 +453,58 @@ def test_closed_loop_on_device_equals_host_loop(envs, agent_name, lim, hist, loo
     assert np.array_equal(o1, o2) and r1 == r2
 
 
+@pytest.mark.parametrize("hist,reward", [(2, 'trinary'), ('full', 'trinary'), (3, 'jones')])
+def test_run_policy_equals_host_loop(envs, hist, reward):
+    """env.run_policy(): the reference's loop `a = agent(obs, env); env.step(a)` (run_environment.py:26-29) with an ARBITRARY policy
+    evaluated on the GPU and no host round trip per step.  Two policies written in torch against the PolicyView -- the visible-greedy
+    rule on the device scores, and arg-max trace(P) taken from the observation rows -- against the host loop with the same rule:
+    identical actions, rewards and dones, bit-identical states and update records."""
+    import torch
+    from ssa_gym_amd import agents
+    cfg = dict(envs.env_config)
+    cfg.update(rso_count=41, steps=40, reward_type=reward, obs_returned='flatten', seed=13, obs_limit=5.0, history=hist)
+    K = 24
+
+    def visible_greedy(view):          # agents.py:36 in torch: argmax trace(P) over the visible objects, object 0 if none is
+        sc, mask = view.scores()
+        masked = torch.where(mask.bool(), sc[0], torch.full_like(sc[0], -float("inf")))
+        j = torch.argmax(masked)
+        return torch.where(mask.bool().any(), j, torch.zeros_like(j)).to(torch.int32).reshape(1)
+
+    def trace_from_obs(view):          # agents.py:7 from the observation rows [x | diag P] (results.py:61)
+        return torch.argmax(view.obs[:, 6:].sum(dim=1)).to(torch.int32).reshape(1)
+
+    for policy in (visible_greedy, trace_from_obs):
+        host, dev = envs.make(config=cfg), envs.make(config=cfg)
+        acts, rews, dns = [], [], []
+        for k in range(K):
+            if policy is visible_greedy:
+                vis = host.visible_objects()
+                tr = np.trace(host.P_filter[host.i], axis1=1, axis2=2)
+                a = int(vis[np.argmax(tr[vis])]) if len(vis) else 0
+            else:
+                a = int(policy(dev.PolicyView(host, host.i)).item())       # (the same torch expression on the host env's state)
+            _, r, d, _ = host.step(a)
+            acts.append(a); rews.append(r); dns.append(d)
+            if d:
+                break
+        dacts, drews, ddones = dev.run_policy(policy, K)
+        n = len(acts)
+        assert list(dacts) == acts and list(ddones) == dns, (list(dacts), acts)
+        np.testing.assert_array_equal(drews, np.array(rews))
+        assert dev.i == host.i == n and len(set(acts)) > 1
+        assert np.array_equal(dev.x_filter[n], host.x_filter[n]) and np.array_equal(dev.P_filter[n], host.P_filter[n])
+        assert np.array_equal(dev.x_true[n], host.x_true[n])
+        assert np.array_equal(dev.obs_taken[1:n + 1], host.obs_taken[1:n + 1])
+        assert np.array_equal(np.asarray(dev.z_true[1:n + 1]), np.asarray(host.z_true[1:n + 1]), equal_nan=True)
+        if not dns[-1]:
+            o1, r1, _, _ = dev.step(3)         # the env keeps stepping normally afterwards
+            o2, r2, _, _ = host.step(3)
+            assert np.array_equal(o1, o2) and r1 == r2
+    with pytest.raises(TypeError):
+        envs.make(config=cfg).run_policy(lambda v: 3, 2)
+
+
 def test_anees_and_nis_of_an_episode(envs):
     """anees() (ssa_tasker_simple_2.py:436-446) and the NIS series of fitness_test() (:750-754) from the device against the
     reference's numpy expressions on the env's own history arrays."""
