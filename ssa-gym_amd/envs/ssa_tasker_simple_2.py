@@ -543,12 +543,14 @@ class SSA_Tasker_Env(Env):
         valid until the next step is launched; nothing is copied, nothing crosses PCIe)."""
 
         def __init__(self, env, i):
-            e = env._engine
             self.env, self.i = env, i
-            cur, prev = i % e.H, (i - 1) % e.H
-            self.obs = e.obs[cur]                                            # [m, 12]: x_filter | diag P   (results.py:61)
-            self.x_filter, self.P_filter, self.x_true = e.x_filter[cur], e.P_filter[cur], e.x_true[cur]
-            self.P_filter_prev = e.P_filter[prev] if i >= 1 else None
+
+        # (views are formed on access: a tensor slice costs the host 1-2 us, and most policies read one or two of them)
+        obs = property(lambda s: s.env._engine.obs[s.i % s.env._engine.H])            # [m, 12]: x_filter | diag P   (results.py:61)
+        x_filter = property(lambda s: s.env._engine.x_filter[s.i % s.env._engine.H])
+        P_filter = property(lambda s: s.env._engine.P_filter[s.i % s.env._engine.H])
+        x_true = property(lambda s: s.env._engine.x_true[s.i % s.env._engine.H])
+        P_filter_prev = property(lambda s: s.env._engine.P_filter[(s.i - 1) % s.env._engine.H] if s.i >= 1 else None)
 
         def visible(self):
             """uint8 CUDA mask [m]: object_visibility() of the true states (ssa_tasker_simple_2.py:427-434)"""
