@@ -615,15 +615,23 @@ def test_cowell_acceleration_hook(envs):
 
 @pytest.mark.parametrize("m,agent_name,reward", [(4100, "agent_visible_greedy", 'trinary'), (20000, "agent_visible_greedy", 'trinary'),
                                                  (20000, "agent_shannon", 'trinary'), (20160, "agent_pos_error_greedy", 'trinary'),
-                                                 (2000, "agent_vel_error_greedy", 'jones')])
+                                                 (2000, "agent_vel_error_greedy", 'jones'),
+                                                 (2003, "agent_visible_greedy", 'trinary xyz'), (2003, "agent_shannon", 'trinary hybrid'),
+                                                 (2003, "agent_visible_greedy", 'trinary elements'), (2003, "agent_visible_greedy", 'trinary j2')])
 def test_persistent_closed_loop_equals_per_step_launches_at_size(envs, m, agent_name, reward):
     """ssa_env_closed_loop_f64 at sizes where the decision really crosses wavefront groups (4 100 objects: 1 025 wavefronts = 16
     groups + one wavefront; 20 000: 79 groups over all eight XCDs; 20 160: with the 80 service wavefronts every resident slot taken): same actions, bit-identical
     states and statistics as the step + select launches, through run_agent.  'jones': an episode that ends inside the run."""
     cfg = dict(envs.env_config)
+    reward, _, variant = reward.partition(' ')   # (variant: the xyz measurement model / another propagator instance of the kernel; 2 003: a ragged tile)
     K = 40 if reward == 'trinary' else 190      # ('jones': max delta_pos crosses 5e6 m after ~150 predict-mostly steps)
     cfg.update(rso_count=m, steps=K + 20, reward_type=reward, obs_returned='flatten', seed=3, obs_limit=10.0,
                history=(2 if reward == 'trinary' else 'full'), device_rng=True)
+    if variant == 'xyz':
+        from ssa_gym_amd.envs import dynamics as D
+        cfg.update(obs_type='xyz', z_sigma=(5e2,) * 3, R=np.diag([5e2 ** 2] * 3), hx=D.hx_xyz, mean_z=D.mean_xyz, residual_z=np.subtract)
+    elif variant:
+        cfg.update(propagator=variant)
     fallback = np.random.RandomState(9).randint(0, m, size=K + 1)
     out = {}
     for loop in ('persistent', 'per_step'):
