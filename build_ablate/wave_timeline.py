@@ -53,10 +53,20 @@ for lab, sel in (("waves started < 1 us", early), ("waves started >= 1 us", ~ear
     print("%s: n=%d  lifetime %.2f us" % (lab, sel.sum(), life[sel].mean()))
     for k, nme in enumerate(names):
         print("    %-8s %6.2f us (p90 %6.2f)" % (nme, d[:, k].mean(), np.percentile(d[:, k], 90)))
+# which branch of the out-of-line propagation the wavefront's lanes took (bit 1 hyperbolic, 2 near-parabolic band, 4 elliptic beyond the
+# series) and their longest hyperbolic Newton run -- words 13 / 14 of the -DSSA_TRACE build
+br, it = tr[:, 13] & 7, tr[:, 14]
+kep = (t[:, 3] - t[:, 2]) / 1e3
+if br.any():
+    for code, nme in ((0, "no call"), (1, "hyperbolic only"), (2, "band only"), (3, "hyperbolic + band"), (4, "elliptic beyond the series"), (5, "4+1"), (6, "4+2"), (7, "4+2+1")):
+        sel = br == code
+        if sel.sum():
+            print("  kepler stage by branch  %-28s n=%5d  mean %6.2f us  p90 %6.2f  max %6.2f   Newton iterations p50 %d max %d  lifetime mean %.2f max %.2f" % (
+                nme, sel.sum(), kep[sel].mean(), np.percentile(kep[sel], 90), kep[sel].max(), np.median(it[sel]), it[sel].max(), life[sel].mean(), life[sel].max()))
 slow = np.argsort(life)[-8:]
 print("slowest waves (lifetime, per-stage us):")
 for w_ in slow:
-    print("   %.2f  " % life[w_], (np.diff(t[w_]) / 1e3).round(2))
+    print("   %.2f  " % life[w_], (np.diff(t[w_]) / 1e3).round(2), " branch bits %d  Newton iterations %d" % (br[w_], it[w_]))
 hw = tr[:, 15] & 0xffffffff
 xcc = (tr[:, 15] >> 32) & 0xf
 simd = (hw >> 4) & 3

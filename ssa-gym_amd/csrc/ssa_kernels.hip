@@ -266,6 +266,14 @@ __device__ __noinline__ Vec6 kepler_general_tagged(Vec6 x, double tof)
 // cosh in the hyperbolic Newton loop) instead of libm -- the complete restatement costs ~3 000 vector instructions per
 // call, four times the whole SSA_PROP_FG step, and late in an episode most wavefronts hold a diverged sigma point.
 // Episode-level failure statistics: as SSA_PROP_ELEMENTS / the oracle (tests/test_episode_failures.py).
+#ifdef SSA_TRACE   // (diagnostic build: which branch of the out-of-line propagation a workgroup's lanes took, and their longest Newton run)
+__device__ unsigned g_kep_dbg[16384 * 2];
+#define SSA_KEP_DBG_BRANCH(b) atomicOr(&g_kep_dbg[(blockIdx.x & 16383) * 2], (unsigned)(b))
+#define SSA_KEP_DBG_ITERS(n) atomicMax(&g_kep_dbg[(blockIdx.x & 16383) * 2 + 1], (unsigned)(n))
+#else
+#define SSA_KEP_DBG_BRANCH(b) do { } while (0)
+#define SSA_KEP_DBG_ITERS(n) do { } while (0)
+#endif
 namespace genf {
 // log x for finite x > 0 (the arguments of this path: ratios and sums of positive magnitudes; anything else takes libm):
 // x = m 2^k with m in [sqrt(1/2), sqrt 2), log m = 2 atanh(s), s = (m - 1)/(m + 1), by the fdlibm kernel polynomial; < 1 ulp,
@@ -314,7 +322,8 @@ __device__ static double newton_hyp(double x0, double M, double ecc)
         if (!done && fabs(d) < NEWTON_TOL) { res = p; done = true; }
         p0 = p;
         if (!(fabs(p0) <= 1.79769313486231570e308)) done = true;      // (inf / NaN iterate: it will never converge)
-        if (__ballot(!done) == 0ull) break;
+        if (__ballot(!done) == 0ull) { SSA_KEP_DBG_ITERS(i + 1); break; }
+        if (i == 99) SSA_KEP_DBG_ITERS(100);
         // sinh / cosh of the new iterate: by the addition formulas while every active lane's step is small (all steps after the
         // first or second: the exponential of a fresh evaluation is four times as long), afresh otherwise
         if (__ballot(!done && !(fabs(d) <= 0.02)) == 0ull) {
@@ -393,6 +402,7 @@ SSA_DEV Vec6 kepler_general_fast_impl(Vec6 xin, double tof)
     nu = wrap_pi(nu);
     double q = div_fast(p, 1.0 + ecc);
     double nu1;
+    SSA_KEP_DBG_BRANCH(ecc > 1.0 + 1e-2 ? 1 : (ecc >= 1.0 - 1e-2 ? 2 : 4));   // hyperbolic | near-parabolic band | elliptic the series declined
     if (ecc > 1.0 + 1e-2) {   // the strong-hyperbolic branch (farnocchia.py:909-912, :1001-1004): where a diverged filter lives
         double sn, cn;
         sincos_fast(nu, sn, cn);
@@ -1319,6 +1329,8 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         g_trace[tile * 16 + 15] = ((unsigned long long)xcc << 32) | hw;
+        g_kep_dbg[(blockIdx.x & 16383) * 2] = 0u;
+        g_kep_dbg[(blockIdx.x & 16383) * 2 + 1] = 0u;
     }
 #endif
 
@@ -1842,6 +1854,12 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
           }
         }
         SSA_TR(9);
+#ifdef SSA_TRACE
+        if (lane == 0 && tile < 16384 && !__any(my_update)) {   // (the update's wavefront uses words 10-14 for its own phases)
+            g_trace[tile * 16 + 13] = __hip_atomic_load(&g_kep_dbg[(blockIdx.x & 16383) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g_trace[tile * 16 + 14] = __hip_atomic_load(&g_kep_dbg[(blockIdx.x & 16383) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#endif
 #endif
         // raw-shard consumers (stat_shards_clear): the first tile's wavefront zeroes the shard set the NEXT step accumulates
         // into -- at the very end, so that no wavefront waits for this pointer's kernarg line before its tile loads
