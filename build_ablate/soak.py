@@ -5,7 +5,9 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 sys.argv = ['bench.py']
 import bench
-from ssa_gym_amd import host, engine, _lib
+from ssa_gym_amd import host, engine, _lib, _build
+if os.environ.get("LIB"):     # a diagnostic build instead of the shipped library
+    _build.LIB = os.path.join(ROOT, os.environ["LIB"])
 m, EP = 20000, int(os.environ.get("EPISODES", "20"))
 pb = bench.build_problem(m, seed=100)
 consts = host.make_consts(pb["Q"], pb["R"], 1e-4, 2.0, -3, 20.0, np.radians(10.0), pb["obs_lla"], obs_type='aer', propagator=os.environ.get('PROP', 'fg'))

@@ -946,10 +946,10 @@ SSA_DEV void chol_store_rows(double* Ug, const double (&uc)[6], int l)
 // robust_cholesky (dynamics.py:402-417) for the four objects of the wavefront: plain attempt, then a + 10^i I for
 // i = -6..9 (first success wins); returns the calling row's -1, 0..15, or 16 (LinAlgError).
 // The plain attempt runs row-parallel (each row its own object).  Rows that fail are then served ONE AT A TIME BY THE
-// WHOLE WAVEFRONT: the four rows try four rungs of that object's ladder at once and the lowest successful one wins -- the
-// same answer as the reference's sequential ladder in two factorisations (a diverged filter late in an episode needs rung
-// 10-15: rung by rung its wavefront ran 11-16 factorisations back to back and held the end of the launch,
-// build_ablate/wave_timeline.py).
+// WHOLE WAVEFRONT: the four rows try four consecutive rungs of that object's ladder at once and the lowest successful
+// one wins -- the same answer as the reference's sequential ladder in a quarter of the factorisations (a diverged
+// filter late in an episode needs rung 10-15: without this its wavefront ran 11-16 factorisations back to back and held
+// the end of the launch, build_ablate/wave_timeline.py).
 __constant__ double JITTER[16] = {1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1.0, 10.0, 100.0, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9};
 SSA_DEV int robust_chol_row_lds(Tiles& t, double scale, int g, int l)
 {
@@ -976,20 +976,20 @@ SSA_DEV int robust_chol_row_lds(Tiles& t, double scale, int g, int l)
             }
             int found = 16;
             if (__ballot(!finite) == 0ull) {
-                // Two factorisations per object whatever its rung: the rows first try the LAST rung of each group of four (3, 7,
-                // 11, 15) -- a + j I that factors at j factors at 10 j, so the first group whose last rung succeeds holds the
-                // ladder's answer -- then the four rungs of that group, lowest success wins.  (Group by group from the bottom it
-                // was 3-4 factorisations for the rungs 10-15 a diverged filter needs, per failed row, in the wavefronts that
-                // already hold the end of a late-episode launch: 5-10 us of their 25.)
-                const bool ok1 = chol_row_regs<false>(Pg, scale, JITTER[4 * g + 3], g, l, uc);
-                const unsigned long long won1 = __ballot(ok1);
-                if (won1 != 0ull) {
-                    const int grp = (won1 & 0xFFFFull) ? 0 : ((won1 >> 16) & 0xFFFFull) ? 1 : ((won1 >> 32) & 0xFFFFull) ? 2 : 3;
-                    const bool okr = chol_row_regs<false>(Pg, scale, JITTER[grp * 4 + g], g, l, uc);   // row g tries rung 4 grp + g
-                    const unsigned long long won = __ballot(okr);                                      // (row 3 repeats the known success)
-                    const int win = (won & 0xFFFFull) ? 0 : ((won >> 16) & 0xFFFFull) ? 1 : ((won >> 32) & 0xFFFFull) ? 2 : 3;
-                    found = grp * 4 + win;
-                    if (g == win) chol_store_rows(&t.UA[gf * 36], uc, l);
+                // (Group by group from the bottom, NOT by bisection: with (n + lambda) P ~ 1e14 -- a diverged filter -- the low rungs'
+                // jitter is below the rounding noise of the pivots, success is then NOT monotone in the jitter, and the reference's
+                // answer is the first rung that happens to succeed.  A two-pass search (last rung of each group, then the group)
+                // was tried: 1 object in 20 000 picks another rung every ~270 steps and three filters that used to survive an
+                // episode fail -- build_ablate/ladder_ab.py.)
+                for (int pass = 0; pass < 4; ++pass) {
+                    const bool okr = chol_row_regs<false>(Pg, scale, JITTER[pass * 4 + g], g, l, uc);   // row g tries rung 4 pass + g
+                    const unsigned long long won = __ballot(okr);
+                    if (won != 0ull) {
+                        const int win = (won & 0xFFFFull) ? 0 : ((won >> 16) & 0xFFFFull) ? 1 : ((won >> 32) & 0xFFFFull) ? 2 : 3;
+                        found = pass * 4 + win;
+                        if (g == win) chol_store_rows(&t.UA[gf * 36], uc, l);
+                        break;
+                    }
                 }
             }
             if (g == gf) rung = found;
