@@ -9,6 +9,7 @@ from ssa_gym_amd import host, engine, _lib, _build
 if os.environ.get("LIB"):     # a diagnostic build instead of the shipped library
     _build.LIB = os.path.join(ROOT, os.environ["LIB"])
 m, EP = 20000, int(os.environ.get("EPISODES", "20"))
+AGENT = getattr(_lib, "AGENT_" + os.environ.get("AGENT", "VISIBLE_GREEDY"))      # the closed loops' device agent
 pb = bench.build_problem(m, seed=100)
 consts = host.make_consts(pb["Q"], pb["R"], 1e-4, 2.0, -3, 20.0, np.radians(10.0), pb["obs_lla"], obs_type='aer', propagator=os.environ.get('PROP', 'fg'))
 def run_persistent():
@@ -26,8 +27,8 @@ def run_persistent():
     for ep in range(EP):
         tick += (-tick) % 480
         eng.restore(tick % 2, snap)
-        eng.launch_agent_select(tick, tick, _lib.AGENT_VISIBLE_GREEDY, log.data_ptr(), fallback_ptr=fb.data_ptr())
-        assert eng.launch_closed_loop(tick % 2, tick + 1, _lib.AGENT_VISIBLE_GREEDY, log, stats, fallback=fb[:480])
+        eng.launch_agent_select(tick, tick, AGENT, log.data_ptr(), fallback_ptr=fb.data_ptr())
+        assert eng.launch_closed_loop(tick % 2, tick + 1, AGENT, log, stats, fallback=fb[:480])
         tick += 479
         torch.cuda.synchronize()
         assert int(eng.loop_error[0]) == 0
@@ -53,13 +54,13 @@ def run(closed):
         tick += (-tick) % 480
         eng.flush_stats(); eng.restore(tick % 2, snap)
         if closed:
-            eng.launch_agent_select(tick, tick, _lib.AGENT_VISIBLE_GREEDY, word.data_ptr(), fallback_ptr=fb.data_ptr())
+            eng.launch_agent_select(tick, tick, AGENT, word.data_ptr(), fallback_ptr=fb.data_ptr())
         for i in range(1, 480):
             tick += 1
             ap = word.data_ptr() if closed else sched.data_ptr() + 4 * (ep * 480 + i)
             eng.launch_step((tick - 1) % 2, tick % 2, tick, actions_ptr=ap, fast_stats=True, defer_fold=True)
             if closed:
-                eng.launch_agent_select(tick, tick, _lib.AGENT_VISIBLE_GREEDY, word.data_ptr(), fallback_ptr=fb.data_ptr())
+                eng.launch_agent_select(tick, tick, AGENT, word.data_ptr(), fallback_ptr=fb.data_ptr())
         eng.flush_stats(); torch.cuda.synchronize()
         s = tick % 2
         for tns in (eng.x_true[s], eng.x_filter[s], eng.P_filter[s], eng.stats[s], eng.status):
@@ -70,7 +71,7 @@ def run(closed):
 for closed in (False, True):
     a = run(closed); b = run(closed)
     print("%s: %d episodes x 479 steps, %.1f s (%.0f env-steps/s incl. resets and per-episode read-back); failed filters at episode ends: min %d max %d; "
-          "run 1 == run 2 bit for bit: %s  (sha256 %s)" % ("closed loop (visible greedy, 10 deg mask)" if closed else "round-robin schedule",
+          "run 1 == run 2 bit for bit: %s  (sha256 %s)" % ("closed loop (%s, 10 deg mask)" % os.environ.get("AGENT", "VISIBLE_GREEDY").lower() if closed else "round-robin schedule",
           EP, a[2], EP * 479 / a[2], min(a[1]), max(a[1]), a[0] == b[0], a[0][:16]), flush=True)
     assert a[0] == b[0]
 a = run_persistent(); b = run_persistent(); c = run(True)
