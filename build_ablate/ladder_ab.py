@@ -7,6 +7,10 @@ sys.argv = ['bench.py']
 import bench
 from ssa_gym_amd import host, engine, _lib, _build
 _build.LIB = os.path.join(ROOT, os.environ["LIB"])
+import ctypes
+_probe = ctypes.CDLL(_build.LIB)           # (an older build: bind what it has, accept its ABI number -- the step's parameter block
+_lib.SIGNATURES = {k: v for k, v in _lib.SIGNATURES.items() if hasattr(_probe, k)}      # only ever grew at the end)
+_lib.ABI_VERSION = _probe.ssa_abi_version()
 m = 20000
 pb = bench.build_problem(m, seed=100)
 consts = host.make_consts(pb["Q"], pb["R"], 1e-4, 2.0, -3, 20.0, np.radians(10.0), pb["obs_lla"], obs_type='aer', propagator='fg')
