@@ -7,8 +7,9 @@
 One "step" = one call of the reference's SSA_Tasker_Env.step() (ssa_tasker_simple_2.py:243-367)
 for M objects per GPU: M true-state propagations + M UKF predicts (13 Kepler solves, 6x6
 Cholesky, unscented transform each) + one az-el-range UKF update + observations / error
-metrics / reward statistics.  Inputs are synthetic (catalogue.synthetic_catalogue: the
-reference's regime mix; the reference's own catalogue file does not travel) and resident in
+metrics / reward statistics.  Inputs are synthetic (catalogue.synthetic_catalogue: drawn by the
+reference's own recipe, envs/orbit_gen.py:30-70 -- regime probabilities AND the visibility
+acceptance rule; the reference's own catalogue file does not travel) and resident in
 HBM before the timed region.  Workload at N=1: BASELINE config 3 (20 000 objects, two-body
 Farnocchia; the "J2 on" of that config has no counterpart in the reference -- SURVEY section 0).
 N>1: BASELINE config 4 -- one env of N x 20 000 objects sharded 20k per GPU, with one RCCL
@@ -32,7 +33,7 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_OBJECT_STEP = 896   # r+w x_true 48, x 48, P 288 each way; obs 96; metrics 32
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-FP64_FLOP_PER_OBJECT_STEP = 6400  # profiles/r02_counters.json: (ADD 18 + MUL 89 + 2 FMA 106 + TRANS 10) x 64 lanes + 9 MFMA x 512, per 4 objects
+FP64_FLOP_PER_OBJECT_STEP = 6400  # profiles/r03_counters.json (fg kernel): (ADD 18 + MUL 89 + 2 FMA 106 + TRANS 10) x 64 lanes + 9 MFMA x 512, per 4 objects
 FP64_PEAK_TFLOPS = 78.6           # MI355X datasheet fp64 vector peak (an FMA micro-benchmark reaches 63.2 on these boxes)
 
 
@@ -304,12 +305,14 @@ def closed_loop_rate(m, K, W, seed=100, persistent=True, chunk=120, agent=None):
                     "closed loop on the device: step launch + ssa_agent_select_f64 (2 launches) per step, no host round trip"}
 
 
-def gym_api_rate(m, mode, n=200, obs_device=False):
+def gym_api_rate(m, mode, n=200, obs_device=False, zero_copy=False):
     """env.step() through the gym API (host in the loop: action in, launch, one sync, statistics + observation out over
-    PCIe): the closed-loop rate an unmodified agents.py / RLlib worker sees.  Never `value`."""
+    PCIe): the closed-loop rate an unmodified agents.py / RLlib worker sees.  Never `value`.  zero_copy: config['obs_zero_copy'] --
+    step() hands out a view of the host-mapped ring instead of a fresh copy (the default, as the reference)."""
     from ssa_gym_amd.envs import env_config, make
     cfg = dict(env_config)
-    cfg.update(rso_count=m, steps=480, reward_type='trinary', obs_returned=mode, seed=0, history=2, device_rng=True, obs_device=obs_device)
+    cfg.update(rso_count=m, steps=480, reward_type='trinary', obs_returned=mode, seed=0, history=2, device_rng=True, obs_device=obs_device,
+               obs_zero_copy=zero_copy)
     env = make(config=cfg)
     for k in range(20):
         env.step(k % m)
@@ -329,10 +332,11 @@ def gym_api_rate(m, mode, n=200, obs_device=False):
             "obs_bytes_per_step": 0 if obs_device else m * (12 if mode == 'flatten' else 4) * 8}
 
 
-def torch_policy_rate(m, n=200):
+def torch_policy_rate(m, n=192):
     """env.run_policy(): the closed loop with a policy written in torch (here the visible-greedy rule as tensor expressions on the
-    device scores; any torch module fits) -- step launch + the policy's own kernels per step, no host round trip, one
-    synchronisation per n steps.  Never `value`."""
+    device scores; any torch module fits) -- the policy's own kernels + the step launch per step, captured ONCE per 32 steps into a
+    hipGraph and replayed (`graph`), or enqueued kernel by kernel from the host (`eager`); no host round trip per step either way, one
+    synchronisation per chunk.  Never `value`."""
     import torch
     from ssa_gym_amd.envs import env_config, make
     cfg = dict(env_config)
@@ -341,45 +345,51 @@ def torch_policy_rate(m, n=200):
 
     def policy(view):
         sc, mask = view.scores()
-        masked = torch.where(mask.bool(), sc[0], torch.full_like(sc[0], -float("inf")))
-        return torch.argmax(masked).to(torch.int32).reshape(1)
+        return torch.argmax(torch.where(mask.view(torch.bool), sc[0], float("-inf"))).to(torch.int32).reshape(1)
     fixed = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+    def fixed_policy(view):
+        return fixed
     picked = []
 
     def prepare():
         if env.i + n >= env.n - 1:
             env.reset()
 
-    def measure(pol):
-        for _ in range(3):          # (untimed: torch's first launches of each expression, the caching allocator)
+    def measure(pol, graph):
+        for _ in range(3):          # (untimed: torch's first launches of each expression, the caching allocator, the graph captures)
             prepare()
-            env.run_policy(pol, n)
+            env.run_policy(pol, n, graph=graph)
 
         def block():
-            a, _, _ = env.run_policy(pol, n)
+            a, _, _ = env.run_policy(pol, n, graph=graph)
             picked.extend(a.tolist())
         return timed_repeats(block, lambda: None, prepare=prepare)
-    el0, _, _, _ = measure(lambda view: fixed)     # the env's side alone: a policy that returns a preallocated tensor
+    el0, _, _, _ = measure(fixed_policy, False)     # the env's side alone: a policy that returns a preallocated tensor
+    ele, _, _, _ = measure(policy, False)
     picked.clear()
-    el, lo, hi, reps = measure(policy)
+    el, lo, hi, reps = measure(policy, True)
     dt = el / n
     return {"value": round(1.0 / dt * (m / 20000.0), 2), "ms_per_step": round(1e3 * dt, 5), **spread(n, m / 20000.0, el, lo, hi, reps),
-            "distinct_objects_selected": len(set(picked)),
+            "distinct_objects_selected": len(set(picked)), "graph_error": env.policy_graph_error,
+            "eager": {"value": round(n / ele * (m / 20000.0), 2), "ms_per_step": round(1e3 * ele / n, 5),
+                      "note": "the same policy with every kernel enqueued from the host (run_policy(graph=False): round 3's form)"},
             "env_side_only": {"value": round(n / el0 * (m / 20000.0), 2), "ms_per_step": round(1e3 * el0 / n, 5),
-                              "note": "the same call with a policy that returns a preallocated tensor: what run_policy itself costs "
-                                      "(step launch + bookkeeping); the rest of `ms_per_step` is the policy's own eager torch kernels"},
-            "note": "SSA_Tasker_Env.run_policy(): %d steps per call, the policy = torch tensor expressions on the device (scores kernel + where + "
-                    "argmax), its action read by the next step's launch from device memory; bookkeeping of the %d steps on the host afterwards" % (n, n)}
+                              "note": "eager, with a policy that returns a preallocated tensor: what run_policy itself costs (step launch + bookkeeping)"},
+            "note": "SSA_Tasker_Env.run_policy(): %d steps per call = %d replays of a 32-step hipGraph holding, per step, the policy's torch kernels "
+                    "(scores kernel + where + argmax + cast) and the step launch that reads their action word from device memory; the time index "
+                    "advances on the device; bookkeeping of the steps on the host after each chunk" % (n, n // 32)}
 
 
-def vec_env_rate(m, E=8, n=60, obs_device=False):
+def vec_env_rate(m, E=8, n=60, obs_device=False, zero_copy=False):
     """BASELINE config 5's per-GPU load through the vector-env API: E envs of m objects advanced by ONE launch per
     SSA_Tasker_VecEnv.step() (per-env actions and time indices, auto-reset), host in the loop, the E 'aer' observation
     vectors returned over PCIe.  Reported in 20 000-object env-steps per second (E per call).  Never `value`."""
     from ssa_gym_amd.envs import env_config
     from ssa_gym_amd.envs.vector_env import SSA_Tasker_VecEnv
     cfg = dict(env_config)
-    cfg.update(rso_count=m, steps=480, reward_type='trinary', obs_returned='aer', seed=0, device_rng=True, obs_device=obs_device)
+    cfg.update(rso_count=m, steps=480, reward_type='trinary', obs_returned='aer', seed=0, device_rng=True, obs_device=obs_device,
+               obs_zero_copy=zero_copy)
     env = SSA_Tasker_VecEnv(cfg, num_envs=E, seed=0)
     acts = lambda k: [(k * 7 + 13 * e) % m for e in range(E)]    # noqa: E731
     for k in range(10):
@@ -390,7 +400,15 @@ def vec_env_rate(m, E=8, n=60, obs_device=False):
         for _ in range(n):
             env.step(acts(cnt["k"]))
             cnt["k"] += 1
-    el, lo, hi, reps = timed_repeats(block, lambda: None)
+
+    def prepare():
+        # (round 3's line showed one repeat in six 3.6 x slower than the others, reproducibly: the block in which the eight envs reach step
+        # 479 and auto-reset -- eight host-side catalogue draws, 24 host-to-device copies of 1 MB and eight noise tables, ~25 ms inside a
+        # 7 ms block.  A reset is not a step: the envs are reset UNTIMED when the next block would cross the episode's end, as the
+        # gym-API legs do.)
+        if int(env.i.max()) + n >= env.n - 1:
+            env.reset()
+    el, lo, hi, reps = timed_repeats(block, lambda: None, prepare=prepare)
     dt = el / n
     return {"value": round(E / dt * (m / 20000.0), 2), "ms_per_vector_step": round(1e3 * dt, 5), "envs": E,
             **spread(n, E * m / 20000.0, el, lo, hi, reps),
@@ -726,22 +744,24 @@ def main():
         kern_ms = sum(eng.profile_ms(k) for k in range(nl)) / nl
         alg_bytes = ALG_BYTES_PER_OBJECT_STEP * m
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_src = None, None
         tj = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tj):
+        if os.path.exists(tj):      # (PMC passes cannot run inside this process: the figure is the committed profile's, labelled as such)
             try:
-                traffic = json.load(open(tj)).get("%s_%d" % (args.propagator, m))
+                tjd = json.load(open(tj))
+                traffic = tjd.get("%s_%d" % (args.propagator, m))
+                traffic_src = "profiles/traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, NOT measured in this run" % tjd.get("collected", "committed profile")
             except Exception:  # noqa: BLE001
                 traffic = None
         fp64_tflops = FP64_FLOP_PER_OBJECT_STEP * m / (kern_ms * 1e-3) / 1e12
         roof = {"bound": "hbm", "kernel": "ssa::step_fast_kernel<%d>" % {"elements": 0, "fg": 1, "j2": 2, "hybrid": 3}[args.propagator],
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel_ms": round(kern_ms, 5), "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": nl,
                 "fp64_frac": round(fp64_tflops / FP64_PEAK_TFLOPS, 4),
                 "fp64": {"flop_per_object_step": FP64_FLOP_PER_OBJECT_STEP, "achieved_tflops": round(fp64_tflops, 2),
                          "peak_tflops": FP64_PEAK_TFLOPS,
-                         "note": "flop count from the SQ_INSTS_VALU_*_F64 / MFMA counters of the fg kernel (profiles/r02_counters.json); datasheet vector peak"},
+                         "note": "flop count from the SQ_INSTS_VALU_*_F64 / MFMA counters of the fg kernel (profiles/r03_counters.json); datasheet vector peak"},
                 "limiter": "per-wavefront dependency chain + VALU / LDS issue (HBM idles between the load and store bursts); "
                            "`bound` names the roofline north_star declares for the path, the kernel is not memory-bound",
                 "note": "whole 479-step episode of back-to-back per-step launches, HIP event pair bound to each dispatch"}
@@ -793,13 +813,17 @@ def main():
             legs["closed_loop"] = dict(legs["closed_loop_per_step_launches"], note="more than 20 160 objects: ssa_env_closed_loop_f64 declines "
                                        "(SSA_E_UNSUPPORTED), the closed loop runs as step + ssa_agent_select_f64 launches")
         legs["gym_api"] = {"flatten": gym_api_rate(m, 'flatten'), "aer": gym_api_rate(m, 'aer'),
+                           "flatten_zero_copy": gym_api_rate(m, 'flatten', zero_copy=True),
                            "flatten_device_obs": gym_api_rate(m, 'flatten', obs_device=True),
-                           "note": "SSA_Tasker_Env.step() per call, host in the loop, PCIe + one sync inclusive (20 000 objects); "
+                           "note": "SSA_Tasker_Env.step() per call, host in the loop, PCIe + one sync inclusive (20 000 objects).  flatten: the default "
+                                   "-- a FRESH observation array per step, as the reference (1.92 MB host copy); flatten_zero_copy: config['obs_zero_copy'] "
+                                   "-- a view of the two-deep host-mapped ring the kernel writes; aer: the reference's one persistent array; "
                                    "flatten_device_obs: config['obs_device'] -- the observation stays on the GPU as a CUDA tensor (a policy that "
                                    "lives there), reward / done still cross PCIe"}
         legs["closed_loop_torch_policy"] = torch_policy_rate(m)
         if m == 20000:
             legs["vec_env"] = vec_env_rate(m)
+            legs["vec_env_zero_copy"] = vec_env_rate(m, zero_copy=True)
             legs["vec_env_device_obs"] = vec_env_rate(m, obs_device=True)
 
     cpu, cpu_all, ep_fail = None, None, None

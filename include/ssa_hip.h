@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SSA_ABI_VERSION 20
+#define SSA_ABI_VERSION 21
 #define SSA_INLINE_ENVS 8
 
 /* error codes */
@@ -158,8 +158,8 @@ typedef struct ssa_step_params {
                                   step kernel accumulates max delta_pos / trinary counts / failures itself with sharded
                                   atomics (and writes aer_out, if asked, in its epilogue); a one-wave fold kernel writes
                                   `stats` and clears the words: two launches per step instead of three.  arg-max
-                                  sigma_pos (only the 'shaped' reward needs it) is then NOT computed:
-                                  stats[SSA_STAT_ARGMAX_SPOS] = -1, stats[SSA_STAT_MAX_SPOS] = NaN. */
+                                  sigma_pos (only the 'shaped' reward needs it) is then computed only when spos_tiles is
+                                  given; without: stats[SSA_STAT_ARGMAX_SPOS] = -1, stats[SSA_STAT_MAX_SPOS] = NaN. */
     uint64_t *stat_shards_prev;/* deferred fold (with SSA_LAUNCH_DEFER_FOLD in launch_mask): the shard set the PREVIOUS step
                                   accumulated into, or NULL.  The step kernel then carries n_env extra wavefronts that fold
                                   it into stats_prev and clear it while the objects of THIS step are being advanced, and
@@ -190,6 +190,15 @@ typedef struct ssa_step_params {
     int32_t inline_time[SSA_INLINE_ENVS];   /* with SSA_LAUNCH_INLINE_ENVS (n_env <= SSA_INLINE_ENVS): env e's time index and action BY VALUE; */
     int32_t inline_action[SSA_INLINE_ENVS]; /* `env_time` / `actions` are then not read (env_time must still be non-NULL).  A vector env whose
                                   actions are born on the host every step saves the host-to-device copy in front of the launch */
+    uint64_t *spos_tiles;      /* [ceil(E*m / 4)][2] device words or NULL (with stat_shards): arg-max of sigma_pos ON THE ONE-LAUNCH PATHS -- what the
+                                  'shaped' reward reads, np.argmax(sigma_pos[i - 1]) (ssa_tasker_simple_2.py:339-352).  Every wavefront of the step
+                                  kernel leaves (ordered bits of its tile's largest sigma_pos, index in the env of the first object that holds it) in
+                                  its tile's slot -- no atomics -- and whoever folds the statistics shards (the fold kernel, the deferred fold's
+                                  wavefront in the next launch, the last wavefront with SSA_LAUNCH_FOLD_INSIDE) reduces the slots with np.argmax's
+                                  semantics (first maximum; the first NaN wins): stats[SSA_STAT_ARGMAX_SPOS] and stats[SSA_STAT_MAX_SPOS] are then
+                                  exact on these paths too.  Needs whole tiles per env: n_env == 1 or n_obj % 4 == 0 (SSA_E_UNSUPPORTED otherwise:
+                                  take the three-launch path, stat_shards = NULL).  Contents need no initialisation. */
+    uint64_t *spos_tiles_prev; /* with SSA_LAUNCH_DEFER_FOLD: the slots the PREVIOUS step wrote (folded with stat_shards_prev), or NULL */
 } ssa_step_params;
 
 /* ---------------------------------------------------------------- fused hot path
@@ -241,12 +250,16 @@ typedef struct ssa_rollout_params {
     double *stats_ring;        /* [H][E][SSA_STAT_STRIDE]; only the last H steps' statistics survive, as in any ring */
     const int32_t *actions;    /* [K][E] */
     uint64_t *stat_shards;     /* [K][E][SSA_STAT_SHARDS][SSA_STAT_SHARD_WORDS] zero-initialised; cleared again by the fold */
+    uint64_t *spos_tiles;      /* [K][ceil(E*m / 4)][2] or NULL: per-step arg-max slots (ssa_step_params.spos_tiles): the statistics of every
+                                  step then carry np.argmax(sigma_pos) -- the 'shaped' reward over a rollout */
 } ssa_rollout_params;
 int ssa_env_rollout_f64(const ssa_consts *c_host, const ssa_step_params *first, const ssa_rollout_params *r, void *stream);
 
 /* folds a shard set into stats[n_env][SSA_STAT_STRIDE] and clears it: the last step of a deferred-fold sequence,
  * or whenever the host wants the statistics of the step just launched */
 int ssa_stats_fold_f64(uint64_t *stat_shards, double *stats, int32_t n_env, void *stream);
+/* the same with the arg-max slots of that step (ssa_step_params.spos_tiles; NULL = as ssa_stats_fold_f64) */
+int ssa_stats_fold_spos_f64(uint64_t *stat_shards, const uint64_t *spos_tiles, double *stats, int64_t n_obj, int32_t n_env, void *stream);
 /* historical: size of the `work` buffer (now unused); returns a token size */
 int64_t ssa_env_step_work_bytes(int64_t n_obj, int32_t n_env);
 
@@ -268,6 +281,11 @@ int ssa_kepler_elements_f64(const double *x_in, double *coe, int64_t n, double d
 /* U2  robust_cholesky(A) for n 6x6 matrices: U upper (zeros below), rung[n] = -1 (no jitter),
  * 0..15 (10^(rung-6) added), 16 = LinAlgError (dynamics.py:402). */
 int ssa_robust_cholesky6_f64(const double *A, double *U, int32_t *rung, int64_t n, void *stream);
+/* U2 as the FUSED step kernels run it (the row-distributed ladder of robust_chol_row_lds, four matrices per wavefront): rung[n] as above
+ * from the kernel's one-pass ladder, mask[n] = bit i set when rung i (jitter 10^(i-6)) factorises in the kernel's arithmetic (bit 16: the
+ * plain attempt) -- all sixteen rungs are actually tried, so rung[n] must be the lowest set bit of mask[n] whatever the pattern.  For
+ * numerically rank-one (n + lambda) P -- a diverged filter -- success is NOT monotone in the jitter (tests/golden/ladder_nonmonotone.npz). */
+int ssa_ladder_probe_f64(const double *A, double scale, int32_t *rung, int32_t *mask, double *U, int64_t n, void *stream);
 /* U1  MerweScaledSigmaPoints.sigma_points(x, P): sig[n][13][6], fail[n] (0 / SSA_ST_PREDICT_LINALG). */
 int ssa_sigma_points_f64(const double *x, const double *P, double scale, double *sig, int32_t *fail,
                          int64_t n, void *stream);
@@ -357,7 +375,7 @@ int ssa_chi2_contained_f64(const double *v, int64_t n, double lo, double hi, int
  *   actions[k]   out: the agent's choice for step k (0-based), k = 1 .. K  (actions[K]: the decision after the last step)
  *   fallback[k]     : used for actions[k] when no object qualifies at that decision (the reference samples at random,
  *                     agents.py:40-42: the caller supplies the draws); NULL -> -1 (no update)
- *   stats_out[k]    : [SSA_STAT_STRIDE] reward statistics of step k (arg-max sigma_pos not computed: -1 / NaN, as with stat_shards)
+ *   stats_out[k]    : [SSA_STAT_STRIDE] reward statistics of step k (arg-max sigma_pos only with SSA_LOOP_ARGMAX_SPOS; else -1 / NaN)
  *   upd_out[k]      : [SSA_UPD_STRIDE] update record of step k, or NULL
  *   picks[k]        : optional [K+1][2] int64: arg-max (-1 = fallback used) and the winning score's bits of decision k >= 1
  *   error           : optional device-visible int32, set to 1 if a wavefront waited 2 s for a decision and the launch gave up
@@ -377,7 +395,15 @@ typedef struct ssa_closed_loop_params {
     int32_t *error;            /* or NULL */
     void *workspace;           /* ssa_closed_loop_workspace_bytes() bytes of device memory (contents irrelevant) */
     int64_t workspace_bytes;
+    int64_t wait_ticks;        /* bound of every wait inside the launch, in ticks of the 100 MHz wall clock; 0 = the default (2 s).  A wavefront
+                                  that waits longer for a decision publishes the abort generation, every wavefront leaves, `error` is set */
+    uint32_t flags;            /* SSA_LOOP_* */
+    uint32_t reserved;
 } ssa_closed_loop_params;
+#define SSA_LOOP_ARGMAX_SPOS 1u   /* stats_out[k][SSA_STAT_ARGMAX_SPOS / SSA_STAT_MAX_SPOS] = np.argmax / np.max of sigma_pos after step k (the
+                                     'shaped' reward): two more words per wavefront in the exchange */
+#define SSA_LOOP_DEBUG_WITHHOLD 2u /* DIAGNOSTIC: the deciding wavefront never publishes -- every wait runs into its bound.  For the test of the
+                                     give-up path (tests/test_env_gpu.py): the grid must drain, `error` must be set, later launches must work */
 int ssa_env_closed_loop_f64(const ssa_consts *c_host, const ssa_step_params *first, const ssa_closed_loop_params *r, void *stream);
 int64_t ssa_closed_loop_workspace_bytes(int64_t n_obj, int32_t n_env);
 

@@ -8,7 +8,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "ssa_kernels.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "ssa_math.hpp"),
+DEPS = [SRC, os.path.join(HERE, "csrc", "ssa_math.hpp"), os.path.join(HERE, "csrc", "ssa_conics.hpp"),
         os.path.join(os.path.dirname(HERE), "include", "ssa_hip.h")]
 LIB = os.path.join(HERE, "libssa_hip.so")
 ARCH = "gfx950"

@@ -35,6 +35,7 @@ class ssa_step_params(C.Structure):
         ("stat_shards", c_dp), ("stat_shards_prev", c_dp), ("stats_prev", c_dp), ("aer_out", c_dp),
         ("stat_shards_clear", c_dp), ("aer_cols", C.c_int32), ("action0", C.c_int32), ("obs_mirror", c_dp),
         ("inline_time", C.c_int32 * 8), ("inline_action", C.c_int32 * 8),
+        ("spos_tiles", c_dp), ("spos_tiles_prev", c_dp),
     ]
 
 
@@ -42,7 +43,7 @@ class ssa_rollout_params(C.Structure):
     _fields_ = [
         ("n_steps", C.c_int32), ("history", C.c_int32), ("slot_out", C.c_int32), ("reserved", C.c_int32),
         ("x_true_ring", c_dp), ("x_ring", c_dp), ("P_ring", c_dp), ("obs_ring", c_dp), ("metrics_ring", c_dp),
-        ("upd_ring", c_dp), ("stats_ring", c_dp), ("actions", c_dp), ("stat_shards", c_dp),
+        ("upd_ring", c_dp), ("stats_ring", c_dp), ("actions", c_dp), ("stat_shards", c_dp), ("spos_tiles", c_dp),
     ]
 
 
@@ -52,12 +53,13 @@ class ssa_closed_loop_params(C.Structure):
         ("x_true_ring", c_dp), ("x_ring", c_dp), ("P_ring", c_dp), ("obs_ring", c_dp), ("metrics_ring", c_dp),
         ("upd_out", c_dp), ("stats_out", c_dp), ("actions", c_dp), ("fallback", c_dp), ("picks", c_dp), ("error", c_dp),
         ("workspace", c_dp), ("workspace_bytes", C.c_int64),
+        ("wait_ticks", C.c_int64), ("flags", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 
 # constants of include/ssa_hip.h
 E_INVALID, E_LAUNCH, E_UNSUPPORTED = -1, -2, -3
-ABI_VERSION = 20
+ABI_VERSION = 21
 ST_OK, ST_PREDICT_NAN, ST_PREDICT_LINALG, ST_UPDATE_NAN, ST_UPDATE_LINALG = range(5)
 OBS_AER, OBS_XYZ = 0, 1
 PROP_ELEMENTS, PROP_FG, PROP_J2_RK4, PROP_HYBRID = 0, 1, 2, 3
@@ -72,6 +74,7 @@ LAUNCH_INLINE_ACTION = 16
 LAUNCH_FOLD_INSIDE = 32
 LAUNCH_INLINE_ENVS = 64
 INLINE_ENVS = 8
+LOOP_ARGMAX_SPOS, LOOP_DEBUG_WITHHOLD = 1, 2
 AGENT_NAIVE_GREEDY, AGENT_VISIBLE_GREEDY, AGENT_SHANNON, AGENT_POS_ERROR, AGENT_VEL_ERROR = range(5)
 STAT_STRIDE, STAT_MAX_DPOS, STAT_CNT_LT_1E4, STAT_CNT_LT_1E7, STAT_ARGMAX_SPOS, STAT_N_FAILED, STAT_MAX_SPOS = 8, 0, 1, 2, 3, 4, 5
 
@@ -83,6 +86,8 @@ SIGNATURES = {
     "ssa_env_step_profiled_f64": (C.c_int, [C.POINTER(ssa_consts), C.POINTER(ssa_step_params), c_dp, C.c_int32]),
     "ssa_env_step_profile_ms": (C.c_int, [C.c_int32, C.POINTER(C.c_float)]),
     "ssa_stats_fold_f64": (C.c_int, [c_dp, c_dp, C.c_int32, c_dp]),
+    "ssa_stats_fold_spos_f64": (C.c_int, [c_dp, c_dp, c_dp, C.c_int64, C.c_int32, c_dp]),
+    "ssa_ladder_probe_f64": (C.c_int, [c_dp, C.c_double, c_dp, c_dp, c_dp, C.c_int64, c_dp]),
     "ssa_env_rollout_f64": (C.c_int, [C.POINTER(ssa_consts), C.POINTER(ssa_step_params), C.POINTER(ssa_rollout_params), c_dp]),
     "ssa_env_closed_loop_f64": (C.c_int, [C.POINTER(ssa_consts), C.POINTER(ssa_step_params), C.POINTER(ssa_closed_loop_params), c_dp]),
     "ssa_closed_loop_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32]),

@@ -1,13 +1,17 @@
-"""Synthetic orbit catalogue with the regime mix of the reference's sampler.
+"""Synthetic orbit catalogue by the reference's own recipe.
 
-The reference ships `envs/1.5_hour_viz_20000_of_20000_sample_orbits_seed_0.npy` (20000x6,
-m and m/s, GCRS), produced by envs/orbit_gen.py from `init_state_vec` (dynamics.py:357-399):
-regimes LEO / MEO / GEO / Tundra / Molniya in proportion 2:2:2:1:1, uniformly random
-inc/raan/argp/nu, half of the GEO rows exactly circular-equatorial.  That file is an input of
-the reference repo and does not travel with this package; `synthetic_catalogue` draws rows
-from the same distributions (vectorised; not the same random stream) so that benchmarks and
-tests exercise the same branch mix -- including the exactly circular / equatorial rows that
-take rv2coe's special branches (farnocchia.py:278-309).
+The reference ships `envs/1.5_hour_viz_20000_of_20000_sample_orbits_seed_0.npy` (20000x6, m and m/s, GCRS), produced by
+envs/orbit_gen.py:30-70: per row a regime is drawn -- LEO / MEO / GEO / Tundra / Molniya with probabilities 1/3, 1/3, 1/9, 1/9, 1/9
+(:53) -- and `init_state_vec` (dynamics.py:357-399) candidates of that regime are drawn until one is ACCEPTED (:55-70): propagated over
+4 h in 150 s steps it must stay above 300 km altitude and, seen from the observer (38.83 N, 77.31 W) above 15 deg elevation, either be
+visible all the time or be visible within the first 45 min and never out of sight for 1.5 h or longer.  Regime shares are therefore
+exactly the draw probabilities (6 755 LEO rows in the reference file), every GEO row is equatorial (inc = 0: 2 231 rows) and half of
+them circular (1 135: `stationary * ecc`, :383-385), eccentricities reach 0.737 (Molniya); WITHIN a regime the rule shapes the
+distribution of inclination, node and phase (a LEO object has to pass over the site on consecutive revolutions).  That file is an
+input of the reference repo and does not travel with this package; `synthetic_catalogue` draws rows by the same recipe (vectorised:
+not the same random stream), including the exactly circular / equatorial rows that take rv2coe's special branches
+(farnocchia.py:278-309).  Workload synthesis for bench.py and the tests -- numpy, no device needed: Kepler's equation in closed
+elliptic form for the 96 sample times, the elevation of envs/transformations.py:330-352.
 """
 import numpy as np
 
@@ -27,28 +31,103 @@ def coe2rv_host(p, ecc, inc, raan, argp, nu):
                      vx * r00 + vy * r01, vx * r10 + vy * r11, vx * r20 + vy * r21], axis=-1)
 
 
-def synthetic_catalogue(n=20000, seed=0):
+def _draw_elements(rs, regime, k):
+    """k candidates of one regime, as init_state_vec (dynamics.py:357-399): (a, ecc, inc, raan, argp, nu)"""
+    inc = np.radians(rs.uniform(0, 180, k))
+    raan = np.radians(rs.uniform(0, 360, k))
+    argp = np.radians(rs.uniform(0, 360, k))
+    nu = np.radians(rs.uniform(0, 360, k))
+    if regime in (0, 1):      # LEO / MEO: exo-atmospheric rejection on the semi-minor axis (:369-382)
+        lo, hi = [(RE_EQ + 300e3, RE_EQ + 2000e3), (RE_EQ + 2000e3, RE_EQ + 35786e3)][regime]
+        a, ecc = rs.uniform(lo, hi, k), rs.uniform(0, .25, k)
+        bad = a * np.sqrt(1 - ecc ** 2) <= RE_EQ + 300e3
+        while bad.any():
+            a[bad], ecc[bad] = rs.uniform(lo, hi, bad.sum()), rs.uniform(0, .25, bad.sum())
+            bad = a * np.sqrt(1 - ecc ** 2) <= RE_EQ + 300e3
+    elif regime == 2:         # GEO: inc = 0 always, ecc = 0 for half of them (:383-386)
+        stationary = rs.randint(0, 2, k)
+        a, ecc, inc = np.full(k, 42164e3), stationary * rs.uniform(0, .25, k), np.zeros(k)
+    elif regime == 3:         # Tundra
+        a, inc, ecc, argp = np.full(k, 42164e3), np.full(k, np.radians(63.4)), np.full(k, 0.2), np.full(k, np.radians(270))
+    else:                     # Molniya
+        a, inc, ecc, argp = np.full(k, 26600e3), np.full(k, np.radians(63.4)), np.full(k, 0.737), np.full(k, np.radians(270))
+    return a, ecc, inc, raan, argp, nu
+
+
+def _accepted(a, ecc, inc, raan, argp, nu, M_t, times, enu, obs_itrs, el_min, first, max_gap):
+    """orbit_gen.py:55-70 for a batch of candidates: bool[k]"""
+    k = len(a)
+    cO, sO, ci, si, cw, sw = np.cos(raan), np.sin(raan), np.cos(inc), np.sin(inc), np.cos(argp), np.sin(argp)
+    P = np.stack([cO * cw - sO * ci * sw, sO * cw + cO * ci * sw, si * sw], axis=1)          # perifocal unit vectors in GCRS
+    Q = np.stack([-cO * sw - sO * ci * cw, -sO * sw + cO * ci * cw, si * cw], axis=1)
+    E0 = 2.0 * np.arctan2(np.sqrt(1 - ecc) * np.sin(nu / 2), np.sqrt(1 + ecc) * np.cos(nu / 2))
+    M0 = E0 - ecc * np.sin(E0)
+    n = np.sqrt(MU / a ** 3)
+    b = a * np.sqrt(1 - ecc ** 2)
+    ok_alt = np.ones(k, dtype=bool)
+    vis = np.empty((len(times), k), dtype=bool)
+    for i, t in enumerate(times):
+        M = M0 + n * t
+        E = M + ecc * np.sin(M)
+        for _ in range(12):       # Newton on Kepler's equation (ecc <= 0.737: converged to 1e-14 long before)
+            E = E - (E - ecc * np.sin(E) - M) / (1 - ecc * np.cos(E))
+        r = (a * (np.cos(E) - ecc))[:, None] * P + (b * np.sin(E))[:, None] * Q
+        x = r @ M_t[i].T                                                                        # GCRS -> ITRS
+        rn = np.linalg.norm(x, axis=1)
+        lat = np.arcsin(x[:, 2] / rn)
+        ok_alt &= rn - WGS84_A * (1 - WGS84_F * np.sin(lat) ** 2) > 300e3                      # (geodetic height to ~1 km)
+        d = x - obs_itrs
+        up = d @ enu[:, 2]
+        vis[i] = np.arcsin(up / np.linalg.norm(d, axis=1)) >= el_min
+    run = np.zeros(k, dtype=np.int64)
+    worst = np.zeros(k, dtype=np.int64)
+    for i in range(len(times)):
+        run = np.where(vis[i], 0, run + 1)
+        worst = np.maximum(worst, run)
+    always = vis.all(axis=0)
+    return ok_alt & (always | (vis[:first].any(axis=0) & (worst < max_gap)))
+
+
+WGS84_A, WGS84_F = 6378137.0, 0.0033528106647474805
+_CACHE = {}
+
+
+def synthetic_catalogue(n=20000, seed=0, visibility=True):
+    """n rows by orbit_gen.py's recipe (module docstring).  visibility=False: the regime mix and element distributions alone (every
+    candidate accepted) -- the catalogue of rounds 1-3 up to its regime probabilities."""
+    key = (int(n), int(seed), bool(visibility))
+    if key in _CACHE:
+        return _CACHE[key].copy()
+    if visibility:      # the benchmark's catalogue ships as data (ten minutes of numpy to draw: LEO candidates pass the rule once in ~100)
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "synthetic_catalogue_n%d_seed%d.npy" % key[:2])
+        if os.path.exists(path):
+            _CACHE[key] = np.load(path)
+            return _CACHE[key].copy()
+    from datetime import datetime
+    from .envs.transformations import trans_matrix_table
+    from . import host
     rs = np.random.RandomState(seed)
-    regime = rs.choice(5, size=n, p=[0.25, 0.25, 0.25, 0.125, 0.125])   # LEO MEO GEO Tundra Molniya
-    inc = np.radians(rs.uniform(0, 180, n))
-    raan = np.radians(rs.uniform(0, 360, n))
-    argp = np.radians(rs.uniform(0, 360, n))
-    nu = np.radians(rs.uniform(0, 360, n))
-    a = np.empty(n)
-    ecc = np.empty(n)
-    for k, (lo, hi) in enumerate([(RE_EQ + 300e3, RE_EQ + 2000e3), (RE_EQ + 2000e3, RE_EQ + 35786e3)]):
+    regime = rs.choice(5, size=n, p=[1 / 3, 1 / 3, 1 / 9, 1 / 9, 1 / 9])   # LEO MEO GEO Tundra Molniya (orbit_gen.py:53)
+    step, duration = 150.0, 4 * 3600.0
+    T = int(np.ceil(duration / step))
+    times = step * np.arange(T)
+    M_t = trans_matrix_table(datetime(2020, 5, 4, 0, 0, 0), step, T)
+    obs_lla = np.array((38.828198, -77.305352, 20.0)) * [host.deg2rad, host.deg2rad, 1]
+    enu, obs_itrs = host.enu_matrix(obs_lla), host.lla2ecef(obs_lla)
+    el = np.empty((n, 6))
+    for k in range(5):
         idx = np.where(regime == k)[0]
-        aa, ee = rs.uniform(lo, hi, idx.size), rs.uniform(0, .25, idx.size)
-        bad = aa * np.sqrt(1 - ee ** 2) <= RE_EQ + 300e3
-        while bad.any():   # exo-atmospheric rejection (dynamics.py:369-382)
-            aa[bad], ee[bad] = rs.uniform(lo, hi, bad.sum()), rs.uniform(0, .25, bad.sum())
-            bad = aa * np.sqrt(1 - ee ** 2) <= RE_EQ + 300e3
-        a[idx], ecc[idx] = aa, ee
-    g = regime == 2
-    stationary = rs.randint(0, 2, g.sum())
-    a[g], ecc[g], inc[g] = 42164e3, stationary * rs.uniform(0, .25, g.sum()), 0.0
-    t = regime == 3
-    a[t], inc[t], ecc[t], argp[t] = 42164e3, np.radians(63.4), 0.2, np.radians(270)
-    mo = regime == 4
-    a[mo], inc[mo], ecc[mo], argp[mo] = 26600e3, np.radians(63.4), 0.737, np.radians(270)
-    return np.ascontiguousarray(coe2rv_host(a * (1 - ecc ** 2), ecc, inc, raan, argp, nu))
+        got = 0
+        while got < idx.size:
+            batch = max(4096, 4 * (idx.size - got))
+            cand = _draw_elements(rs, k, batch)
+            ok = (_accepted(*cand, M_t, times, enu, obs_itrs, np.radians(15.0), int(45 * 60 / step), int(1.5 * 3600 / step))
+                  if visibility else np.ones(batch, dtype=bool))
+            sel = np.where(ok)[0][:idx.size - got]
+            el[idx[got:got + sel.size]] = np.stack([c[sel] for c in cand], axis=1)
+            got += sel.size
+    a, ecc, inc, raan, argp, nu = el.T
+    out = np.ascontiguousarray(coe2rv_host(a * (1 - ecc ** 2), ecc, inc, raan, argp, nu))
+    _CACHE[key] = out
+    return out.copy()

@@ -12,234 +12,15 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstddef>
+#include <cstdlib>
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/ssa_hip.h"
 #include "ssa_math.hpp"
+#include "ssa_conics.hpp"
 
 namespace ssa {
-
-// ------------------------------------------------------------------------------------------
-// Complete farnocchia() restatement (all conic branches).  Scalar, out of line.
-// farnocchia.py:165-313 (rv2coe), :847-921 (delta_t_from_nu), :925-1006 (nu_from_delta_t),
-// :337-353 (newton), :692-843 (near-parabolic series), :101-161 (coe2rv).
-namespace gen {
-__device__ static double pymod(double a, double b)
-{
-    double m = fmod(a, b);
-    if (m != 0.0 && ((m < 0.0) != (b < 0.0))) m += b;
-    return m;
-}
-__device__ static double newton(bool hyper, double x0, double M, double ecc, int maxiter)
-{
-    double p0 = x0;
-    for (int i = 0; i < maxiter; ++i) {
-        double fval, fder;
-        if (hyper) {
-            fval = (ecc * sinh(p0) - p0) - M;
-            fder = ecc * cosh(p0) - 1.0;
-        } else {
-            fval = (p0 - ecc * sin(p0)) - M;
-            fder = 1.0 - ecc * cos(p0);
-        }
-        double p = p0 - fval / fder;
-        if (fabs(p - p0) < NEWTON_TOL) return p;
-        p0 = p;
-    }
-    return __builtin_nan("");
-}
-// S_x / dS_x_alt (farnocchia.py:692-760) sum (ecc - 1/(2k+3)) [(2k+3)] x^k until the term drops below
-// 1e-12 -- tens of thousands of terms as |x| -> 1.  Both series have closed forms, used here
-// (they agree with the truncated sums to the truncation tolerance):
-//   sum x^k/(2k+3) = (A(x) - 1)/x,  A = atanh(sqrt x)/sqrt x (x>0) | atan(sqrt -x)/sqrt -x (x<0)
-//   sum (2k+3) x^k = 2x/(1-x)^2 + 3/(1-x)
-__device__ static double S_x(double ecc, double x, bool alt)
-{
-    if (!(fabs(x) < 1.0)) return __builtin_nan("");   // the reference asserts abs(x) < 1
-    const double omx = 1.0 - x;
-    if (alt) return ecc * (2.0 * x / (omx * omx) + 3.0 / omx) - 1.0 / omx;
-    if (fabs(x) < 0.05) {   // short series; the closed form cancels as x -> 0
-        double S = 0.0, xk = 1.0;
-        for (int k = 0; k < 12; ++k) { S += (ecc - 1.0 / (2 * k + 3)) * xk; xk *= x; }
-        return S;
-    }
-    const double sx = sqrt(fabs(x));
-    const double A = (x > 0.0) ? atanh(sx) / sx : atan(sx) / sx;
-    return ecc / omx - (A - 1.0) / x;
-}
-__device__ static double D_to_M_np(double D, double ecc)
-{
-    double x = (ecc - 1.0) / (ecc + 1.0) * (D * D);
-    double S = S_x(ecc, x, false);
-    double ope = 1.0 + ecc;
-    return sqrt(2.0 / ope) * D + sqrt(2.0 / (ope * ope * ope)) * (D * D * D) * S;
-}
-__device__ static double M_to_D(double M)
-{
-    double B = 3.0 * M / 2.0;
-    double A = pow(B + sqrt(1.0 + B * B), 2.0 / 3.0);
-    return 2.0 * A * B / (1.0 + A + A * A);
-}
-__device__ static double M_to_D_np(double M, double ecc)
-{
-    double D0 = M_to_D(M);
-    double ope = 1.0 + ecc;
-    for (int i = 0; i < 50; ++i) {
-        double fval = D_to_M_np(D0, ecc) - M;
-        double x = (ecc - 1.0) / ope * (D0 * D0);
-        double S = S_x(ecc, x, true);
-        double fder = sqrt(2.0 / ope) + sqrt(2.0 / (ope * ope * ope)) * (D0 * D0) * S;
-        double D = D0 - fval / fder;
-        if (fabs(D - D0) < NEWTON_TOL) return D;
-        D0 = D;
-    }
-    return __builtin_nan("");
-}
-__device__ static double E_to_nu(double E, double ecc) { return 2.0 * atan(sqrt((1.0 + ecc) / (1.0 - ecc)) * tan(E / 2.0)); }
-__device__ static double nu_to_E(double nu, double ecc) { return 2.0 * atan(sqrt((1.0 - ecc) / (1.0 + ecc)) * tan(nu / 2.0)); }
-__device__ static double F_to_nu(double F, double ecc) { return 2.0 * atan(sqrt((ecc + 1.0) / (ecc - 1.0)) * tanh(F / 2.0)); }
-__device__ static double nu_to_F(double nu, double ecc) { return 2.0 * atanh(sqrt((ecc - 1.0) / (ecc + 1.0)) * tan(nu / 2.0)); }
-
-__device__ __forceinline__ static double delta_t_from_nu(double nu, double ecc, double k, double q)
-{
-    const double delta = 1e-2;
-    double M, n;
-    double q3 = q * q * q;
-    if (ecc < 1.0 - delta) {
-        double E = nu_to_E(nu, ecc);
-        M = E - ecc * sin(E);
-        n = sqrt(k * (1.0 - ecc) * (1.0 - ecc) * (1.0 - ecc) / q3);
-    } else if (1.0 - delta <= ecc && ecc < 1.0) {
-        double E = nu_to_E(nu, ecc);
-        if (delta <= 1.0 - ecc * cos(E)) {
-            M = E - ecc * sin(E);
-            n = sqrt(k * (1.0 - ecc) * (1.0 - ecc) * (1.0 - ecc) / q3);
-        } else {
-            M = D_to_M_np(tan(nu / 2.0), ecc);
-            n = sqrt(k / (2.0 * q3));
-        }
-    } else if (ecc == 1.0) {
-        double D = tan(nu / 2.0);
-        M = D + D * D * D / 3.0;
-        n = sqrt(k / (2.0 * q3));
-    } else if (1.0 + ecc * cos(nu) < 0.0) {
-        return __builtin_nan("");
-    } else if (1.0 < ecc && ecc <= 1.0 + delta) {
-        double F = nu_to_F(nu, ecc);
-        if (delta <= ecc * cosh(F) - 1.0) {
-            M = ecc * sinh(F) - F;
-            n = sqrt(k * (ecc - 1.0) * (ecc - 1.0) * (ecc - 1.0) / q3);
-        } else {
-            M = D_to_M_np(tan(nu / 2.0), ecc);
-            n = sqrt(k / (2.0 * q3));
-        }
-    } else if (1.0 + delta < ecc) {
-        double F = nu_to_F(nu, ecc);
-        M = ecc * sinh(F) - F;
-        n = sqrt(k * (ecc - 1.0) * (ecc - 1.0) * (ecc - 1.0) / q3);
-    } else {
-        return __builtin_nan("");
-    }
-    return M / n;
-}
-__device__ static double M_to_E(double M, double ecc)
-{
-    double E0 = (ecc < 0.8) ? M : PI * ((M > 0.0) - (M < 0.0));
-    return newton(false, E0, M, ecc, 50);
-}
-__device__ __forceinline__ static double nu_from_delta_t(double delta_t, double ecc, double k, double q)
-{
-    const double delta = 1e-2;
-    double q3 = q * q * q;
-    if (ecc < 1.0 - delta) {
-        double n = sqrt(k * (1.0 - ecc) * (1.0 - ecc) * (1.0 - ecc) / q3);
-        double M = n * delta_t;
-        return E_to_nu(M_to_E(pymod(M + PI, TWO_PI) - PI, ecc), ecc);
-    } else if (1.0 - delta <= ecc && ecc < 1.0) {
-        double E_delta = acos((1.0 - delta) / ecc);
-        double n = sqrt(k * (1.0 - ecc) * (1.0 - ecc) * (1.0 - ecc) / q3);
-        double M = n * delta_t;
-        if (E_delta - ecc * sin(E_delta) <= fabs(M))
-            return E_to_nu(M_to_E(pymod(M + PI, TWO_PI) - PI, ecc), ecc);
-        n = sqrt(k / (2.0 * q3));
-        return 2.0 * atan(M_to_D_np(n * delta_t, ecc));
-    } else if (ecc == 1.0) {
-        double n = sqrt(k / (2.0 * q3));
-        return 2.0 * atan(M_to_D(n * delta_t));
-    } else if (1.0 < ecc && ecc <= 1.0 + delta) {
-        double F_delta = acosh((1.0 + delta) / ecc);
-        double n = sqrt(k * (ecc - 1.0) * (ecc - 1.0) * (ecc - 1.0) / q3);
-        double M = n * delta_t;
-        if (ecc * sinh(F_delta) - F_delta <= fabs(M))
-            return F_to_nu(newton(true, asinh(M / ecc), M, ecc, 100), ecc);
-        n = sqrt(k / (2.0 * q3));
-        return 2.0 * atan(M_to_D_np(n * delta_t, ecc));
-    } else {
-        double n = sqrt(k * (ecc - 1.0) * (ecc - 1.0) * (ecc - 1.0) / q3);
-        double M = n * delta_t;
-        return F_to_nu(newton(true, asinh(M / ecc), M, ecc, 100), ecc);
-    }
-}
-}  // namespace gen
-
-__device__ static void kepler_general_impl(const double* x, double tof, double* out, double* diag)
-{
-    const double tol = 1e-8;
-    const double* r = x;
-    const double* v = x + 3;
-    double h[3] = {r[1] * v[2] - r[2] * v[1], r[2] * v[0] - r[0] * v[2], r[0] * v[1] - r[1] * v[0]};
-    double n[3] = {-h[1], h[0], 0.0};
-    double rn = sqrt(dot3(r, r)), vv = dot3(v, v), rv = dot3(r, v);
-    double c1 = vv - MU / rn;
-    double e[3] = {(c1 * r[0] - rv * v[0]) / MU, (c1 * r[1] - rv * v[1]) / MU, (c1 * r[2] - rv * v[2]) / MU};
-    double ecc = sqrt(dot3(e, e));
-    double p = dot3(h, h) / MU;
-    double hn = sqrt(dot3(h, h));
-    double inc = acos(h[2] / hn);
-    bool circular = ecc < tol, equatorial = fabs(inc) < tol;
-    double raan, argp, nu;
-    if (equatorial && !circular) {
-        raan = 0.0;
-        argp = gen::pymod(atan2(e[1], e[0]), TWO_PI);
-        double t[3] = {e[1] * r[2] - e[2] * r[1], e[2] * r[0] - e[0] * r[2], e[0] * r[1] - e[1] * r[0]};
-        nu = atan2(dot3(h, t) / hn, dot3(r, e));
-    } else if (!equatorial && circular) {
-        raan = gen::pymod(atan2(n[1], n[0]), TWO_PI);
-        argp = 0.0;
-        double t[3] = {h[1] * n[2] - h[2] * n[1], h[2] * n[0] - h[0] * n[2], h[0] * n[1] - h[1] * n[0]};
-        nu = atan2(dot3(r, t) / hn, dot3(r, n));
-    } else if (equatorial && circular) {
-        raan = 0.0;
-        argp = 0.0;
-        nu = gen::pymod(atan2(r[1], r[0]), TWO_PI);
-    } else {
-        double a = p / (1.0 - ecc * ecc);
-        double ka = MU * a;
-        if (a > 0.0) {
-            double e_se = rv / sqrt(ka);
-            double e_ce = rn * vv / MU - 1.0;
-            nu = gen::E_to_nu(atan2(e_se, e_ce), ecc);
-        } else {
-            double e_sh = rv / sqrt(-ka);
-            double e_ch = rn * vv / MU - 1.0;
-            nu = gen::F_to_nu(log((e_ch + e_sh) / (e_ch - e_sh)) / 2.0, ecc);
-        }
-        raan = gen::pymod(atan2(n[1], n[0]), TWO_PI);
-        double t[3] = {h[1] * n[2] - h[2] * n[1], h[2] * n[0] - h[0] * n[2], h[0] * n[1] - h[1] * n[0]};
-        double px = dot3(r, n), py = dot3(r, t) / hn;
-        argp = gen::pymod(atan2(py, px) - nu, TWO_PI);
-    }
-    nu = gen::pymod(nu + PI, TWO_PI) - PI;
-    double q = p / (1.0 + ecc);
-    double dt0 = gen::delta_t_from_nu(nu, ecc, MU, q);
-    double nu1 = gen::nu_from_delta_t(dt0 + tof, ecc, MU, q);
-    coe2rv(p, ecc, inc, raan, argp, nu1, out);
-    if (diag) {
-        diag[0] = p; diag[1] = ecc; diag[2] = inc; diag[3] = raan; diag[4] = argp; diag[5] = nu;
-        diag[6] = dt0; diag[7] = nu1;
-    }
-}
 
 __device__ __noinline__ Vec6 kepler_general_v(Vec6 x, double tof)
 {
@@ -255,182 +36,22 @@ __device__ __noinline__ Vec6 kepler_general_tagged(Vec6 x, double tof)
     kepler_general_impl(x.v, tof, o.v, nullptr);
     return o;
 }
-// ------------------------------------------------------------------------------------------
-// SSA_PROP_HYBRID: the reference's BRANCHES where they matter, at a fraction of their cost.
-// What makes the reference lose filters late in an episode is (a) the cancellation in its covariance sum
-// (SSA_FLAG_REFERENCE_COV) acting on (b) priors that have left the strong-elliptic regime, which farnocchia() then propagates
-// through its hyperbolic / near-parabolic formulas -- tens of metres off for such states.  On strong-elliptic
-// states its chain and the universal-variable solver agree to 1e-14, so there the hybrid runs the series solver of
-// SSA_PROP_FG; every other sigma point goes through the reference's formulas, branch by branch and NaN by NaN as
-// kepler_general_impl above, but with this file's fast primitives (atan2_fast, sincos_fast, one exponential for sinh AND
-// cosh in the hyperbolic Newton loop) instead of libm -- the complete restatement costs ~3 000 vector instructions per
-// call, four times the whole SSA_PROP_FG step, and late in an episode most wavefronts hold a diverged sigma point.
-// Episode-level failure statistics: as SSA_PROP_ELEMENTS / the oracle (tests/test_episode_failures.py).
-#ifdef SSA_TRACE   // (diagnostic build: which branch of the out-of-line propagation a workgroup's lanes took, and their longest Newton run)
-__device__ unsigned g_kep_dbg[16384 * 2];
-#define SSA_KEP_DBG_BRANCH(b) atomicOr(&g_kep_dbg[(blockIdx.x & 16383) * 2], (unsigned)(b))
-#define SSA_KEP_DBG_ITERS(n) atomicMax(&g_kep_dbg[(blockIdx.x & 16383) * 2 + 1], (unsigned)(n))
-#else
-#define SSA_KEP_DBG_BRANCH(b) do { } while (0)
-#define SSA_KEP_DBG_ITERS(n) do { } while (0)
-#endif
-namespace genf {
-// log x for finite x > 0 (the arguments of this path: ratios and sums of positive magnitudes; anything else takes libm):
-// x = m 2^k with m in [sqrt(1/2), sqrt 2), log m = 2 atanh(s), s = (m - 1)/(m + 1), by the fdlibm kernel polynomial; < 1 ulp,
-// ~35 instructions (libm's log: ~80)
-__device__ static double log_pos(double x)
-{
-    if (!(x > 2.2250738585072014e-308 && x <= 1.79769313486231570e308)) return log(x);
-    int k;
-    double m = frexp(x, &k);                // m in [0.5, 1)
-    if (m < 0.70710678118654752440) { m += m; k -= 1; }
-    const double f = m - 1.0;
-    const double sq = div_fast(f, 2.0 + f);
-    const double z = sq * sq, w = z * z;
-    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
-    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
-    const double R = t2 + t1;
-    const double hfsq = 0.5 * f * f;
-    const double dk = (double)k;
-    return dk * 6.93147180369123816490e-01 - ((hfsq - (sq * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
-}
-__device__ static double F_to_nu(double F, double ecc)
-{
-    double sh, chm1;
-    sinh_coshm1(F, sh, chm1);
-    return 2.0 * atan2_fast(sqrt_fast(div_fast(ecc + 1.0, ecc - 1.0)) * div_fast(sh, chm1 + 2.0), 1.0);   // tanh(F/2) = sinh F / (cosh F + 1)
-}
-__device__ static double nu_to_F(double nu, double ecc)
-{
-    double s, c;
-    sincos_fast(nu, s, c);
-    const double x = sqrt_fast(div_fast(ecc - 1.0, ecc + 1.0)) * div_fast(s, 1.0 + c);     // tan(nu/2) = sin nu / (1 + cos nu)
-    return log_pos(div_fast(1.0 + x, 1.0 - x));                                              // 2 atanh(x)
-}
-// newton() on e sinh F - F - M (farnocchia.py:337-353: step tolerance 1.48e-8, 100 iterations, NaN when it gives up)
-__device__ static double newton_hyp(double x0, double M, double ecc)
-{
-    double p0 = x0, res = __builtin_nan("");
-    bool done = false;
-    double sh, chm1;
-    sinh_coshm1(p0, sh, chm1);
-    for (int i = 0; i < 100; ++i) {
-        const double fval = (ecc * sh - p0) - M;
-        const double fder = ecc * (chm1 + 1.0) - 1.0;
-        const double p = p0 - div_fast(fval, fder);
-        const double d = p - p0;
-        if (!done && fabs(d) < NEWTON_TOL) { res = p; done = true; }
-        p0 = p;
-        if (!(fabs(p0) <= 1.79769313486231570e308)) done = true;      // (inf / NaN iterate: it will never converge)
-        if (__ballot(!done) == 0ull) { SSA_KEP_DBG_ITERS(i + 1); break; }
-        if (i == 99) SSA_KEP_DBG_ITERS(100);
-        // sinh / cosh of the new iterate: by the addition formulas while every active lane's step is small (all steps after the
-        // first or second: the exponential of a fresh evaluation is four times as long), afresh otherwise
-        if (__ballot(!done && !(fabs(d) <= 0.02)) == 0ull) {
-            const double d2 = d * d;
-            const double sd = d * (1.0 + d2 * (1.0 / 6.0) * (1.0 + d2 * (1.0 / 20.0) * (1.0 + d2 * (1.0 / 42.0))));
-            const double cdm1 = d2 * 0.5 * (1.0 + d2 * (1.0 / 12.0) * (1.0 + d2 * (1.0 / 30.0) * (1.0 + d2 * (1.0 / 56.0))));
-            const double sh2 = fma(sh, cdm1, sh) + (chm1 + 1.0) * sd;
-            chm1 = fma(chm1, cdm1, chm1) + cdm1 + sh * sd;
-            sh = sh2;
-        } else sinh_coshm1(p0, sh, chm1);
-    }
-    return res;
-}
-}  // namespace genf
-// (the rare bands -- near-parabolic, parabolic, elliptic beyond the series -- as a call of their own: inlined they pushed
-// the whole function past the step kernels' 96 registers)
-template <int TAG>
-__device__ __noinline__ double kepler_band_nu(double nu, double ecc, double q, double tof)
-{
-    const double dt0 = gen::delta_t_from_nu(nu, ecc, MU, q);
-    return gen::nu_from_delta_t(dt0 + tof, ecc, MU, q);
-}
-template <int TAG>
-SSA_DEV Vec6 kepler_general_fast_impl(Vec6 xin, double tof)
-{
-    const double tol = 1e-8;
-    const double* r = xin.v;
-    const double* v = xin.v + 3;
-    Vec6 outv;
-    double h[3] = {r[1] * v[2] - r[2] * v[1], r[2] * v[0] - r[0] * v[2], r[0] * v[1] - r[1] * v[0]};
-    double n[3] = {-h[1], h[0], 0.0};
-    const double inv_mu = 1.0 / MU;
-    double rn = sqrt_fast(dot3(r, r)), vv = dot3(v, v), rv = dot3(r, v);
-    double c1 = vv - div_fast(MU, rn);
-    double e[3] = {(c1 * r[0] - rv * v[0]) * inv_mu, (c1 * r[1] - rv * v[1]) * inv_mu, (c1 * r[2] - rv * v[2]) * inv_mu};
-    double ecc = sqrt_fast(dot3(e, e));
-    double p = dot3(h, h) * inv_mu;
-    double hn = sqrt(dot3(h, h));
-    const double inv_hn = rcp_nr(hn);
-    double inc = acos(h[2] / hn);        // (as rv2coe_elliptic: the equatorial test needs the correctly rounded quotient)
-    bool circular = ecc < tol, equatorial = fabs(inc) < tol;
-    double raan, argp, nu;
-    if (equatorial && !circular) {
-        raan = 0.0;
-        argp = mod_2pi(atan2_fast(e[1], e[0]));
-        double t[3] = {e[1] * r[2] - e[2] * r[1], e[2] * r[0] - e[0] * r[2], e[0] * r[1] - e[1] * r[0]};
-        nu = atan2_fast(dot3(h, t) * inv_hn, dot3(r, e));
-    } else if (!equatorial && circular) {
-        raan = mod_2pi(atan2_fast(n[1], n[0]));
-        argp = 0.0;
-        double t[3] = {h[1] * n[2] - h[2] * n[1], h[2] * n[0] - h[0] * n[2], h[0] * n[1] - h[1] * n[0]};
-        nu = atan2_fast(dot3(r, t) * inv_hn, dot3(r, n));
-    } else if (equatorial && circular) {
-        raan = 0.0;
-        argp = 0.0;
-        nu = mod_2pi(atan2_fast(r[1], r[0]));
-    } else {
-        double a = div_fast(p, 1.0 - ecc * ecc);
-        double ka = MU * a;
-        if (a > 0.0) {
-            double e_se = rv * rsqrt_nr(ka);
-            double e_ce = rn * vv * inv_mu - 1.0;
-            double sh, ch;
-            sincos_fast(0.5 * atan2_fast(e_se, e_ce), sh, ch);
-            nu = 2.0 * atan2_fast(sqrt_fast(div_fast(1.0 + ecc, 1.0 - ecc)) * div_fast(sh, ch), 1.0);
-        } else {
-            double e_sh = rv * rsqrt_nr(-ka);
-            double e_ch = rn * vv * inv_mu - 1.0;
-            nu = genf::F_to_nu(0.5 * genf::log_pos(div_fast(e_ch + e_sh, e_ch - e_sh)), ecc);
-        }
-        raan = mod_2pi(atan2_fast(n[1], n[0]));
-        double t[3] = {h[1] * n[2] - h[2] * n[1], h[2] * n[0] - h[0] * n[2], h[0] * n[1] - h[1] * n[0]};
-        double px = dot3(r, n), py = dot3(r, t) * inv_hn;
-        argp = mod_2pi(atan2_fast(py, px) - nu);
-    }
-    nu = wrap_pi(nu);
-    double q = div_fast(p, 1.0 + ecc);
-    double nu1;
-    SSA_KEP_DBG_BRANCH(ecc > 1.0 + 1e-2 ? 1 : (ecc >= 1.0 - 1e-2 ? 2 : 4));   // hyperbolic | near-parabolic band | elliptic the series declined
-    if (ecc > 1.0 + 1e-2) {   // the strong-hyperbolic branch (farnocchia.py:909-912, :1001-1004): where a diverged filter lives
-        double sn, cn;
-        sincos_fast(nu, sn, cn);
-        if (1.0 + ecc * cn < 0.0) nu1 = __builtin_nan("");          // (:885-888: beyond the asymptote)
-        else {
-            const double F0 = genf::nu_to_F(nu, ecc);
-            double sh, chm1;
-            sinh_coshm1(F0, sh, chm1);
-            const double M0 = ecc * sh - F0;
-            const double em1 = ecc - 1.0;
-            const double nmm = sqrt_fast(div_fast(MU * em1 * em1 * em1, q * q * q));
-            const double M = nmm * (div_fast(M0, nmm) + tof);
-            const double me = div_fast(M, ecc);
-            // asinh(M / e) = sign log(|.| + sqrt(.^2 + 1))
-            const double am = fabs(me);
-            const double F = genf::newton_hyp(copysign(genf::log_pos(am + sqrt_fast(am * am + 1.0)), me), M, ecc);
-            nu1 = genf::F_to_nu(F, ecc);
-        }
-    } else {                  // elliptic / parabolic / near-parabolic bands: the complete restatement
-        nu1 = kepler_band_nu<TAG>(nu, ecc, q, tof);
-    }
-    coe2rv(p, ecc, inc, raan, argp, nu1, outv.v);
-    return outv;
-}
-__device__ __noinline__ Vec6 kepler_general_fast_v(Vec6 x, double tof) { return kepler_general_fast_impl<0>(x, tof); }
 // the step kernels' own instance (inherits their register budget, see kepler_general_tagged)
 template <int TAG>
 __device__ __noinline__ Vec6 kepler_general_fast_tagged(Vec6 x, double tof) { return kepler_general_fast_impl<TAG>(x, tof); }
+// What the series solver declined, out of line: every conic of the general orientation in the lean form, bands inline (ssa_conics.hpp);
+// what THAT declines -- rv2coe's special branches, non-finite input: practically never inside a step -- goes on to the complete
+// restatement from here (a nested call: the kernels see ONE call site, as they always did).
+template <int TAG>
+__device__ __noinline__ Vec6 kepler_beyond_series_tagged(Vec6 x, double tof)
+{
+    Vec6 o;
+    const bool ok = kepler_conic_lean<TAG, false>(x.v, tof, o.v);
+    if (__any(!ok)) {
+        if (!ok) o = kepler_general_fast_tagged<TAG>(x, tof);
+    }
+    return o;
+}
 // the hybrid's lane-level choice: true = the series solver's result stands (strong-elliptic state inside its domain)
 SSA_DEV bool kepler_hybrid_fast(const double* s, double tof, double* o)
 {
@@ -951,6 +572,34 @@ SSA_DEV void chol_store_rows(double* Ug, const double (&uc)[6], int l)
 // filter late in an episode needs rung 10-15: without this its wavefront ran 11-16 factorisations back to back and held
 // the end of the launch, build_ablate/wave_timeline.py).
 __constant__ double JITTER[16] = {1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1.0, 10.0, 100.0, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9};
+// Does scale * P + jit * I factorise?  ONE lane decides, alone, in its own registers: the ladder's unit of work when every lane
+// of a row tries its own rung (robust_chol_row_lds below).  Operation by operation the arithmetic of chol_row_regs<false> --
+// the same fused multiply-adds in the same order, the same refined reciprocal square root -- so a rung succeeds here exactly
+// when it succeeds there (the round-3 library's results are reproduced bit for bit: profiles/r04_ab_against_round3.txt).
+// Only the verdict leaves: an entry U[i][c] is dead once step c has used it, so at most nine entries are live at a time
+// (a lane that kept its whole factor, 42 registers, made the closed-loop kernels spill); the winning rung's factor is then
+// formed once more by the row (chol_row_regs<false>), which is where it is needed in the row-distributed layout anyway.
+// The matrix is read from LDS where it is used (the lanes of a row read the same address: a broadcast).
+SSA_DEV bool chol_lane_ok(const double* Pg, double scale, double jit)
+{
+    double U[21];
+    double y = 0.0;
+#pragma unroll
+    for (int J = 0; J < 6; ++J) {
+        double vp = fma(scale, Pg[J * 6 + J], jit);
+#pragma unroll
+        for (int i = 0; i < J; ++i) vp = fma(-U[tri(i, J)], U[tri(i, J)], vp);
+        y = rsqrt_nr(vp);               // NaN / inf when the pivot is <= 0 or NaN: poisons everything behind it (see chol_step)
+#pragma unroll
+        for (int c = J + 1; c < 6; ++c) {
+            double v = scale * Pg[J * 6 + c];
+#pragma unroll
+            for (int i = 0; i < J; ++i) v = fma(-U[tri(i, J)], U[tri(i, c)], v);
+            U[tri(J, c)] = v * y;
+        }
+    }
+    return (y > 0.0) && (y <= 1.79769313486231570e308);
+}
 SSA_DEV int robust_chol_row_lds(Tiles& t, double scale, int g, int l)
 {
     double uc[6];
@@ -965,7 +614,40 @@ SSA_DEV int robust_chol_row_lds(Tiles& t, double scale, int g, int l)
         wave_lds_sync();
         if (bad == 0ull) return rung;                  // the common case, wave-uniform
         __builtin_amdgcn_s_setprio(3);                 // a straggler in the making: issue priority for the rest of its life
-        for (int gf = 0; gf < OBJ_PER_WAVE; ++gf) {    // wave-uniform loop over the rows that failed
+#ifndef SSA_LADDER_BY_PASSES
+        // The ladder in ONE pass, every failed row at once: lane l of a row decides, whole and alone (chol_lane_ok), whether its
+        // row's matrix factorises with rung l's jitter, so the sixteen rungs of up to four objects are tried side by side; the
+        // FIRST rung that succeeds -- the reference's sequential answer, dynamics.py:406-414, also where success is not monotone
+        // in the jitter: every rung is actually tried -- is the lowest set bit of the row's ballot, and the row forms that rung's
+        // factor.  Two factorisations' latency whatever the rung and however many of the four objects need the ladder (before:
+        // the rows took turns, four rungs per pass: a wavefront with four diverged objects at rungs 12-15 ran sixteen passes back
+        // to back and held the end of a late-episode launch, build_ablate/wave_timeline.py).
+        {
+            const bool mine = ((bad >> (g * 16)) & 1ull) != 0ull;   // row-uniform
+            if (mine) {
+                const double* Pg = &t.P[g * 36];
+                const double jit = JITTER[l];
+                bool finite = true;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int idx = l + 16 * r;
+                    if (idx < 36) finite = finite && (fabs(Pg[idx]) <= 1.79769313486231570e308);
+                }
+                finite = ((__ballot(!finite) >> (g * 16)) & 0xFFFFull) == 0ull;      // scipy's check_finite: the whole matrix
+                const bool okr = chol_lane_ok(Pg, scale, jit) && finite;
+                const unsigned won = (unsigned)((__ballot(okr) >> (g * 16)) & 0xFFFFull);
+                if (won != 0u) {
+                    rung = __ffs((int)won) - 1;
+                    const double jw = __shfl(jit, g * 16 + rung, 64);            // the winning rung's jitter, from the lane that tried it
+                    chol_row_regs<false>(Pg, scale, jw, g, l, uc);               // (succeeds: the same arithmetic said so)
+                    chol_store_rows(&t.UA[g * 36], uc, l);
+                }
+            }
+            wave_lds_sync();
+            return rung;
+        }
+#endif
+        for (int gf = 0; gf < OBJ_PER_WAVE; ++gf) {    // wave-uniform loop over the rows that failed (the former form: -DSSA_LADDER_BY_PASSES)
             if (((bad >> (gf * 16)) & 1ull) == 0ull) continue;
             const double* Pg = &t.P[gf * 36];
             bool finite = true;
@@ -981,7 +663,22 @@ SSA_DEV int robust_chol_row_lds(Tiles& t, double scale, int g, int l)
                 // answer is the first rung that happens to succeed.  A two-pass search (last rung of each group, then the group)
                 // was tried: 1 object in 20 000 picks another rung every ~270 steps and three filters that used to survive an
                 // episode fail -- build_ablate/ladder_ab.py.)
+#ifdef SSA_LADDER_TWO_PASS   // diagnostic ONLY (tests/golden/gen_ladder_nonmonotone.py): the search round 3 tried and reverted -- last rung of
+                // each group of four, then the group.  It assumes success is monotone in the jitter; the committed fixture is a case where it is not.
+                const bool ok1 = chol_row_regs<false>(Pg, scale, JITTER[4 * g + 3], g, l, uc);
+                const unsigned long long won1 = __ballot(ok1);
+                if (won1 != 0ull) {
+                    const int grp = (won1 & 0xFFFFull) ? 0 : ((won1 >> 16) & 0xFFFFull) ? 1 : ((won1 >> 32) & 0xFFFFull) ? 2 : 3;
+                    const bool okr = chol_row_regs<false>(Pg, scale, JITTER[grp * 4 + g], g, l, uc);
+                    const unsigned long long won = __ballot(okr);
+                    const int win = (won & 0xFFFFull) ? 0 : ((won >> 16) & 0xFFFFull) ? 1 : ((won >> 32) & 0xFFFFull) ? 2 : 3;
+                    found = grp * 4 + win;
+                    if (g == win) chol_store_rows(&t.UA[gf * 36], uc, l);
+                }
+                for (int pass = 4; pass < 4; ++pass) {
+#else
                 for (int pass = 0; pass < 4; ++pass) {
+#endif
                     const bool okr = chol_row_regs<false>(Pg, scale, JITTER[pass * 4 + g], g, l, uc);   // row g tries rung 4 pass + g
                     const unsigned long long won = __ballot(okr);
                     if (won != 0ull) {
@@ -1129,6 +826,83 @@ SSA_DEV bool stat_tile_counted(const ssa_step_params& p, int64_t e, int tile)
     __hip_atomic_store(env0 + 4, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
 }
+// ---- arg-max of sigma_pos on the one-launch paths (the 'shaped' reward needs np.argmax(sigma_pos[i - 1]),
+// ssa_tasker_simple_2.py:346).  Every wavefront leaves (key, index) of its tile's first maximum in the tile's slot of `spos_tiles`
+// -- no atomics -- and whoever folds the statistics shards reduces the slots with np.argmax's semantics: the first maximum, and a
+// NaN ranks above everything (the first NaN wins).  key = the double's bits (sigma_pos >= 0: non-negative doubles order like
+// unsigned integers, NaN -- canonicalised -- above infinity); index = the object's index in its env.
+constexpr unsigned long long SPOS_NAN_KEY = 0x7ff8000000000000ull;
+SSA_DEV unsigned long long spos_key(double v)
+{
+    return (v != v) ? SPOS_NAN_KEY : ((unsigned long long)__double_as_longlong(v) & 0x7fffffffffffffffull);
+}
+SSA_DEV double spos_of_key(unsigned long long k) { return __longlong_as_double((long long)k); }
+// first maximum of the tile's `cnt` objects (lane-local: any lane may call it; reads t.Met)
+SSA_DEV void spos_tile_best(const Tiles& t, int cnt, int64_t j0, unsigned long long& key, unsigned long long& idx)
+{
+    key = spos_key(t.Met[2]);
+    idx = (unsigned long long)j0;
+#pragma unroll
+    for (int g = 1; g < OBJ_PER_WAVE; ++g) {
+        const unsigned long long k = spos_key(t.Met[g * 4 + 2]);
+        if (g < cnt && k > key) { key = k; idx = (unsigned long long)(j0 + g); }
+    }
+}
+// 64-bit wave folds by DPP rotations + readlanes (see the closed loop, which introduced them)
+template <int CTRL>
+SSA_DEV unsigned long long dpp_u64(unsigned long long v)
+{
+    return (unsigned long long)__builtin_amdgcn_update_dpp((long long)v, (long long)v, CTRL, 0xF, 0xF, true);
+}
+SSA_DEV unsigned long long lane_u64(unsigned long long v, int l)
+{
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)v, l);
+}
+struct OpMax { SSA_DEV unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a > b ? a : b; } };
+struct OpMin { SSA_DEV unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a < b ? a : b; } };
+struct OpAdd { SSA_DEV unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a + b; } };
+template <class OP>
+SSA_DEV unsigned long long wave_fold_u64(unsigned long long v, OP op)
+{
+    v = op(v, dpp_u64<0x128>(v));   // row_ror:8
+    v = op(v, dpp_u64<0x124>(v));   // row_ror:4
+    v = op(v, dpp_u64<0x122>(v));   // row_ror:2
+    v = op(v, dpp_u64<0x121>(v));   // row_ror:1
+    return op(op(lane_u64(v, 0), lane_u64(v, 16)), op(lane_u64(v, 32), lane_u64(v, 48)));
+}
+// reduces the slots of env e's tiles (tiles [t_lo, t_hi]: whole tiles of ONE env -- the launcher refuses spos_tiles for envs whose
+// object count is not a multiple of four unless there is only one env) into stats.  COHERENT: agent-scope loads (the slots were
+// written by other wavefronts of the SAME launch: SSA_LAUNCH_FOLD_INSIDE); otherwise a kernel boundary lies in between.
+template <bool COHERENT>
+SSA_DEV void fold_spos_tiles(const unsigned long long* __restrict__ slots, int t_lo, int t_hi, double* __restrict__ stats, int lane)
+{
+    unsigned long long key = 0ull, idx = ~0ull;
+    bool any = false;
+    for (int tb = t_lo + lane; tb <= t_hi; tb += 64) {
+        unsigned long long k, i;
+        if (COHERENT) {
+            k = __hip_atomic_load(slots + 2 * (int64_t)tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            i = __hip_atomic_load(slots + 2 * (int64_t)tb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(slots + 2 * (int64_t)tb);
+            k = v.x; i = v.y;
+        }
+        if (!any || k > key) { key = k; idx = i; any = true; }      // (a lane's tiles come in increasing order: ties keep the earlier one)
+    }
+    const unsigned long long top = wave_fold_u64(any ? key : 0ull, OpMax());
+    const unsigned long long who = wave_fold_u64((any && key == top) ? idx : ~0ull, OpMin());
+    if (lane == 0) {
+        stats[SSA_STAT_ARGMAX_SPOS] = (double)(long long)who;
+        stats[SSA_STAT_MAX_SPOS] = spos_of_key(top);
+    }
+}
+// tiles of env e (whole tiles; one env: all of them)
+SSA_DEV void env_tile_range(int64_t n_obj, int e, int& t_lo, int& t_hi)
+{
+    const int64_t first = (int64_t)e * n_obj;
+    t_lo = (int)(first / OBJ_PER_WAVE);
+    t_hi = (int)((first + n_obj - 1) / OBJ_PER_WAVE);
+}
 SSA_DEV void fold_stat_shards_inside(unsigned long long* __restrict__ shards, double* __restrict__ stats, int lane)
 {
     unsigned long long* sh = shards + (int64_t)lane * SSA_STAT_SHARD_WORDS;
@@ -1185,13 +959,14 @@ struct LoopK;
 SSA_DEV void closed_loop_prescore(ActLate& a, Tiles& t, int lane, int cnt);   // (defined with the closed-loop kernel)
 SSA_DEV void closed_loop_store(const LoopK* lk, Tiles& t, int lane, int kk, int64_t base, int cnt);
 constexpr unsigned CL_ABORT_GEN = 0xFFFFFFFFu;            // decision number that means "give up" (a wavefront timed out)
-constexpr unsigned long long CL_TIMEOUT_TICKS = 200000000ull;   // 2 s of the 100 MHz wall clock without the awaited decision
+constexpr unsigned long long CL_TIMEOUT_TICKS = 200000000ull;   // default bound of a wait: 2 s of the 100 MHz wall clock (ssa_closed_loop_params.wait_ticks)
 struct ActLate {
     static constexpr bool late = true;
     unsigned long long* flag;        // this wavefront's group flag: (decision number << 32) | action
     unsigned long long* all_flags;   // [nflags] flags, 16 words apart (abort broadcast)
     int* err;                        // device word set to 1 on a timeout (may be host-mapped)
     int nflags;
+    unsigned long long timeout;      // bound of every wait, 100 MHz ticks
     unsigned want;                   // decision needed: the step's index (>= 1); 0 = `first`
     int first;                       // action of the launch's first step (decided by the caller)
     int last;                        // the action get() returned most recently
@@ -1245,7 +1020,7 @@ struct ActLate {
             lo = __builtin_amdgcn_readfirstlane((unsigned)v);
             hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
             if (hi >= want) break;
-            if (wall_clock64() - t0 > CL_TIMEOUT_TICKS) {
+            if (wall_clock64() - t0 > timeout) {
                 abort_all();
                 hi = CL_ABORT_GEN;
                 break;
@@ -1391,13 +1166,21 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         if (PROP == 3) {
             if (__any(!kep_ok)) {   // sigma points outside the strong-elliptic regime: the reference's branches (whole-wave branch)
                 __builtin_amdgcn_s_setprio(3);
-                if (!kep_ok) {
-                    Vec6 si;
+                // second tier, inline: the conic branches for the general orientation (the strong-hyperbolic one -- where a diverged filter
+                // lives -- without a call); third tier, out of line: the complete restatement for rv2coe's special branches and NaN input
+                bool served = kep_ok;
+                if (!ACT::late) {     // (the closed-loop instance keeps the call alone -- with the tier inline it spilled; the callee takes the lean form too)
+                    if (!kep_ok) served = kepler_conic_lean<1, true>(s, C.dt, o);
+                }
+                if (__any(!served)) {
+                    if (!served) {
+                        Vec6 si;
 #pragma unroll
-                    for (int c = 0; c < 6; ++c) si.v[c] = s[c];
-                    Vec6 oo = kepler_general_fast_tagged<1>(si, C.dt);
+                        for (int c = 0; c < 6; ++c) si.v[c] = s[c];
+                        Vec6 oo = kepler_beyond_series_tagged<1>(si, C.dt);
 #pragma unroll
-                    for (int c = 0; c < 6; ++c) o[c] = oo.v[c];
+                        for (int c = 0; c < 6; ++c) o[c] = oo.v[c];
+                    }
                 }
             }
         } else if (PROP != 0) {
@@ -1413,15 +1196,21 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
         } else if (__any(!kep_ok)) {
             // SSA_PROP_ELEMENTS outside the strong-elliptic regime (or NaN input): the complete restatement of
             // farnocchia(), out of line, for the lanes that need it (whole-wave branch: skipped otherwise)
-            if (!kep_ok) {
-                Vec6 si;
+            // (the reference's formulas branch by branch with this file's fast primitives, as SSA_PROP_HYBRID: the strong-hyperbolic
+            // branch inline, the rest through the out-of-line restatement)
+            bool served = kep_ok;
+            if (!ACT::late) {     // (the closed-loop instance of this variant keeps the call alone: with the tier inline it spilled)
+                if (!kep_ok) served = kepler_conic_lean<2, true>(s, C.dt, o);
+            }
+            if (__any(!served)) {
+                if (!served) {
+                    Vec6 si;
 #pragma unroll
-                for (int c = 0; c < 6; ++c) si.v[c] = s[c];
-                // (the reference's formulas branch by branch with this file's fast primitives, as SSA_PROP_HYBRID: the libm
-                // restatement kepler_general_tagged costs three times as much per call and late in an episode most wavefronts call it)
-                Vec6 oo = kepler_general_fast_tagged<2>(si, C.dt);
+                    for (int c = 0; c < 6; ++c) si.v[c] = s[c];
+                    Vec6 oo = kepler_beyond_series_tagged<2>(si, C.dt);
 #pragma unroll
-                for (int c = 0; c < 6; ++c) o[c] = oo.v[c];
+                    for (int c = 0; c < 6; ++c) o[c] = oo.v[c];
+                }
             }
         }
     }
@@ -1767,6 +1556,13 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     SSA_TR(7);
     if (!ACT::late) {   // (closed_loop_kernel stores the tile itself, AFTER it has announced its part of the decision)
 #if !(defined(SSA_ABLATE) && (SSA_ABLATE & 32))
+        if (p.spos_tiles && p.stat_shards && lane == 0) {   // the tile's first maximum of sigma_pos (np.argmax for the 'shaped' reward): one slot, no atomics
+            unsigned long long key, idx;
+            spos_tile_best(t, cnt, obj - (int64_t)e * p.n_obj, key, idx);
+            unsigned long long* slot = (unsigned long long*)p.spos_tiles + 2 * (int64_t)tile;
+            __hip_atomic_store(slot, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (agent scope: SSA_LAUNCH_FOLD_INSIDE reads them in this launch)
+            __hip_atomic_store(slot + 1, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         store_tile<TILE != 1>(t, p, lane, base, cnt);
         SSA_TR(8);
         // O3 by sharded atomics: max delta_pos (as ordered bits: non-negative doubles and NaN order like unsigned
@@ -1811,6 +1607,11 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                 const int64_t e_tile = (p.n_env > 1) ? (int64_t)((uint32_t)base / (uint32_t)p.n_obj) : 0;
                 fold_stat_shards_inside((unsigned long long*)p.stat_shards + e_tile * SSA_STAT_SHARDS * SSA_STAT_SHARD_WORDS,
                                         p.stats + e_tile * SSA_STAT_STRIDE, lane);
+                if (p.spos_tiles) {
+                    int t_lo, t_hi;
+                    env_tile_range(p.n_obj, (int)e_tile, t_lo, t_hi);
+                    fold_spos_tiles<true>((const unsigned long long*)p.spos_tiles, t_lo, t_hi, p.stats + e_tile * SSA_STAT_STRIDE, lane);
+                }
             }
         } else if (p.stat_shards) {   // a tile that straddles envs: one group of atomics per env (lane 0)
           unsigned fold_envs = 0u;    // bit i: env e_first + i was completed by this tile (a tile spans at most four envs)
@@ -1850,7 +1651,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
               for (int i = 0; i < OBJ_PER_WAVE; ++i)
                   if (fold_envs & (1u << i))
                       fold_stat_shards_inside((unsigned long long*)p.stat_shards + (e_first + i) * SSA_STAT_SHARDS * SSA_STAT_SHARD_WORDS,
-                                              p.stats + (e_first + i) * SSA_STAT_STRIDE, lane);
+                                              p.stats + (e_first + i) * SSA_STAT_STRIDE, lane);      // (straddling tiles: no spos_tiles, see step_launch)
           }
         }
         SSA_TR(9);
@@ -1873,7 +1674,8 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
 }
 
 // folds the SSA_STAT_SHARDS accumulators of the atomics path of env e into stats and clears them (one wavefront)
-SSA_DEV void fold_stat_shards(unsigned long long* __restrict__ shards, double* __restrict__ stats, int e, int lane)
+SSA_DEV void fold_stat_shards(unsigned long long* __restrict__ shards, double* __restrict__ stats, int e, int lane,
+                              const unsigned long long* __restrict__ spos = nullptr, int64_t n_obj = 0)
 {
     static_assert(SSA_STAT_SHARDS == 128, "two shards per lane");
     unsigned long long* sh = shards + ((int64_t)e * SSA_STAT_SHARDS + lane) * SSA_STAT_SHARD_WORDS;
@@ -1902,10 +1704,16 @@ SSA_DEV void fold_stat_shards(unsigned long long* __restrict__ shards, double* _
         o[SSA_STAT_MAX_SPOS] = __builtin_nan("");
         o[6] = 0.0; o[7] = 0.0;
     }
+    if (spos && stats) {     // np.argmax / np.max of sigma_pos from the tiles' slots (a kernel boundary behind their writers)
+        int t_lo, t_hi;
+        env_tile_range(n_obj, e, t_lo, t_hi);
+        fold_spos_tiles<false>(spos, t_lo, t_hi, stats + (int64_t)e * SSA_STAT_STRIDE, lane);
+    }
 }
-__global__ void __launch_bounds__(64) reward_fold_kernel(unsigned long long* __restrict__ shards, double* __restrict__ stats)
+__global__ void __launch_bounds__(64) reward_fold_kernel(unsigned long long* __restrict__ shards, double* __restrict__ stats,
+                                                         const unsigned long long* __restrict__ spos, int64_t n_obj)
 {
-    fold_stat_shards(shards, stats, blockIdx.x, threadIdx.x);
+    fold_stat_shards(shards, stats, blockIdx.x, threadIdx.x, spos, n_obj);
 }
 
 // Workgroup -> tile, XCD-aware.  Workgroups are handed to the eight XCDs round-robin (block b runs on XCD b % 8) and every XCD
@@ -1948,7 +1756,8 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) step_fast_kernel(int ntile
     int lane = threadIdx.x;
     const int unit = (int)blockIdx.x;
     if (unit >= nwork) {   // deferred fold of the previous step's statistics: one extra wavefront per env
-        fold_stat_shards((unsigned long long*)k_arg.p.stat_shards_prev, k_arg.p.stats_prev, unit - nwork, lane);
+        fold_stat_shards((unsigned long long*)k_arg.p.stat_shards_prev, k_arg.p.stats_prev, unit - nwork, lane,
+                         (const unsigned long long*)k_arg.p.spos_tiles_prev, k_arg.p.n_obj);
         return;
     }
     const int64_t total = (int64_t)k_arg.p.n_env * k_arg.p.n_obj;
@@ -2061,6 +1870,7 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) rollout_kernel(const RollK
             pk.upd = (r.upd_ring && kk >= K - H) ? r.upd_ring + so * su : nullptr;
             pk.actions = r.actions + (int64_t)kk * E;
             pk.stat_shards = r.stat_shards + (int64_t)kk * E * SSA_STAT_SHARDS * SSA_STAT_SHARD_WORDS;
+            pk.spos_tiles = r.spos_tiles ? r.spos_tiles + (int64_t)kk * ntiles * 2 : nullptr;
             pk.aer_out = nullptr;
             ActEarly early;
             process_wave<PROP, 2>(t, k.c, pk, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, pf, 0, 0, tile, early);
@@ -2071,12 +1881,14 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) rollout_kernel(const RollK
 // grid (n_steps, n_env): folds step k's shard set into the statistics slot of step k -- when that slot still
 // belongs to step k at the end of the rollout (the last `history` steps) -- and clears it
 __global__ void __launch_bounds__(64) rollout_fold_kernel(unsigned long long* __restrict__ shards, double* __restrict__ stats_ring,
-                                                          int n_env, int n_steps, int slot_out, int history)
+                                                          int n_env, int n_steps, int slot_out, int history,
+                                                          const unsigned long long* __restrict__ spos, int64_t n_obj, int64_t ntiles)
 {
     const int kk = blockIdx.x, e = blockIdx.y;
     const int so = (slot_out + kk) % history;
     double* dst = (kk >= n_steps - history) ? stats_ring + (int64_t)so * n_env * SSA_STAT_STRIDE : nullptr;
-    fold_stat_shards(shards + (int64_t)kk * n_env * SSA_STAT_SHARDS * SSA_STAT_SHARD_WORDS, dst, e, threadIdx.x);
+    fold_stat_shards(shards + (int64_t)kk * n_env * SSA_STAT_SHARDS * SSA_STAT_SHARD_WORDS, dst, e, threadIdx.x,
+                     spos ? spos + (int64_t)kk * ntiles * 2 : nullptr, n_obj);
 }
 
 // Post kernel, grid (nparts, n_env) x 256 threads, launched when a payload or the exact statistics are wanted:
@@ -2233,13 +2045,16 @@ __global__ void propagate_hybrid_kernel(const double* __restrict__ xin, double* 
     double x[6], o[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) x[c] = xin[ii * 6 + c];
-    const bool fast = kepler_hybrid_fast(x, dt, o);
+    bool fast = kepler_hybrid_fast(x, dt, o);
+    if (__any(!fast)) {       // the step kernels' tiers: strong-hyperbolic inline, the rest out of line
+        if (!fast) fast = kepler_conic_lean<0, true>(x, dt, o);
+    }
     if (__any(!fast)) {
         if (!fast) {
             Vec6 si;
 #pragma unroll
             for (int c = 0; c < 6; ++c) si.v[c] = x[c];
-            Vec6 oo = kepler_general_fast_v(si, dt);
+            Vec6 oo = kepler_beyond_series_tagged<0>(si, dt);
 #pragma unroll
             for (int c = 0; c < 6; ++c) o[c] = oo.v[c];
         }
@@ -2292,6 +2107,37 @@ __global__ void cholesky_kernel(const double* __restrict__ A, double* __restrict
 #pragma unroll
         for (int c = 0; c < 6; ++c) U[i * 36 + r * 6 + c] = (c >= r && rg != 16) ? u[tri(r, c)] : 0.0;
     rung[i] = rg;
+}
+// U2 as the fused step kernels run it: one wavefront per four matrices, the row-distributed ladder itself (robust_chol_row_lds) plus,
+// for the record, WHICH rungs factorise in that arithmetic (chol_lane_ok per lane = per rung; bit 16 = the plain attempt).
+__global__ void __launch_bounds__(64) ladder_probe_kernel(const double* __restrict__ A, double scale, int32_t* __restrict__ rung_out,
+                                                          int32_t* __restrict__ mask_out, double* __restrict__ U, int64_t n)
+{
+    __shared__ Tiles t;
+    const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
+    const int64_t base = (int64_t)blockIdx.x * OBJ_PER_WAVE;
+    const int cnt = (int)((n - base) < OBJ_PER_WAVE ? (n - base) : OBJ_PER_WAVE);
+    for (int i = lane; i < OBJ_PER_WAVE * 36; i += 64) {
+        const int gg = i / 36;
+        t.P[i] = (gg < cnt) ? A[base * 36 + i] : ((i % 36) % 7 == 0 ? 1.0 : 0.0);     // (rows beyond n: the identity)
+        t.UA[i] = 0.0;
+    }
+    wave_lds_sync();
+    const int rung = robust_chol_row_lds(t, scale, g, l);
+    wave_lds_sync();
+    const double* Pg = &t.P[g * 36];
+    bool finite = true;
+    for (int i = 0; i < 36; ++i) finite = finite && (fabs(Pg[i]) <= 1.79769313486231570e308);
+    const bool okl = finite && chol_lane_ok(Pg, scale, JITTER[l]);
+    const bool ok0 = finite && chol_lane_ok(Pg, scale, 0.0);
+    const unsigned m16 = (unsigned)((__ballot(okl) >> (g * 16)) & 0xFFFFull);
+    if (g < cnt) {
+        if (l == 0) {
+            rung_out[base + g] = rung;
+            mask_out[base + g] = (int32_t)(m16 | (ok0 ? 0x10000u : 0u));
+        }
+        if (U) for (int i = l; i < 36; i += 16) U[(base + g) * 36 + i] = (rung != 16) ? t.UA[g * 36 + i] : 0.0;
+    }
 }
 __global__ void sigma_points_kernel(const double* __restrict__ x, const double* __restrict__ P, double scale,
                                     double* __restrict__ sig, int32_t* __restrict__ fail, int64_t n)
@@ -2619,60 +2465,52 @@ __global__ void __launch_bounds__(64) agent_final_kernel(const AgentPart* __rest
 // every flag and all wavefronts leave -- the grid drains whatever happens.  Needs every wavefront resident at once (one tile
 // per compute wavefront + the service wavefronts): the launcher checks that against the occupancy the runtime reports and
 // refuses otherwise.
-struct ClPart { double best; long long arg; unsigned long long mx, cnt; };   // cnt: [< 1e4] | [< 1e7] << 21 | [failed] << 42
+// (skey, sarg: the part's first maximum of sigma_pos -- ordered key and object index -- for np.argmax(sigma_pos), the 'shaped' reward;
+// exchanged only with SSA_LOOP_ARGMAX_SPOS (`wide`): two more words per part)
+struct ClPart { double best; long long arg; unsigned long long mx, cnt, skey, sarg; };   // cnt: [< 1e4] | [< 1e7] << 21 | [failed] << 42
+constexpr int CL_PART_WORDS = 8;      // words between parts (64 bytes: six used)
 SSA_DEV void cl_merge(ClPart& a, const ClPart& b)
 {
     agent_merge(a.best, a.arg, b.best, b.arg);
     a.mx = b.mx > a.mx ? b.mx : a.mx;
     a.cnt += b.cnt;
+    if (b.skey > a.skey || (b.skey == a.skey && b.sarg < a.sarg)) { a.skey = b.skey; a.sarg = b.sarg; }
 }
 SSA_DEV ClPart cl_identity()
 {
     ClPart r;
-    r.best = 0.0; r.arg = -1; r.mx = 0ull; r.cnt = 0ull;
+    r.best = 0.0; r.arg = -1; r.mx = 0ull; r.cnt = 0ull; r.skey = 0ull; r.sarg = ~0ull;
     return r;
 }
-SSA_DEV ClPart cl_load(const unsigned long long* w)
+SSA_DEV ClPart cl_load(const unsigned long long* w, bool wide)
 {
     ClPart r;
     r.best = __longlong_as_double((long long)__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     r.arg = (long long)__hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     r.mx = __hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     r.cnt = __hip_atomic_load(w + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r.skey = 0ull; r.sarg = ~0ull;
+    if (wide) {
+        r.skey = __hip_atomic_load(w + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r.sarg = __hip_atomic_load(w + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     return r;
 }
-SSA_DEV void cl_store(unsigned long long* w, const ClPart& v)
+SSA_DEV void cl_store(unsigned long long* w, const ClPart& v, bool wide)
 {
     __hip_atomic_store(w, (unsigned long long)__double_as_longlong(v.best), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(w + 1, (unsigned long long)v.arg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(w + 2, v.mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(w + 3, v.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wide) {
+        __hip_atomic_store(w + 4, v.skey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(w + 5, v.sarg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 // Fold over the 64 lanes, result wave-uniform.  Four DPP rotations leave every row's fold in all of its lanes, four readlanes
 // combine the rows (the ds_bpermute shuffle tree this replaces took ~1.5 us per fold: 48 dependent LDS-crossbar round trips).
 // The agent's "first maximum" (highest score, lowest index among equals, agent_merge) becomes two folds of integers: the
 // score as an order-preserving 64-bit key (0 = no candidate), then the lowest index among the lanes that hold the maximum.
-template <int CTRL>
-SSA_DEV unsigned long long dpp_u64(unsigned long long v)
-{
-    return (unsigned long long)__builtin_amdgcn_update_dpp((long long)v, (long long)v, CTRL, 0xF, 0xF, true);
-}
-SSA_DEV unsigned long long lane_u64(unsigned long long v, int l)
-{
-    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)v, l);
-}
-struct OpMax { SSA_DEV unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a > b ? a : b; } };
-struct OpMin { SSA_DEV unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a < b ? a : b; } };
-struct OpAdd { SSA_DEV unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a + b; } };
-template <class OP>
-SSA_DEV unsigned long long wave_fold_u64(unsigned long long v, OP op)
-{
-    v = op(v, dpp_u64<0x128>(v));   // row_ror:8
-    v = op(v, dpp_u64<0x124>(v));   // row_ror:4
-    v = op(v, dpp_u64<0x122>(v));   // row_ror:2
-    v = op(v, dpp_u64<0x121>(v));   // row_ror:1
-    return op(op(lane_u64(v, 0), lane_u64(v, 16)), op(lane_u64(v, 32), lane_u64(v, 48)));
-}
 SSA_DEV unsigned long long score_key(double v)   // order-preserving; > 0 for every non-NaN double (-0 ranks as +0)
 {
     const unsigned long long b = (unsigned long long)__double_as_longlong(v + 0.0);
@@ -2682,7 +2520,7 @@ SSA_DEV double score_of_key(unsigned long long k)
 {
     return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
 }
-SSA_DEV ClPart cl_wave_reduce(const ClPart& a)
+SSA_DEV ClPart cl_wave_reduce(const ClPart& a, bool wide)
 {
     const unsigned long long key = a.arg >= 0 ? score_key(a.best) : 0ull;
     const unsigned long long top = wave_fold_u64(key, OpMax());
@@ -2693,6 +2531,11 @@ SSA_DEV ClPart cl_wave_reduce(const ClPart& a)
     r.best = top ? score_of_key(top) : 0.0;
     r.mx = wave_fold_u64(a.mx, OpMax());
     r.cnt = wave_fold_u64(a.cnt, OpAdd());
+    r.skey = 0ull; r.sarg = ~0ull;
+    if (wide) {
+        r.skey = wave_fold_u64(a.skey, OpMax());
+        r.sarg = wave_fold_u64((a.skey == r.skey) ? a.sarg : ~0ull, OpMin());
+    }
     return r;
 }
 // own stores acknowledged (visible at agent scope) before what follows
@@ -2710,10 +2553,10 @@ static __host__ __device__ inline ClLayout cl_layout(int nwork)
     L.flags = 0;                                   // [ng] x 16 words: one 128-byte line per group
     L.gcount = (int64_t)L.ng * 16;                 // [ng] x 16: arrivals so far (all steps)
     L.fcount = L.gcount + (int64_t)L.ng * 16;      // x 16: folded groups so far (all steps)
-    L.parts = L.fcount + 16;                       // [2][nwork] x 4
-    L.gparts = L.parts + (int64_t)8 * nwork;       // [2][ng] x 4
-    L.cparts = L.gparts + (int64_t)8 * L.ng;       // [2] x 4: the part of the wavefront that ran the update (straight to the decision)
-    L.total = L.cparts + 8;
+    L.parts = L.fcount + 16;                       // [2][nwork] x CL_PART_WORDS
+    L.gparts = L.parts + (int64_t)2 * CL_PART_WORDS * nwork;       // [2][ng] x CL_PART_WORDS
+    L.cparts = L.gparts + (int64_t)2 * CL_PART_WORDS * L.ng;       // [2] x CL_PART_WORDS: the part of the wavefront that ran the update (straight to the decision)
+    L.total = L.cparts + 2 * CL_PART_WORDS;
     return L;
 }
 
@@ -2764,7 +2607,7 @@ SSA_DEV bool cl_service_wait(const unsigned long long* counter, unsigned long lo
         }
         const unsigned long long f = __hip_atomic_load(ab.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)(lane_u64(f, 0) >> 32) == CL_ABORT_GEN) return false;
-        if (wall_clock64() - t0 > CL_TIMEOUT_TICKS) {
+        if (wall_clock64() - t0 > ab.timeout) {
             ab.abort_all();
             return false;
         }
@@ -2807,10 +2650,12 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) closed_loop_kernel(const L
     asrc.all_flags = ws + L.flags;
     asrc.err = a.c.error;
     asrc.nflags = L.ng;
+    asrc.timeout = a.c.wait_ticks > 0 ? (unsigned long long)a.c.wait_ticks : CL_TIMEOUT_TICKS;
     asrc.aborted = false;
     asrc.last = -1;
     asrc.agent = a.c.agent;
     asrc.vis = vis_row;
+    const bool wide = (a.c.flags & SSA_LOOP_ARGMAX_SPOS) != 0u;      // np.argmax(sigma_pos) travels with the parts
 
     // ---------------- service wavefronts: w in [nwork, nwork + ng) fold one group each, w == nwork + ng decides
     if (w >= nwork) {
@@ -2831,10 +2676,10 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) closed_loop_kernel(const L
                 if (!cl_service_wait(ws + L.gcount + (int64_t)G * 16, target, asrc)) return;
                 const int q = kk & 1;
                 ClPart me = cl_identity();
-                if (lane < gsize && G * 64 + lane != cw) me = cl_load(ws + L.parts + ((int64_t)q * nwork + (int64_t)G * 64 + lane) * 4);
-                const ClPart red = cl_wave_reduce(me);
+                if (lane < gsize && G * 64 + lane != cw) me = cl_load(ws + L.parts + ((int64_t)q * nwork + (int64_t)G * 64 + lane) * CL_PART_WORDS, wide);
+                const ClPart red = cl_wave_reduce(me, wide);
                 if (lane == 0) {
-                    cl_store(ws + L.gparts + ((int64_t)q * L.ng + G) * 4, red);
+                    cl_store(ws + L.gparts + ((int64_t)q * L.ng + G) * CL_PART_WORDS, red, wide);
                     cl_stores_done();
                     __hip_atomic_fetch_add(ws + L.fcount, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -2846,20 +2691,21 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) closed_loop_kernel(const L
             if (!cl_service_wait(ws + L.fcount, (unsigned long long)(kk + 1) * (unsigned long long)(L.ng + 1), asrc)) return;
             const int q = kk & 1;
             ClPart f = cl_identity();
-            if (lane == 63) f = cl_load(ws + L.cparts + (int64_t)q * 4);    // the update's wavefront
+            if (lane == 63) f = cl_load(ws + L.cparts + (int64_t)q * CL_PART_WORDS, wide);    // the update's wavefront
             for (int i0 = 0; i0 < L.ng; i0 += 128) {     // (two loads in flight per lane: 128 groups = 32 768 objects per round)
                 ClPart b0 = cl_identity(), b1 = cl_identity();
-                if (i0 + lane < L.ng) b0 = cl_load(ws + L.gparts + ((int64_t)q * L.ng + i0 + lane) * 4);
-                if (i0 + lane + 64 < L.ng) b1 = cl_load(ws + L.gparts + ((int64_t)q * L.ng + i0 + lane + 64) * 4);
+                if (i0 + lane < L.ng) b0 = cl_load(ws + L.gparts + ((int64_t)q * L.ng + i0 + lane) * CL_PART_WORDS, wide);
+                if (i0 + lane + 64 < L.ng) b1 = cl_load(ws + L.gparts + ((int64_t)q * L.ng + i0 + lane + 64) * CL_PART_WORDS, wide);
                 cl_merge(f, b0);
                 cl_merge(f, b1);
             }
-            f = cl_wave_reduce(f);
+            f = cl_wave_reduce(f, wide);
             const ssa_closed_loop_params& r = a.c;
             const int action = (f.arg >= 0) ? (int)f.arg : (r.fallback ? r.fallback[kk + 1] : -1);   // (wave-uniform)
             const unsigned long long word = ((unsigned long long)(unsigned)(kk + 1) << 32) | (unsigned long long)(unsigned)action;
-            for (int i = lane; i < L.ng; i += 64)
-                __hip_atomic_store(ws + L.flags + (int64_t)i * 16, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(r.flags & SSA_LOOP_DEBUG_WITHHOLD))      // (diagnostic: the decision is never published -> every wait runs into its bound)
+                for (int i = lane; i < L.ng; i += 64)
+                    __hip_atomic_store(ws + L.flags + (int64_t)i * 16, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (lane == 0) {   // (for the host: nobody in the launch reads these)
                 r.actions[kk + 1] = action;
                 if (r.picks) { r.picks[2 * (int64_t)(kk + 1)] = f.arg; r.picks[2 * (int64_t)(kk + 1) + 1] = __double_as_longlong(f.best); }
@@ -2867,9 +2713,9 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) closed_loop_kernel(const L
                 o[SSA_STAT_MAX_DPOS] = __longlong_as_double((long long)f.mx);
                 o[SSA_STAT_CNT_LT_1E4] = (double)(f.cnt & 0x1fffffull);
                 o[SSA_STAT_CNT_LT_1E7] = (double)((f.cnt >> 21) & 0x1fffffull);
-                o[SSA_STAT_ARGMAX_SPOS] = -1.0;
+                o[SSA_STAT_ARGMAX_SPOS] = wide ? (double)(long long)f.sarg : -1.0;
                 o[SSA_STAT_N_FAILED] = (double)(f.cnt >> 42);
-                o[SSA_STAT_MAX_SPOS] = __builtin_nan("");
+                o[SSA_STAT_MAX_SPOS] = wide ? spos_of_key(f.skey) : __builtin_nan("");
                 o[6] = 0.0; o[7] = 0.0;
             }
         }
@@ -3007,6 +2853,7 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) closed_loop_kernel(const L
                     const double dp = t.Met[g * 4 + 0];
                     me.mx = (unsigned long long)__double_as_longlong(dp) & 0x7fffffffffffffffull;   // (ordered bits; NaN on top: np.max)
                     me.cnt = (unsigned long long)(dp < 1e4) | ((unsigned long long)(dp < 1e7) << 21) | ((unsigned long long)(t.St[g] != 0) << 42);
+                    if (wide) { me.skey = spos_key(t.Met[g * 4 + 2]); me.sarg = (unsigned long long)(base + g); }
                 }
                 rowpart[g] = me;
             }
@@ -3023,7 +2870,7 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) closed_loop_kernel(const L
             cl_merge(me, rowpart[2]);
             cl_merge(me, rowpart[3]);
             const bool closer = tile == closer_tile(asrc.last, total);
-            cl_store(closer ? ws + L.cparts + (int64_t)(kk & 1) * 4 : ws + L.parts + ((int64_t)(kk & 1) * nwork + w) * 4, me);
+            cl_store(closer ? ws + L.cparts + (int64_t)(kk & 1) * CL_PART_WORDS : ws + L.parts + ((int64_t)(kk & 1) * nwork + w) * CL_PART_WORDS, me, wide);
             cl_stores_done();
             __hip_atomic_fetch_add(closer ? ws + L.fcount : ws + L.gcount + (int64_t)G * 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (nobody waits for it here)
         }
@@ -3238,6 +3085,8 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
     } else if (!p->actions) return SSA_E_INVALID;
     if ((p->launch_mask & SSA_LAUNCH_FOLD_INSIDE) &&
         (!p->stat_shards || !p->stats || (p->launch_mask & SSA_LAUNCH_DEFER_FOLD))) return SSA_E_INVALID;
+    if (p->spos_tiles && !p->stat_shards) return SSA_E_INVALID;
+    if ((p->spos_tiles || p->spos_tiles_prev) && p->n_env > 1 && (p->n_obj % OBJ_PER_WAVE) != 0) return SSA_E_UNSUPPORTED;   // whole tiles per env
     if (c->obs_type != SSA_OBS_AER && c->obs_type != SSA_OBS_XYZ) return SSA_E_INVALID;
     if (p->aer_cols != 0 && p->aer_cols != 1 && p->aer_cols != 4) return SSA_E_INVALID;
     StepK k;
@@ -3284,7 +3133,8 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
                         // (2 launches), unless deferred (1 launch)
         if ((p->launch_mask & SSA_LAUNCH_FOLD_INSIDE) && per_wave == 1) return launch_status();   // (folded by the step kernel's last wavefronts)
         if ((mask & 6u) && !defer && p->stats)   // (stats NULL: the caller consumes the raw shard words, see stat_shards_clear)
-            hipLaunchKernelGGL(reward_fold_kernel, dim3(p->n_env), dim3(64), 0, s, (unsigned long long*)p->stat_shards, p->stats);
+            hipLaunchKernelGGL(reward_fold_kernel, dim3(p->n_env), dim3(64), 0, s, (unsigned long long*)p->stat_shards, p->stats,
+                               (const unsigned long long*)p->spos_tiles, p->n_obj);
         return launch_status();
     }
     if (mask & 2u) {
@@ -3334,10 +3184,13 @@ int ssa_env_rollout_f64(const ssa_consts* c, const ssa_step_params* p, const ssa
     if (c->propagator == SSA_PROP_J2_RK4 && (c->rk4_substeps < 1 || c->rk4_substeps > 4096)) return SSA_E_INVALID;
     const int64_t total = (int64_t)p->n_env * p->n_obj;
     if (total >= ((int64_t)1 << 31)) return SSA_E_INVALID;
+    if (r->spos_tiles && p->n_env > 1 && (p->n_obj % OBJ_PER_WAVE) != 0) return SSA_E_UNSUPPORTED;
     RollK rk;
     rk.k.c = *c;
     rk.k.p = *p;
     rk.k.p.aer_out = nullptr;
+    rk.k.p.spos_tiles = nullptr;
+    rk.k.p.spos_tiles_prev = nullptr;
     rk.r = *r;
     const int64_t ntiles = (total + OBJ_PER_WAVE - 1) / OBJ_PER_WAVE;
     const int64_t slots = (int64_t)device_cu_count() * 4 * SSA_STEP_WAVES;
@@ -3349,7 +3202,7 @@ int ssa_env_rollout_f64(const ssa_consts* c, const ssa_step_params* p, const ssa
     else if (c->propagator == SSA_PROP_HYBRID) hipLaunchKernelGGL(rollout_kernel<3>, dim3(nwork), dim3(64), 0, s, rk, (int)ntiles, nwork);
     else hipLaunchKernelGGL(rollout_kernel<2>, dim3(nwork), dim3(64), 0, s, rk, (int)ntiles, nwork);
     hipLaunchKernelGGL(rollout_fold_kernel, dim3(r->n_steps, p->n_env), dim3(64), 0, s, (unsigned long long*)r->stat_shards, r->stats_ring,
-                       p->n_env, r->n_steps, r->slot_out, r->history);
+                       p->n_env, r->n_steps, r->slot_out, r->history, (const unsigned long long*)r->spos_tiles, p->n_obj, ntiles);
     return launch_status();
 }
 int64_t ssa_closed_loop_workspace_bytes(int64_t n_obj, int32_t n_env)
@@ -3392,26 +3245,59 @@ int ssa_env_closed_loop_f64(const ssa_consts* c, const ssa_step_params* p, const
     const ClLayout L = cl_layout((int)ntiles);
     if (ntiles + L.ng + 1 > cap) return SSA_E_UNSUPPORTED;   // every wavefront (compute + service) must be resident: the decision is a grid-wide exchange
     if (r->workspace_bytes < L.total * 8) return SSA_E_INVALID;
+    if (r->wait_ticks < 0 || (r->flags & ~(SSA_LOOP_ARGMAX_SPOS | SSA_LOOP_DEBUG_WITHHOLD))) return SSA_E_INVALID;
     LoopK lk;
     lk.k.c = *c;
     lk.k.p = *p;
     lk.k.p.aer_out = nullptr;
+    lk.k.p.spos_tiles = nullptr;
+    lk.k.p.spos_tiles_prev = nullptr;
     lk.c = *r;
     hipStream_t s = (hipStream_t)stream;
     // counters, flags: zero (a memset node: capturable)
     if (hipMemsetAsync(r->workspace, 0, (size_t)L.parts * 8, s) != hipSuccess) return SSA_E_LAUNCH;
-    const int nwork = (int)ntiles;
+    int nwork = (int)ntiles;
     const dim3 grid((unsigned)(nwork + L.ng + 1));
-    if (c->propagator == SSA_PROP_FG) hipLaunchKernelGGL(closed_loop_kernel<1>, grid, dim3(64), 0, s, lk, nwork, nwork);
-    else if (c->propagator == SSA_PROP_ELEMENTS) hipLaunchKernelGGL(closed_loop_kernel<0>, grid, dim3(64), 0, s, lk, nwork, nwork);
-    else if (c->propagator == SSA_PROP_HYBRID) hipLaunchKernelGGL(closed_loop_kernel<3>, grid, dim3(64), 0, s, lk, nwork, nwork);
-    else hipLaunchKernelGGL(closed_loop_kernel<2>, grid, dim3(64), 0, s, lk, nwork, nwork);
+    // A COOPERATIVE launch: the decision is a grid-wide exchange, so every wavefront must be resident at once -- with a cooperative
+    // launch that is the runtime's guarantee (it refuses a grid the device cannot hold next to what else is running), not only this
+    // function's occupancy estimate above.  SSA_LOOP_PLAIN_LAUNCH=1 in the environment: the plain launch of round 3 (diagnostic).
+    static const bool plain = []() { const char* e = getenv("SSA_LOOP_PLAIN_LAUNCH"); return e && e[0] == '1'; }();
+    if (plain) {
+        if (c->propagator == SSA_PROP_FG) hipLaunchKernelGGL(closed_loop_kernel<1>, grid, dim3(64), 0, s, lk, nwork, nwork);
+        else if (c->propagator == SSA_PROP_ELEMENTS) hipLaunchKernelGGL(closed_loop_kernel<0>, grid, dim3(64), 0, s, lk, nwork, nwork);
+        else if (c->propagator == SSA_PROP_HYBRID) hipLaunchKernelGGL(closed_loop_kernel<3>, grid, dim3(64), 0, s, lk, nwork, nwork);
+        else hipLaunchKernelGGL(closed_loop_kernel<2>, grid, dim3(64), 0, s, lk, nwork, nwork);
+        return launch_status();
+    }
+    void* args[3] = {(void*)&lk, (void*)&nwork, (void*)&nwork};
+    const void* fn = (c->propagator == SSA_PROP_FG) ? (const void*)closed_loop_kernel<1>
+                     : (c->propagator == SSA_PROP_ELEMENTS) ? (const void*)closed_loop_kernel<0>
+                     : (c->propagator == SSA_PROP_HYBRID) ? (const void*)closed_loop_kernel<3> : (const void*)closed_loop_kernel<2>;
+    const hipError_t ce = hipLaunchCooperativeKernel(fn, grid, dim3(64), args, 0, s);
+    if (ce == hipErrorCooperativeLaunchTooLarge) {
+        (void)hipGetLastError();
+        return SSA_E_UNSUPPORTED;          // (the device cannot hold the grid right now: the caller takes the per-step launches)
+    }
+    if (ce != hipSuccess) {
+        fprintf(stderr, "libssa_hip: cooperative launch of the closed loop failed: %s (%s)\n", hipGetErrorName(ce), hipGetErrorString(ce));
+        (void)hipGetLastError();
+        return SSA_E_LAUNCH;
+    }
     return launch_status();
 }
 int ssa_stats_fold_f64(uint64_t* stat_shards, double* stats, int32_t n_env, void* stream)
 {
     if (!stat_shards || !stats || n_env <= 0) return SSA_E_INVALID;
-    hipLaunchKernelGGL(reward_fold_kernel, dim3(n_env), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)stat_shards, stats);
+    hipLaunchKernelGGL(reward_fold_kernel, dim3(n_env), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)stat_shards, stats,
+                       (const unsigned long long*)nullptr, (int64_t)0);
+    return launch_status();
+}
+int ssa_stats_fold_spos_f64(uint64_t* stat_shards, const uint64_t* spos_tiles, double* stats, int64_t n_obj, int32_t n_env, void* stream)
+{
+    if (!stat_shards || !stats || n_env <= 0 || n_obj <= 0) return SSA_E_INVALID;
+    if (spos_tiles && n_env > 1 && (n_obj % OBJ_PER_WAVE) != 0) return SSA_E_UNSUPPORTED;
+    hipLaunchKernelGGL(reward_fold_kernel, dim3(n_env), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)stat_shards, stats,
+                       (const unsigned long long*)spos_tiles, n_obj);
     return launch_status();
 }
 int64_t ssa_env_step_work_bytes(int64_t n_obj, int32_t n_env)
@@ -3472,6 +3358,14 @@ int ssa_robust_cholesky6_f64(const double* A, double* U, int32_t* rung, int64_t 
     if (!A || !U || !rung || n < 0) return SSA_E_INVALID;
     if (n == 0) return SSA_OK;
     hipLaunchKernelGGL(cholesky_kernel, dim3(nblk(n, 64)), dim3(64), 0, (hipStream_t)stream, A, U, rung, n);
+    return launch_status();
+}
+
+int ssa_ladder_probe_f64(const double* A, double scale, int32_t* rung, int32_t* mask, double* U, int64_t n, void* stream)
+{
+    if (!A || !rung || !mask || n < 0) return SSA_E_INVALID;
+    if (n == 0) return SSA_OK;
+    hipLaunchKernelGGL(ladder_probe_kernel, dim3(nblk(n, OBJ_PER_WAVE)), dim3(64), 0, (hipStream_t)stream, A, scale, rung, mask, U, n);
     return launch_status();
 }
 

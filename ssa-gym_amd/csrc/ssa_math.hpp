@@ -48,7 +48,8 @@ SSA_DEV double sqrt_fast(double v) { return (v == 0.0) ? 0.0 : v * rsqrt_nr(v); 
 // parts and the fdlibm kernel polynomials on |r| <= pi/4; 1.5 ulp.  Larger arguments (whole-wave branch) go to libm.
 SSA_DEV void sincos_fast(double x, double& so, double& co)
 {
-    if (__all(fabs(x) < 64.0)) {
+    const bool small = fabs(x) < 64.0;
+    {
         const double k = rint(x * 0.63661977236758134308);
         double r = fma(-k, 1.57079632673412561417e+00, x);
         r = fma(-k, 6.07710050650619224932e-11, r);
@@ -71,9 +72,38 @@ SSA_DEV void sincos_fast(double x, double& so, double& co)
         const double a = (n & 1) ? c : s, b = (n & 1) ? s : c;   // quadrant
         so = (n & 2) ? -a : a;
         co = ((n + 1) & 2) ? -b : b;
-    } else {
-        sincos(x, &so, &co);
     }
+    if (!__all(small)) {     // (whole-wave branch; the lanes inside the range keep the result above: lane-local arithmetic)
+        double sl, cl;
+        sincos(x, &sl, &cl);
+        if (!small) { so = sl; co = cl; }
+    }
+}
+// the same for an argument KNOWN to lie inside the range (a wrapped angle, 2 atan(.)): no libm branch at all; NaN in, NaN out
+SSA_DEV void sincos_small(double x, double& so, double& co)
+{
+    const double k = rint(x * 0.63661977236758134308);
+    double r = fma(-k, 1.57079632673412561417e+00, x);
+    r = fma(-k, 6.07710050650619224932e-11, r);
+    const double z = r * r;
+    double ps = 1.58969099521155010221e-10;
+    ps = fma(ps, z, -2.50507602534068634195e-08);
+    ps = fma(ps, z, 2.75573137070700676789e-06);
+    ps = fma(ps, z, -1.98412698298579493134e-04);
+    ps = fma(ps, z, 8.33333333332248946124e-03);
+    ps = fma(ps, z, -1.66666666666666324348e-01);
+    const double s = fma(z * r, ps, r);
+    double pc = -1.13596475577881948265e-11;
+    pc = fma(pc, z, 2.08757232129817482790e-09);
+    pc = fma(pc, z, -2.75573143513906633035e-07);
+    pc = fma(pc, z, 2.48015872894767294178e-05);
+    pc = fma(pc, z, -1.38888888888741095749e-03);
+    pc = fma(pc, z, 4.16666666666666019037e-02);
+    const double c = 1.0 - fma(-z * z, pc, 0.5 * z);
+    const int n = (int)k & 3;
+    const double a = (n & 1) ? c : s, b = (n & 1) ? s : c;   // quadrant
+    so = (n & 2) ? -a : a;
+    co = ((n + 1) & 2) ? -b : b;
 }
 // (s, c) <- (sin, cos)(angle + d), |d| <= 0.02: truncation d^9/9! < 2e-21
 SSA_DEV void rot_small(double d, double& s, double& c)
@@ -360,7 +390,9 @@ SSA_DEV void sinh_coshm1(double x, double& sh, double& chm1)
                (1.0 + x2 * (1.0 / 132.0) * (1.0 + x2 * (1.0 / 182.0) * (1.0 + x2 * (1.0 / 240.0))))))));
     } else {   // one exponential instead of two libm calls: no cancellation for |x| >= 0.5 (cosh x - 1 >= 0.127)
         const double ax = fabs(x);
-        const double ex = (ax < 700.0) ? exp_fast(ax) : exp(ax), ie = rcp_nr(ex);
+        // (beyond 709 the exponential leaves the double range: infinity -- libm's sinh stays finite up to 710.47, a distinction no
+        // state of this path can feel: F = 709 is a hyperbolic anomaly of e^709 radii)
+        const double ex = (ax < 709.0) ? exp_fast(ax) : ((ax == ax) ? __builtin_inf() : ax), ie = rcp_nr(ex);
         const double shp = 0.5 * (ex - ie);
         sh = (x < 0.0) ? -shp : shp;
         chm1 = 0.5 * (ex + ie) - 1.0;

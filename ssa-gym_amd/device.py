@@ -74,6 +74,19 @@ def robust_cholesky(A):
     return U, rung
 
 
+def ladder_probe(A, scale):
+    """U2 as the fused step kernels run it (ssa_ladder_probe_f64): returns (rung[n], mask[n], U[n,6,6]) -- the rung of the kernels' one-pass
+    ladder on scale * A, and which of the sixteen rungs factorise in that arithmetic (bit i; bit 16 = the plain attempt)."""
+    lib = _lib.load()
+    n = A.shape[0]
+    U = torch.empty_like(A)
+    rung = torch.empty(n, dtype=torch.int32, device=A.device)
+    mask = torch.empty(n, dtype=torch.int32, device=A.device)
+    _lib.check(lib.ssa_ladder_probe_f64(_chk(A, "A"), float(scale), _chk(rung, "rung", torch.int32), _chk(mask, "mask", torch.int32),
+                                        _chk(U, "U"), n, _stream()), "ssa_ladder_probe_f64")
+    return rung, mask, U
+
+
 def sigma_points(x, P, scale):
     """U1: returns (sigmas[n,13,6], fail[n])."""
     lib = _lib.load()

@@ -84,6 +84,11 @@ class HotPathEngine:
         self._shard_cur = 0
         self._fold_pending = None      # (shard set index, stats destination) of a step whose fold was deferred
         self._shard_ptr = [self._shard_sets[0].data_ptr(), self._shard_sets[1].data_ptr()]
+        # arg-max slots of sigma_pos (ssa_step_params.spos_tiles: the 'shaped' reward on the one-launch paths), one set per shard set;
+        # the step kernel needs whole tiles per env for them
+        self.ntiles = (N + 3) // 4
+        self.supports_argmax = self.E == 1 or self.m % 4 == 0
+        self._spos_sets = None
         self._actions_ptr = self.actions.data_ptr()
         self._pcache = {}
         self._cref = C.byref(self.consts)
@@ -137,12 +142,27 @@ class HotPathEngine:
         self.stats[slot].copy_(st)
         self.status.zero_()
 
+    def snapshot_state(self, slot):
+        """a history slot AND the per-object status words: what a launch that may have to be undone (the persistent closed loop
+        when it gives up) restores"""
+        return self.snapshot(slot) + (self.status.clone(),)
+
+    def restore_state(self, slot, snap):
+        self.restore(slot, snap[:6])
+        self.status.copy_(snap[6])
+
     # ------------------------------------------------------------------ one step
-    def _step_params(self, slot_in, slot_out, aer_out, stats_out, upd_out, shard_set, shards_out=0, shards_clear=0, aer_cols=4, obs_mirror=0):
+    def _spos_ptr(self, k):
+        if self._spos_sets is None:
+            self._spos_sets = torch.zeros((2, self.ntiles, 2), dtype=torch.int64, device=self.dev)
+        return self._spos_sets[k].data_ptr()
+
+    def _step_params(self, slot_in, slot_out, aer_out, stats_out, upd_out, shard_set, shards_out=0, shards_clear=0, aer_cols=4, obs_mirror=0,
+                     argmax=False):
         """parameter block of a step between two history slots: everything but the time index, the action pointer and the
         deferred-fold hand-over is fixed per (slot pair, outputs, shard set), so the blocks are built once and cached -- a
         step then costs a handful of field stores on the host instead of twenty"""
-        key = (slot_in, slot_out, aer_out, stats_out, upd_out, shard_set, shards_out, shards_clear, aer_cols, obs_mirror)
+        key = (slot_in, slot_out, aer_out, stats_out, upd_out, shard_set, shards_out, shards_clear, aer_cols, obs_mirror, argmax)
         ent = self._pcache.get(key)
         if ent is None:
             p = _lib.ssa_step_params()
@@ -158,6 +178,8 @@ class HotPathEngine:
             p.stat_shards = self._shard_sets[shard_set].data_ptr() if shard_set >= 0 else 0
             p.stat_shards_prev, p.stats_prev, p.launch_mask = 0, 0, 0
             p.stat_shards_clear = 0
+            p.spos_tiles = self._spos_ptr(shard_set) if (argmax and shard_set >= 0) else 0
+            p.spos_tiles_prev = 0
             p.aer_cols = int(aer_cols)
             p.obs_mirror = obs_mirror
             if shards_out:      # raw-shard consumer (include/ssa_hip.h: stat_shards_clear): no fold, no `stats`
@@ -170,21 +192,26 @@ class HotPathEngine:
 
     def launch_step(self, slot_in, slot_out, time_offset, actions_ptr=None, stream=None, aer_out=0, stats_out=0, upd_out=0,
                     fast_stats=False, defer_fold=False, profile_slot=None, shards_out=0, shards_clear=0, aer_cols=4, action=None,
-                    obs_mirror=0, fold_inside=False, env_words=None):
+                    obs_mirror=0, fold_inside=False, env_words=None, argmax_spos=False):
         """enqueue the step; asynchronous, no host sync.  fast_stats: statistics by the step kernel's atomics (two
         launches, no arg-max of sigma_pos).  defer_fold (with fast_stats): ONE launch -- this step's
         statistics are folded by extra wavefronts of the NEXT deferred step, or by flush_stats().  action (one env): the
         action by value in the parameter block (SSA_LAUNCH_INLINE_ACTION) instead of a word in memory; obs_mirror: a second
         destination of the observation rows (host-mapped pinned memory: the observation reaches the host from inside the kernel).
-        env_words = (time indices, actions) of all envs (n_env <= 8) by value in the parameter block (SSA_LAUNCH_INLINE_ENVS)."""
+        env_words = (time indices, actions) of all envs (n_env <= 8) by value in the parameter block (SSA_LAUNCH_INLINE_ENVS).
+        argmax_spos (with fast_stats): np.argmax / np.max of sigma_pos in the step's statistics on the one-launch paths as well
+        (ssa_step_params.spos_tiles; the 'shaped' reward) -- needs self.supports_argmax."""
         s = torch.cuda.current_stream().cuda_stream if stream is None else stream
         if shards_out:
             fast_stats, defer_fold = True, False
         defer = bool(defer_fold and fast_stats)
         if not defer and self._fold_pending is not None:
             self.flush_stats(s)       # a deferred step is followed by an immediate one: fold it first (same stream, in order)
+        argmax = bool(argmax_spos and fast_stats and not shards_out)
+        if argmax and not self.supports_argmax:
+            raise _lib.SsaHipError("argmax_spos on the one-launch paths needs whole tiles per env (n_env == 1 or n_obj % 4 == 0)")
         p, pref, stats_ptr = self._step_params(slot_in, slot_out, aer_out, stats_out, upd_out, self._shard_cur if fast_stats else -1,
-                                               shards_out, shards_clear, aer_cols, obs_mirror)
+                                               shards_out, shards_clear, aer_cols, obs_mirror, argmax)
         p.time_offset = int(time_offset)
         p.actions = self._actions_ptr if actions_ptr is None else actions_ptr
         inline = 0
@@ -202,9 +229,10 @@ class HotPathEngine:
             p.launch_mask = _lib.LAUNCH_DEFER_FOLD | inline
             p.stat_shards_prev = self._shard_ptr[self._fold_pending[0]]
             p.stats_prev = self._fold_pending[1]
+            p.spos_tiles_prev = self._spos_ptr(self._fold_pending[0]) if self._fold_pending[2] else 0
         else:
             p.launch_mask = (_lib.LAUNCH_DEFER_FOLD if defer else 0) | inline
-            p.stat_shards_prev, p.stats_prev = 0, 0
+            p.stat_shards_prev, p.stats_prev, p.spos_tiles_prev = 0, 0, 0
         if profile_slot is None:
             rc = self._lib.ssa_env_step_f64(self._cref, pref, s)
         else:   # the dominant launch bracketed by event pair `profile_slot` (read back with profile_ms)
@@ -212,10 +240,10 @@ class HotPathEngine:
         if rc:
             raise _lib.SsaHipError("ssa_env_step_f64 failed with code %d" % rc)
         if defer:
-            self._fold_pending = (self._shard_cur, stats_ptr)
+            self._fold_pending = (self._shard_cur, stats_ptr, argmax)
             self._shard_cur ^= 1
 
-    def launch_rollout(self, slot_in, time_offset, actions, stream=None):
+    def launch_rollout(self, slot_in, time_offset, actions, stream=None, argmax_spos=False):
         """K = actions.shape[0] consecutive steps in one launch (include/ssa_hip.h: ssa_env_rollout_f64): step k reads
         history slot (slot_in + k) % H, writes (slot_in + k + 1) % H and has time index time_offset + k.  `actions`
         is a device int32 tensor [K][E] (open-loop schedule).  Statistics: the last min(K, H) steps' slots."""
@@ -232,21 +260,33 @@ class HotPathEngine:
         r.x_true_ring, r.x_ring, r.P_ring = self._bx_t, self._bx, self._bP
         r.obs_ring, r.metrics_ring, r.upd_ring, r.stats_ring = self._bo, self._bm, self._bu, self._bs
         r.actions, r.stat_shards = actions.data_ptr(), self._roll_shards.data_ptr()
+        r.spos_tiles = 0
+        if argmax_spos:     # per-step arg-max slots: every step's statistics carry np.argmax(sigma_pos) (the 'shaped' reward)
+            if not self.supports_argmax:
+                raise _lib.SsaHipError("argmax_spos needs whole tiles per env (n_env == 1 or n_obj % 4 == 0)")
+            if getattr(self, "_roll_spos", None) is None or self._roll_spos.shape[0] < K:
+                self._roll_spos = torch.zeros((K, self.ntiles, 2), dtype=torch.int64, device=self.dev)
+            r.spos_tiles = self._roll_spos.data_ptr()
         p = self._p
         p.time_offset = int(time_offset)
         p.launch_mask, p.stat_shards_prev, p.stats_prev, p.aer_out = 0, 0, 0, 0
+        p.spos_tiles, p.spos_tiles_prev = 0, 0
         rc = self._lib.ssa_env_rollout_f64(self._cref, self._pref, C.byref(r), s)
         if rc:
             raise _lib.SsaHipError("ssa_env_rollout_f64 failed with code %d" % rc)
 
-    def launch_closed_loop(self, slot_in, time_offset, kind, actions, stats_out, upd_out=None, fallback=None, picks=None, stream=None):
+    def launch_closed_loop(self, slot_in, time_offset, kind, actions, stats_out, upd_out=None, fallback=None, picks=None, stream=None,
+                           argmax_spos=False, wait_ticks=0, debug_withhold=False):
         """K steps AND the K decisions of a greedy agent in ONE persistent launch (include/ssa_hip.h:
         ssa_env_closed_loop_f64).  `actions`: device int32 [K + 1], actions[0] = the first step's action (given), the kernel
         writes actions[1..K]; `stats_out` device float64 [K][STAT_STRIDE]; `upd_out` [K][UPD_STRIDE] or None; `fallback`
         int32 [K + 1] or None; `picks` int64 [K + 1][2] or None.  Step k reads history slot (slot_in + k) % H and writes
         (slot_in + k + 1) % H with time index time_offset + k.  Returns False -- nothing enqueued -- when the library
         declines the configuration (several envs, or more objects than resident wavefronts x 4): the caller then issues
-        the per-step launches.  self.loop_error (host-mapped int32) turns 1 if the launch gave up on a timeout."""
+        the per-step launches.  self.loop_error (host-mapped int32, cleared before every launch) turns 1 if the launch gave up:
+        a wavefront waited longer than `wait_ticks` (100 MHz ticks; 0 = 2 s) for a decision.  argmax_spos: the statistics carry
+        np.argmax(sigma_pos) (SSA_LOOP_ARGMAX_SPOS).  debug_withhold: diagnostic -- the decision is never published (the test of
+        the give-up path)."""
         if self.E != 1:
             return False
         K = int(actions.numel()) - 1
@@ -268,6 +308,7 @@ class HotPathEngine:
             self.loop_error = self._loop_err_host.numpy()
         s = torch.cuda.current_stream().cuda_stream if stream is None else stream
         self.flush_stats(s)
+        self.loop_error[0] = 0      # (a launch that gave up must not poison the next one: nothing is in flight here, run_agent synchronises)
         r = _lib.ssa_closed_loop_params()
         r.n_steps, r.history, r.slot_out, r.agent = K, self.H, (int(slot_in) + 1) % self.H, int(kind)
         r.x_true_ring, r.x_ring, r.P_ring = self._bx_t, self._bx, self._bP
@@ -278,9 +319,12 @@ class HotPathEngine:
         r.picks = picks.data_ptr() if picks is not None else 0
         r.error = self._loop_err_host.data_ptr()
         r.workspace, r.workspace_bytes = self._loop_ws.data_ptr(), self._loop_ws.numel() * 8
+        r.wait_ticks = int(wait_ticks)
+        r.flags = (_lib.LOOP_ARGMAX_SPOS if argmax_spos else 0) | (_lib.LOOP_DEBUG_WITHHOLD if debug_withhold else 0)
         p = self._p
         p.time_offset = int(time_offset)
         p.launch_mask, p.stat_shards_prev, p.stats_prev, p.aer_out = 0, 0, 0, 0
+        p.spos_tiles, p.spos_tiles_prev = 0, 0
         rc = self._lib.ssa_env_closed_loop_f64(self._cref, self._pref, C.byref(r), s)
         if rc == _lib.E_UNSUPPORTED:
             return False
@@ -318,11 +362,11 @@ class HotPathEngine:
         if self._fold_pending is None:
             return
         s = torch.cuda.current_stream().cuda_stream if stream is None else stream
-        k, dst = self._fold_pending
-        rc = self._lib.ssa_stats_fold_f64(self._shard_sets[k].data_ptr(), dst, self.E, s)
+        k, dst, argmax = self._fold_pending
+        rc = self._lib.ssa_stats_fold_spos_f64(self._shard_sets[k].data_ptr(), self._spos_ptr(k) if argmax else 0, dst, self.m, self.E, s)
         self._fold_pending = None
         if rc:
-            raise _lib.SsaHipError("ssa_stats_fold_f64 failed with code %d" % rc)
+            raise _lib.SsaHipError("ssa_stats_fold_spos_f64 failed with code %d" % rc)
 
     def set_actions(self, actions):
         a = torch.as_tensor(np.asarray(actions, dtype=np.int32).reshape(self.E))

@@ -43,8 +43,8 @@ def resolve_perturbation(config):
 def kernel_consts(config, Q, R, dt, obs_limit_rad, obs_lla):
     """(ssa_consts, measurement model) for a config dict: the ONE place where SSA_Tasker_Env and SSA_Tasker_VecEnv turn the
     operator tokens and the optional keys `propagator`, `resample_sigmas`, `covariance_form` ('reference' | 'centred';
-    default: 'reference' with the 'elements' propagator -- the behaviour-faithful variant -- else 'centred'), `ad` /
-    `ad_kwargs` into kernel constants."""
+    default: 'reference' with the 'hybrid' and 'elements' propagators -- the behaviour-faithful variants -- else 'centred'),
+    `ad` / `ad_kwargs` into kernel constants."""
     from .. import host
     model, propagator = resolve_kernel_variant(config)
     kw = {}

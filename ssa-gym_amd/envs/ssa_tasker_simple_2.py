@@ -182,6 +182,14 @@ class SSA_Tasker_Env(Env):
         self._engine = None
         self._device_rng = bool(config.get('device_rng', False))
         self._obs_buffers = config.get('obs_buffers', 2)
+        # step() hands out a FRESH array per call for the 'flatten' and (m, 12) observations, as the reference does (:360-366: `.flatten()` /
+        # a row of the history that no later step overwrites) -- a consumer may keep it as long as it likes (replay buffers, sample
+        # collectors, GAE targets).  config['obs_zero_copy'] = True (opt-in): a VIEW of the host-mapped ring the kernel writes, valid until
+        # `obs_buffers` (default 2) further steps have been taken -- no 1.9 MB host copy per step at 20 000 objects
+        self._obs_zero_copy = bool(config.get('obs_zero_copy', False))
+        # the persistent closed loop's bound on any wait inside the launch (100 MHz ticks; 0 = the library's 2 s)
+        self._loop_wait_ticks = int(config.get('closed_loop_wait_ticks', 0))
+        self._loop_debug_withhold = False
         # config['obs_device'] = True (opt-in, for policies that live on the GPU): step() returns the observation as a CUDA tensor
         # -- a view of the device-resident history slot ('aer': of the persistent (4 m,) block) -- and nothing crosses PCIe
         self._obs_device = bool(config.get('obs_device', False))
@@ -214,8 +222,9 @@ class SSA_Tasker_Env(Env):
         # ('aer') or a second copy of the observation rows (other modes) straight into host-mapped pinned memory, overlapped
         # with the other wavefronts' arithmetic -- no copy-engine pass behind the kernel (1.92 MB 'flatten' vector: 44 us).
         # 'aer' hands out ONE persistent array refreshed in place, as the reference does (:362-363); the other modes alternate
-        # between TWO pinned arrays, so the observation returned by step i stays intact until step i + 2 is taken (the reference
-        # returns a fresh copy per step; copy it if you keep it longer).  config['obs_buffers'] = k >= 2 deepens that ring.
+        # between TWO pinned arrays the kernel writes, and step() returns a COPY of the current one (the reference returns a fresh
+        # array per step) unless config['obs_zero_copy'] asks for the view itself, which stays intact until step i + 2 is taken
+        # (config['obs_buffers'] = k >= 2 deepens that ring).
         aer = self.obs_returned == 'aer'
         nobs = self.m * (4 if aer else 12)
         nbuf = 1 if aer else max(2, int(self._obs_buffers))
@@ -316,16 +325,17 @@ class SSA_Tasker_Env(Env):
         #                                        and every step ends with a synchronisation, so later work in any stream sees its results)
         aer = self.obs_returned == 'aer'
         k = 0 if aer else i % len(self._obs_ring)
+        shaped = self.reward_type == 'shaped'      # needs np.argmax(sigma_pos[i - 1]) (:346): the arg-max slots of the one-launch path
         if self._obs_device:
             e.launch_step((i - 1) % e.H, i % e.H, i, action=int(a), aer_out=self._aer_dev.data_ptr() if aer else 0,
                           stats_out=self._stats_ptr, upd_out=self._upd_ptr, stream=cur.cuda_stream,
-                          fast_stats=(self.reward_type != 'shaped'), fold_inside=True)
+                          fast_stats=True, fold_inside=True, argmax_spos=shaped)
             obs_np = self._aer_dev if aer else (e.obs[i % e.H].reshape(-1) if self.obs_returned == 'flatten' else e.obs[i % e.H])
         else:
             e.launch_step((i - 1) % e.H, i % e.H, i, action=int(a),
                           aer_out=self._obs_ring_ptr[0] if aer else 0, obs_mirror=0 if aer else self._obs_ring_ptr[k],
                           stats_out=self._stats_ptr, upd_out=self._upd_ptr, stream=cur.cuda_stream,
-                          fast_stats=(self.reward_type != 'shaped'), fold_inside=True)   # only 'shaped' needs argmax(sigma_pos) (:346)
+                          fast_stats=True, fold_inside=True, argmax_spos=shaped)
             obs_np = self._obs_ring_np[k]
         cur.synchronize()
         rec = self._upd_np
@@ -340,7 +350,9 @@ class SSA_Tasker_Env(Env):
         done = self._reward_done(i, a, self._stats, self._argmax_sigma_prev)
         if i + 1 >= self.n:
             done = True
-        obs = obs_np
+        # 'aer' hands out its ONE persistent array refreshed in place, as the reference does (:362-363: self.observation); the other
+        # modes a fresh copy unless config['obs_zero_copy']
+        obs = obs_np if (aer or self._obs_device or self._obs_zero_copy) else obs_np.copy()
         e_t = time.time()
         self.runtime['Observations and Reward'] += e_t - t_dev
         self.runtime['step'] += e_t - step_s
@@ -394,11 +406,10 @@ class SSA_Tasker_Env(Env):
         calls would -- the loop of the reference's agent_naive_random / round-robin drivers (agents.py,
         tests.py:584-603) -- with up to H-1 steps per kernel launch (ssa_env_rollout_f64: state resident on
         chip across the steps, results bit-identical to step()).  Stops at the first `done`.  Returns
-        (observation after the last executed step, rewards[k], dones[k], info).  Rewards 'jones' and
-        'trinary' (the 'shaped' reward needs the arg-max of sigma_pos of every step: use step())."""
+        (observation after the last executed step, rewards[k], dones[k], info).  Every reward type ('shaped': the arg-max of
+        sigma_pos of every step comes from the rollout's arg-max slots, ssa_rollout_params.spos_tiles)."""
         import torch
-        if self.reward_type == 'shaped':
-            raise NotImplementedError("rollout: reward_type 'shaped' needs argmax(sigma_pos) per step; use step()")
+        shaped = self.reward_type == 'shaped'     # (np.argmax(sigma_pos) of every step from the arg-max slots of the rollout)
         actions = np.asarray(actions, dtype=np.int64).ravel()
         for a in actions:
             assert self.action_space.contains(int(a)), "%r invalid" % (a,)
@@ -410,7 +421,7 @@ class SSA_Tasker_Env(Env):
             kk = min(K - pos, e.H - 1)
             i0 = self.i
             act = torch.as_tensor(actions[pos:pos + kk].astype(np.int32)).view(kk, 1).to(e.dev)
-            e.launch_rollout(i0 % e.H, i0 + 1, act)
+            e.launch_rollout(i0 % e.H, i0 + 1, act, argmax_spos=shaped)
             slots = [(i0 + 1 + k) % e.H for k in range(kk)]
             stats = e.stats[slots, 0].cpu().numpy()          # synchronises the stream
             upd = e.upd[slots, 0].cpu().numpy()
@@ -422,14 +433,14 @@ class SSA_Tasker_Env(Env):
                 self._stats = stats[k]
                 if int(stats[k][_lib.STAT_N_FAILED]) != self._n_failed:
                     self._record_failures(at_step=i)
-                done = self._reward_done(i, a, stats[k], -1) or (i + 1 >= self.n)
+                done = self._reward_done(i, a, stats[k], self._argmax_sigma) or (i + 1 >= self.n)
+                self._argmax_sigma = int(stats[k][_lib.STAT_ARGMAX_SPOS])      # (-1 unless 'shaped' asked for it)
                 r = self.rewards[i]
                 rewards.append(r if (self.obs_returned == 'flatten' or np.isfinite(r)) else np.float64(0.5))
                 dones.append(done)
                 if done:
                     break
             pos += kk
-        self._argmax_sigma = -1
         slot = self.i % e.H
         if self.obs_returned == 'aer':
             from .. import device
@@ -455,13 +466,14 @@ class SSA_Tasker_Env(Env):
         in-stream -- no host round trip per step.  `fallback_actions[k]` replaces the reference's action_space.sample()
         when no object is visible at decision k (default: draws from the env's action space, as the reference does).
         Stops at the first `done`.  Returns (observation after the last executed step, actions[k], rewards[k], dones[k]).
-        Rewards 'jones' and 'trinary' (as rollout())."""
+        Every reward type.  If the persistent launch gives up (a wavefront waited longer than config['closed_loop_wait_ticks'] for a
+        decision: something else holds the GPU's wavefront slots) the env restores the state the chunk started from, takes the
+        per-step launches for this and every later call, and warns once."""
         import torch
         name = agent if isinstance(agent, str) else getattr(agent, "__name__", None)
         if name not in self.AGENT_KINDS:
             raise NotImplementedError("run_agent: %r has no device-side version (supported: %s)" % (agent, sorted(self.AGENT_KINDS)))
-        if self.reward_type == 'shaped':
-            raise NotImplementedError("run_agent: reward_type 'shaped' needs argmax(sigma_pos) per step; use step()")
+        shaped = self.reward_type == 'shaped'     # (np.argmax(sigma_pos) of every step travels with the decision / the arg-max slots)
         kind = self.AGENT_KINDS[name]
         e = self._engine
         K = min(int(n_steps), self.n - 1 - self.i)
@@ -487,19 +499,35 @@ class SSA_Tasker_Env(Env):
                 # ONE launch for the kk steps and their kk decisions (ssa_env_closed_loop_f64)
                 stats_d = torch.empty((kk, _lib.STAT_STRIDE), dtype=torch.float64, device=e.dev)
                 upd_d = torch.empty((kk, _lib.UPD_STRIDE), dtype=torch.float64, device=e.dev)
-                used = e.launch_closed_loop(i0 % e.H, i0 + 1, kind, log[pos:pos + kk + 1], stats_d, upd_d, fallback=fb[pos:pos + kk + 1])
+                snap = e.snapshot_state(i0 % e.H)      # (what a launch that gives up is undone to: ~9 MB device-to-device at 20 000 objects)
+                first = log[pos:pos + 1].clone()
+                used = e.launch_closed_loop(i0 % e.H, i0 + 1, kind, log[pos:pos + kk + 1], stats_d, upd_d, fallback=fb[pos:pos + kk + 1],
+                                            argmax_spos=shaped, wait_ticks=self._loop_wait_ticks, debug_withhold=self._loop_debug_withhold)
                 if used:
                     stats = stats_d.cpu().numpy()                      # synchronises the stream
                     upd = upd_d.cpu().numpy()
                     if int(e.loop_error[0]) != 0:
-                        raise _lib.SsaHipError("ssa_env_closed_loop_f64: a wavefront timed out waiting for a decision (launch abandoned)")
-                else:
+                        # the launch gave up (every wait inside it is bounded): the rings hold a partial chunk.  Back to the state the
+                        # chunk started from, and per-step launches from here on -- for this env: whatever took the wavefront slots
+                        # (another stream's kernels, another process on the card) may well stay
+                        import warnings
+                        warnings.warn("ssa_env_closed_loop_f64 gave up (a wavefront waited longer than the bound for a decision); "
+                                      "the chunk is re-run with per-step launches, which this env uses from now on", RuntimeWarning)
+                        e.restore_state(i0 % e.H, snap)
+                        log[pos:pos + 1].copy_(first)
+                        log[pos + 1:pos + kk + 1].fill_(-1)
+                        self.loop_gave_up = getattr(self, "loop_gave_up", 0) + 1
+                        self._closed_loop_persistent = False
+                        used = False
+                if not used:
                     persistent = False
                     kk = min(kk, e.H - 1)
+                del snap
             if not used:
                 for k in range(kk):
                     i = i0 + k + 1
-                    e.launch_step((i - 1) % e.H, i % e.H, i, actions_ptr=log.data_ptr() + 4 * (pos + k), fast_stats=True, defer_fold=True)
+                    e.launch_step((i - 1) % e.H, i % e.H, i, actions_ptr=log.data_ptr() + 4 * (pos + k), fast_stats=True, defer_fold=True,
+                                  argmax_spos=shaped)
                     if pos + k + 1 < K:     # (the decision for the step after this one)
                         e.launch_agent_select(i, i, kind, log.data_ptr() + 4 * (pos + k + 1), fallback_ptr=fb.data_ptr() + 4 * (pos + k + 1))
                 e.flush_stats()
@@ -515,7 +543,8 @@ class SSA_Tasker_Env(Env):
                 self._stats = stats[k]
                 if int(stats[k][_lib.STAT_N_FAILED]) != self._n_failed:
                     self._record_failures(at_step=i)
-                done = self._reward_done(i, a, stats[k], -1) or (i + 1 >= self.n)
+                done = self._reward_done(i, a, stats[k], self._argmax_sigma) or (i + 1 >= self.n)
+                self._argmax_sigma = int(stats[k][_lib.STAT_ARGMAX_SPOS])
                 r = self.rewards[i]
                 actions.append(a)
                 rewards.append(r if (self.obs_returned == 'flatten' or np.isfinite(r)) else np.float64(0.5))
@@ -523,7 +552,6 @@ class SSA_Tasker_Env(Env):
                 if done:
                     break
             pos += kk
-        self._argmax_sigma = -1
         slot = self.i % e.H
         if self.obs_returned == 'aer':
             from .. import device
@@ -542,8 +570,18 @@ class SSA_Tasker_Env(Env):
         """what a device-side policy sees at decision time: CUDA tensors of the env's CURRENT state (views of the history slot --
         valid until the next step is launched; nothing is copied, nothing crosses PCIe)."""
 
-        def __init__(self, env, i):
+        def __init__(self, env, i, tix_dev=None):
             self.env, self.i = env, i
+            # inside a captured graph the step's time index lives on the DEVICE (the graph advances it between replays): the GCRS -> ITRS
+            # matrix of the decision is then gathered by it instead of being picked by a host integer that a capture would freeze
+            self._tix_dev = tix_dev
+
+        def _M(self):
+            e = self.env._engine
+            if self._tix_dev is None:
+                return e.trans[self.i % e.n_time].reshape(3, 3)
+            import torch
+            return torch.index_select(e.trans, 0, torch.remainder(self._tix_dev, e.n_time)).reshape(3, 3)
 
         # (views are formed on access: a tensor slice costs the host 1-2 us, and most policies read one or two of them)
         obs = property(lambda s: s.env._engine.obs[s.i % s.env._engine.H])            # [m, 12]: x_filter | diag P   (results.py:61)
@@ -555,14 +593,75 @@ class SSA_Tasker_Env(Env):
         def visible(self):
             """uint8 CUDA mask [m]: object_visibility() of the true states (ssa_tasker_simple_2.py:427-434)"""
             from .. import device
-            e = self.env._engine
-            return device.visible_mask(self.x_true, e.trans[self.i % e.n_time].reshape(3, 3), self.env._consts)
+            return device.visible_mask(self.x_true, self._M(), self.env._consts)
 
         def scores(self):
             """(scores[4, m], mask[m]) of the reference's heuristic agents (trace P, visible, log-det ratio, delta_pos)"""
-            return self.env.agent_scores()
+            from .. import device
+            return device.agent_scores(self.x_true, self.x_filter, self.P_filter, self.P_filter_prev, self._M(), self.env._consts)
 
-    def run_policy(self, policy, n_steps):
+    # ---- run_policy as a replayed hipGraph: K x [the policy's kernels + the step launch] captured once, replayed per chunk
+    GRAPH_CHUNK = 32
+
+    def _policy_graph(self, policy, K, i0):
+        """capture (once per policy / chunk length / history phase) K steps of the closed loop -- for every step the policy's own kernels on
+        the current history slot, then the step launch reading the action word the policy produced -- into ONE hipGraph.  What changes
+        from replay to replay lives in device memory: the time index (engine.env_time0, advanced by K at the graph's end; the steps
+        read env_time0 + their position), the history slots by parity (K is a multiple of the ring depth).  Returns the cache entry
+        or None when the policy cannot be captured (it synchronises, allocates outside the graph's pool, ...): the caller enqueues
+        eagerly."""
+        import torch
+        e = self._engine
+        key = (id(policy), K, i0 % e.H)
+        ent = self._policy_graphs.get(key)
+        if ent is not None or key in self._policy_graphs:
+            return ent
+        stats_d = torch.zeros((K, _lib.STAT_STRIDE), dtype=torch.float64, device=e.dev)
+        upd_d = torch.zeros((K, _lib.UPD_STRIDE), dtype=torch.float64, device=e.dev)
+        acts_d = torch.full((K,), -1, dtype=torch.int32, device=e.dev)
+        shaped = self.reward_type == 'shaped'
+
+        def enqueue():
+            base = e.env_time0.to(torch.int64)
+            for k in range(K):
+                i = i0 + k + 1
+                a = policy(self.PolicyView(self, i - 1, tix_dev=base + k))
+                if not (isinstance(a, torch.Tensor) and a.is_cuda and a.dtype == torch.int32 and a.numel() == 1):
+                    raise TypeError("run_policy: the policy must return a CUDA int32 tensor with one element (the action)")
+                acts_d[k:k + 1].copy_(a.reshape(1))
+                e.launch_step((i - 1) % e.H, i % e.H, k + 1, actions_ptr=acts_d.data_ptr() + 4 * k, fast_stats=True, defer_fold=True,
+                              stats_out=stats_d[k].data_ptr(), upd_out=upd_d[k].data_ptr(), argmax_spos=shaped)
+            e.flush_stats()
+            e.env_time0.add_(K)
+        stream = torch.cuda.Stream(device=e.dev)
+        g = torch.cuda.CUDAGraph()
+        ok = True
+        try:
+            policy(self.PolicyView(self, i0))      # (eagerly once, result unused: lazy initialisation must not happen inside the capture)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(stream):
+                g.capture_begin(capture_error_mode="thread_local")
+                try:
+                    enqueue()
+                    g.capture_end()
+                except BaseException:
+                    try:
+                        g.capture_end()
+                    except Exception:  # noqa: BLE001
+                        pass
+                    raise
+        except TypeError:
+            raise
+        except Exception as exc:  # noqa: BLE001  (not capture-safe: remembered, the eager loop takes over)
+            ok = False
+            self.policy_graph_error = repr(exc)
+            e._fold_pending = None
+        torch.cuda.current_stream().wait_stream(stream)
+        ent = (g, stats_d, upd_d, acts_d, stream) if ok else None
+        self._policy_graphs[key] = ent
+        return ent
+
+    def run_policy(self, policy, n_steps, graph='auto'):
         """Closed loop with an ARBITRARY policy evaluated on the GPU (a torch module, a hand-written rule):
             a = policy(view)          # view: SSA_Tasker_Env.PolicyView -- CUDA tensors; returns an int32 CUDA tensor [1]
             step(a)
@@ -570,16 +669,56 @@ class SSA_Tasker_Env(Env):
         tensor the policy returned), the statistics and update records go to device rings, ONE synchronisation at the end, then the
         env's bookkeeping (actions, rewards, dones, failures, z_true / y / S records) is filled in as step() would have.  The
         reference's loop `a = agent(obs, env); env.step(a)` (run_environment.py:26-29) for agents that are not one of the built-in
-        greedy ones (those: run_agent, one persistent launch).  Rewards 'jones' and 'trinary'; a data-dependent `done` ('jones') is
+        greedy ones (those: run_agent, one persistent launch).  Every reward type; a data-dependent `done` ('jones', 'shaped') is
         honoured at the bookkeeping -- the steps launched behind it are discarded (chunks of history - 1 steps, as run_agent).
         Returns (actions[k], rewards[k], dones[k])."""
         import torch
-        if self.reward_type == 'shaped':
-            raise NotImplementedError("run_policy: reward_type 'shaped' needs argmax(sigma_pos) per step; use step()")
+        shaped = self.reward_type == 'shaped'
         e = self._engine
         K = min(int(n_steps), self.n - 1 - self.i)
         actions, rewards, dones = [], [], []
         pos, done = 0, False
+        # graph = 'auto' | True: chunks of GRAPH_CHUNK steps replayed from a captured hipGraph where that is possible -- a reward without a
+        # data-dependent `done` ('trinary': every step of the call is wanted), a history ring whose depth divides the chunk, a policy
+        # that can be captured; everything else (and graph = False) takes the eager loop below, step by step from the host
+        G = self.GRAPH_CHUNK
+        use_graph = bool(graph) and self.reward_type == 'trinary' and G % e.H == 0
+        if not hasattr(self, "_policy_graphs"):
+            self._policy_graphs, self.policy_graph_error = {}, None
+        while use_graph and K - pos >= G:
+            i0 = self.i
+            ent = self._policy_graph(policy, G, i0)
+            if ent is None:
+                break
+            g, stats_d, upd_d, acts_d, stream = ent
+            e.flush_stats()
+            e.env_time0.fill_(i0)
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream):
+                g.replay()
+            torch.cuda.current_stream().wait_stream(stream)
+            stats = stats_d.cpu().numpy()                  # synchronises
+            upd = upd_d.cpu().numpy()
+            acts = acts_d.cpu().numpy()
+            e.env_time0.zero_()
+            for k in range(G):
+                self.i += 1
+                i, a = self.i, int(acts[k])
+                if not (0 <= a < self.m):
+                    raise ValueError("run_policy: the policy chose action %d at step %d (valid: 0 .. %d)" % (a, i, self.m - 1))
+                self.actions[i] = a
+                self._book_update(i, a, upd[k])
+                self._stats = stats[k]
+                if int(stats[k][_lib.STAT_N_FAILED]) != self._n_failed:
+                    self._record_failures(at_step=i)
+                done = self._reward_done(i, a, stats[k], self._argmax_sigma) or (i + 1 >= self.n)
+                self._argmax_sigma = int(stats[k][_lib.STAT_ARGMAX_SPOS])
+                actions.append(a)
+                rewards.append(self.rewards[i] if (self.obs_returned == 'flatten' or np.isfinite(self.rewards[i])) else np.float64(0.5))
+                dones.append(done)
+            pos += G
+            if done:
+                break
         while pos < K and not done:
             kk = (K - pos) if self.reward_type == 'trinary' else min(K - pos, e.H - 1)
             i0 = self.i
@@ -593,7 +732,7 @@ class SSA_Tasker_Env(Env):
                     raise TypeError("run_policy: the policy must return a CUDA int32 tensor with one element (the action)")
                 acts_d.append(a)          # (kept alive until the launches that read it have run)
                 e.launch_step((i - 1) % e.H, i % e.H, i, actions_ptr=a.data_ptr(), fast_stats=True, defer_fold=True,
-                              stats_out=stats_d[k].data_ptr(), upd_out=upd_d[k].data_ptr())
+                              stats_out=stats_d[k].data_ptr(), upd_out=upd_d[k].data_ptr(), argmax_spos=shaped)
                 self.i = i                # (the view of the next decision indexes the history by it)
             e.flush_stats()
             stats = stats_d.cpu().numpy()                  # synchronises the stream
@@ -610,7 +749,8 @@ class SSA_Tasker_Env(Env):
                 self._stats = stats[k]
                 if int(stats[k][_lib.STAT_N_FAILED]) != self._n_failed:
                     self._record_failures(at_step=i)
-                done = self._reward_done(i, a, stats[k], -1) or (i + 1 >= self.n)
+                done = self._reward_done(i, a, stats[k], self._argmax_sigma) or (i + 1 >= self.n)
+                self._argmax_sigma = int(stats[k][_lib.STAT_ARGMAX_SPOS])
                 r = self.rewards[i]
                 actions.append(a)
                 rewards.append(r if (self.obs_returned == 'flatten' or np.isfinite(r)) else np.float64(0.5))
@@ -618,7 +758,6 @@ class SSA_Tasker_Env(Env):
                 if done:
                     break
             pos += kk
-        self._argmax_sigma = -1
         return np.asarray(actions, dtype=int), np.asarray(rewards), np.asarray(dones, dtype=bool)
 
     # ------------------------------------------------------------------ failures (:369-382)
@@ -688,7 +827,10 @@ class SSA_Tasker_Env(Env):
         """Tests 2 and 4 of fitness_test() (:750-775): the percentage of normalised innovations squared (NaN dropped, :757)
         and of normalised estimation errors squared (NaN kept in the mean, :771) inside the two-sided (1 - alpha) chi-square
         interval, counted ON THE DEVICE (ssa_nis_f64 / ssa_nees_f64 + ssa_chi2_contained_f64) over the steps simulated so
-        far that are still resident.  Returns {'Test 2: NIS chi2': pct, 'Test 4: NEES chi2': pct, counts...}."""
+        far that are still resident.  The reference's Test 4 covers the WHOLE episode (its history arrays hold every step): build the
+        env with config['history'] = 'full' for that -- with a short ring (history = 2, what 'auto' picks for very large envs) the NEES
+        window is the last `history` steps only, and 'nees_steps' in the result says how many it was.
+        Returns {'Test 2: NIS chi2': pct, 'Test 4: NEES chi2': pct, counts...}."""
         import torch
         from .. import device
         e = self._engine
@@ -713,7 +855,7 @@ class SSA_Tasker_Env(Env):
         lo, hi = self._chi2_points(alpha, 6)
         inside, _ = device.chi2_contained(nees, lo, hi)
         out['Test 4: NEES chi2'] = round(100.0 * inside / nees.numel(), 2)
-        out['nees_inside'], out['nees_total'] = inside, int(nees.numel())
+        out['nees_inside'], out['nees_total'], out['nees_steps'] = inside, int(nees.numel()), len(slots)
         return out
 
     def failed_filters(self):

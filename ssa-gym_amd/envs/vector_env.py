@@ -61,6 +61,9 @@ class SSA_Tasker_VecEnv:
         # config['obs_device'] = True (opt-in, for policies that live on the GPU): step() returns the observations as ONE CUDA tensor
         # [E, ...] -- a view of device memory the step kernel wrote -- and nothing but the statistics crosses PCIe
         self._obs_device = bool(config.get('obs_device', False))
+        # step() returns a FRESH array (gym's vector envs copy their observation buffer by default, and so does the reference's single
+        # env for 'flatten'); config['obs_zero_copy'] = True: a view of the host-mapped ring the kernel writes, valid until step k + 2
+        self._obs_zero_copy = bool(config.get('obs_zero_copy', False))
         self._stats_host = torch.zeros((self.E, _lib.STAT_STRIDE), dtype=torch.float64).pin_memory()
         self._stats_np = self._stats_host.numpy()
         per = self.m * (4 if self.obs_returned == 'aer' else 12)
@@ -143,7 +146,10 @@ class SSA_Tasker_VecEnv:
         sin, sout = (self.tick - 1) % 2, self.tick % 2
         aer = self.obs_returned == 'aer'
         k = self.tick % 2
-        fast = self.reward_type != 'shaped'
+        shaped = self.reward_type == 'shaped'
+        # 'shaped' needs np.argmax(sigma_pos[i - 1]) per env: from the arg-max slots of the one-launch path when every env is whole
+        # tiles (rso_count % 4 == 0), through the three-launch exact statistics otherwise
+        fast = (not shaped) or e.supports_argmax
         if self._obs_device:
             aer_out, mirror = (self._aer.data_ptr() if aer else 0), 0
         else:
@@ -151,17 +157,17 @@ class SSA_Tasker_VecEnv:
         if self._inline:
             cur = self._stream
             e.launch_step(sin, sout, 0, aer_out=aer_out, obs_mirror=mirror, stats_out=self._stats_host.data_ptr(), stream=cur.cuda_stream,
-                          fast_stats=fast, fold_inside=True, env_words=(self.i.tolist(), actions.tolist()))
+                          fast_stats=fast, fold_inside=True, env_words=(self.i.tolist(), actions.tolist()), argmax_spos=shaped and fast)
         else:
             self._time_np[:] = self.i
             self._act_np[:] = actions
             e.time_actions.copy_(self._ta_host, non_blocking=True)
             cur = torch.cuda.current_stream()     # (the stream the time / action copy above was enqueued in)
             e.launch_step(sin, sout, 0, aer_out=aer_out, obs_mirror=mirror, stats_out=self._stats_host.data_ptr(), stream=cur.cuda_stream,
-                          fast_stats=fast, fold_inside=True)
+                          fast_stats=fast, fold_inside=True, argmax_spos=shaped and fast)
         cur.synchronize()
         st = self._stats_np            # (host-mapped: the step kernel's folds wrote it; stable until the next launch)
-        if not fast:
+        if shaped:
             self._argmax_prev = st[:, _lib.STAT_ARGMAX_SPOS].astype(np.int64)
         mx = st[:, _lib.STAT_MAX_DPOS]
         last = self.i + 1 >= self.n
@@ -183,7 +189,7 @@ class SSA_Tasker_VecEnv:
         else:
             rewards, dones = np.zeros(self.E), np.zeros(self.E, dtype=bool)
         self.rewards_sum += rewards
-        obs = self._obs(sout) if self._obs_device else self._obs_ring_np[k]
+        obs = self._obs(sout) if self._obs_device else (self._obs_ring_np[k] if self._obs_zero_copy else self._obs_ring_np[k].copy())
         infos = [{} for _ in range(self.E)]
         if dones.any():   # auto-reset in place; the returned observation of a finished env is its new first one
             for d in np.where(dones)[0]:

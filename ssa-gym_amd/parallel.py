@@ -272,6 +272,8 @@ class GraphedShardedSteps:
         self._idx = torch.zeros(self.U, dtype=torch.int64, device=dev)
         self.window = torch.full((self.U,), -1, dtype=torch.int32, device=dev)
         self._graphs = {}
+        self.capture_failed = None          # repr of the exception that made a phase fall back to the eager enqueue
+        self._force_capture_failure = False
         self.eng.env_time0.zero_()
         self._stream = torch.cuda.Stream(device=dev)                     # capture / replay stream
 
@@ -330,30 +332,43 @@ class GraphedShardedSteps:
         hip.hipGetLastError()     # (the sticky error of the failed capture is consumed here, not by the next launch)
 
     def run_unit(self):
-        """replay (capture on first use) the unit for the current phase; returns nothing, synchronises nothing"""
+        """replay (capture on first use) the unit for the current phase; returns nothing, synchronises nothing.  A phase whose capture
+        fails (a runtime that cannot capture the collective) is remembered and enqueued eagerly from then on -- the same kernels and the
+        same collectives in the same order, so ranks that captured and ranks that did not stay in step; `capture_failed` says why."""
         sh, local = self.sh, self.local
-        key = (local.tick % 2, sh.k % sh.NB)
+        tick0, k0 = local.tick, sh.k
+        key = (tick0 % 2, k0 % sh.NB)
         g = self._graphs.get(key)
         cur = torch.cuda.current_stream()
-        if g is None:
-            # warm the path once eagerly on the capture stream (RCCL sets up its channels on first use), then capture
-            # first use of this phase: the unit runs ONCE eagerly on the capture stream (RCCL sets up its channels on first use,
-            # and this run IS the unit the caller asked for), then the same enqueue sequence is captured for the replays to
-            # come -- the capture itself executes nothing
-            self._stream.wait_stream(cur)
-            with torch.cuda.stream(self._stream):
-                self._enqueue_unit(local.tick, sh.k)
-                self._stream.synchronize()
-            # (begin / end by hand instead of `with torch.cuda.graph(...)`: when the capture fails -- a collective that cannot be
-            # captured -- the context manager's exit raises from capture_end() before it restores the current stream, and a stream
-            # left capturing makes the next allocation or copy of the process fail.  Here a failed capture is ended, every stream
-            # is checked, the current stream is restored, and the caller sees ONE exception it can fall back from.)
-            g = torch.cuda.CUDAGraph()
-            torch.cuda.synchronize()
+        # (host bookkeeping first: whatever happens below, U steps of this rank's state and U all-gathers have been / will be enqueued)
+        local.tick += self.U
+        sh.k += self.U
+        if g is False:                 # this phase could not be captured: per-step enqueue
+            self._enqueue_unit(tick0, k0)
+            return
+        if g is not None:
+            g.replay()
+            return
+        # first use of this phase: the unit runs ONCE eagerly on the capture stream (RCCL sets up its channels on first use,
+        # and this run IS the unit the caller asked for), then the same enqueue sequence is captured for the replays to
+        # come -- the capture itself executes nothing
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            self._enqueue_unit(tick0, k0)
+            self._stream.synchronize()
+        # (begin / end by hand instead of `with torch.cuda.graph(...)`: when the capture fails -- a collective that cannot be
+        # captured -- the context manager's exit raises from capture_end() before it restores the current stream, and a stream
+        # left capturing makes the next allocation or copy of the process fail.  Here a failed capture is ended, every stream
+        # is checked, the current stream is restored, and the phase falls back to the eager enqueue.)
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        try:
             with torch.cuda.stream(self._stream):
                 g.capture_begin(capture_error_mode="thread_local")
                 try:
-                    self._enqueue_unit(local.tick, sh.k)
+                    if self._force_capture_failure:
+                        raise RuntimeError("forced capture failure (test)")
+                    self._enqueue_unit(tick0, k0)
                     g.capture_end()
                 except BaseException:
                     try:
@@ -363,13 +378,11 @@ class GraphedShardedSteps:
                     self._end_stray_capture()
                     raise
             self._graphs[key] = g
-            cur.wait_stream(self._stream)
-            local.tick += self.U
-            sh.k += self.U
-            return
-        g.replay()
-        local.tick += self.U
-        sh.k += self.U
+        except Exception as exc:  # noqa: BLE001
+            self._graphs[key] = False
+            self.capture_failed = repr(exc)
+            # (what the aborted capture recorded of the device-side advances never ran; the eager unit above did advance them once: consistent)
+        cur.wait_stream(self._stream)
 
 
 def fold_raw_statistics(rows_words):

@@ -4,9 +4,10 @@
 // propagators' arithmetic against the reference goldens without a GPU (tests/test_device_math_host.py).
 #include "hip/hip_runtime.h"
 #include "../../ssa-gym_amd/csrc/ssa_math.hpp"
-namespace ssa {   // the out-of-line complete restatement lives in ssa_kernels.hip (device only): not reachable from these entry points' domains
-Vec6 kepler_general_v(Vec6, double) { Vec6 o; for (int i = 0; i < 6; ++i) o.v[i] = __builtin_nan(""); return o; }
-Vec8 kepler_general_diag_v(Vec6, double, Vec6*) { Vec8 d; for (int i = 0; i < 8; ++i) d.v[i] = __builtin_nan(""); return d; }
+#include "../../ssa-gym_amd/csrc/ssa_conics.hpp"
+namespace ssa {   // (the out-of-line wrappers of ssa_kernels.hip)
+Vec6 kepler_general_v(Vec6 x, double tof) { Vec6 o; kepler_general_impl(x.v, tof, o.v, nullptr); return o; }
+Vec8 kepler_general_diag_v(Vec6 x, double tof, Vec6* out) { Vec8 d; Vec6 o; kepler_general_impl(x.v, tof, o.v, d.v); *out = o; return d; }
 }
 extern "C" {
 // prop 1: SSA_PROP_FG (kepler_fg_fast), prop 0: SSA_PROP_ELEMENTS strong-elliptic path (kepler_elements_fast); ok[i] = handled
@@ -23,6 +24,37 @@ void hm_uv_general(const double* x, long n, double dt, double* out, int* ok)
 {
     for (long i = 0; i < n; ++i) ok[i] = ssa::kepler_uv_general(x + 6 * i, dt, out + 6 * i);
 }
+// the conic branches beyond the strong-elliptic one (ssa_conics.hpp): libm-level restatement, fast restatement (its bands through
+// genf::), the inline strong-hyperbolic tier; ok[i] = the tier accepted the state
+void hm_general_libm(const double* x, long n, double dt, double* out, int* ok)
+{
+    for (long i = 0; i < n; ++i) { ssa::kepler_general_impl(x + 6 * i, dt, out + 6 * i, nullptr); ok[i] = 1; }
+}
+void hm_general_fast(const double* x, long n, double dt, double* out, int* ok)
+{
+    for (long i = 0; i < n; ++i) {
+        ssa::Vec6 xi; for (int c = 0; c < 6; ++c) xi.v[c] = x[6 * i + c];
+        const ssa::Vec6 o = ssa::kepler_general_fast_impl<0>(xi, dt);
+        for (int c = 0; c < 6; ++c) out[6 * i + c] = o.v[c];
+        ok[i] = 1;
+    }
+}
+void hm_conic_lean(const double* x, long n, double dt, double* out, int* ok)
+{
+    for (long i = 0; i < n; ++i) {
+        for (int c = 0; c < 6; ++c) out[6 * i + c] = __builtin_nan("");
+        ok[i] = ssa::kepler_conic_lean<0, false>(x + 6 * i, dt, out + 6 * i);
+    }
+}
+// the band functions alone: nu(t0 + tof) from (nu, ecc, q), fast and libm
+void hm_band(const double* nu, const double* ecc, const double* q, long n, double tof, double* fast, double* libm)
+{
+    for (long i = 0; i < n; ++i) {
+        fast[i] = ssa::genf::nu_from_delta_t_band(ssa::genf::delta_t_from_nu_band(nu[i], ecc[i], q[i]) + tof, ecc[i], q[i]);
+        libm[i] = ssa::gen::nu_from_delta_t(ssa::gen::delta_t_from_nu(nu[i], ecc[i], ssa::MU, q[i]) + tof, ecc[i], ssa::MU, q[i]);
+    }
+}
+void hm_log_pos(const double* x, long n, double* r) { for (long i = 0; i < n; ++i) r[i] = ssa::genf::log_pos(x[i]); }
 int hm_robust_chol6(const double* A21, double* U21) { return ssa::robust_chol6(A21, U21); }
 void hm_sincos_fast(const double* x, long n, double* s, double* c) { for (long i = 0; i < n; ++i) ssa::sincos_fast(x[i], s[i], c[i]); }
 void hm_atan2_fast(const double* y, const double* x, long n, double* r) { for (long i = 0; i < n; ++i) r[i] = ssa::atan2_fast(y[i], x[i]); }

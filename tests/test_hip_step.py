@@ -315,8 +315,10 @@ def test_second_step_from_tight_covariances(hip, oracle, oracle_ld):
 
 
 def test_fused_ladder_picks_the_reference_rung_for_every_rung(hip, oracle_ld):
-    """The fused kernel finds an object's robust_cholesky rung in two factorisations (last rungs of the four groups, then the group):
-    the answer must be the sequential ladder's (dynamics.py:402-417) for EVERY rung -1, 0..15 and beyond (LinAlgError).  Indefinite
+    """The fused kernel tries all sixteen rungs of an object's robust_cholesky ladder side by side (one lane per rung) and takes the
+    lowest that factorises: the answer must be the sequential ladder's (dynamics.py:402-417) for EVERY rung -1, 0..15 and beyond
+    (LinAlgError) -- on well-separated cases here; test_ladder_first_success_on_the_non_monotone_case pins the case where success is
+    not monotone in the jitter, which a search that skips rungs gets wrong.  Indefinite
     priors built so that (n + lambda) P needs a given rung (smallest eigenvalue -0.3 x that rung's jitter), mixed in wavefronts of four
     with healthy objects and with each other; checked through the sequential ladder of the single-operator entry point, the failure
     status, and the propagated covariance against the oracle run with that rung (a neighbouring rung changes P by 10 x the jitter)."""
@@ -356,6 +358,138 @@ def test_fused_ladder_picks_the_reference_rung_for_every_rung(hip, oracle_ld):
     sel = (want >= 0) & (want < 15)
     _, _, dP = errs({k: ld10[k][sel] for k in ("x", "P")}, {k: ld[k][sel] for k in ("x", "P")})
     assert dP.min() > 2e-3, dP.min()       # (20 x the tolerance: a rung off by one cannot hide)
+
+
+def test_ladder_first_success_on_the_non_monotone_case(hip, oracle):
+    """robust_cholesky's answer is the FIRST rung that factorises (dynamics.py:406-414) -- also where success is not monotone in the
+    jitter.  tests/golden/ladder_nonmonotone.npz is the prior covariance on which round 3's two-pass search (reverted) parted from the
+    sequential ladder: (n + lambda) P with condition 1e20, the low rungs decided by the last bits of the pivots.  ssa_ladder_probe_f64
+    runs the fused kernels' ladder (robust_chol_row_lds) on it and reports, per rung, whether it factorises in that arithmetic:
+      * the fused rung IS the lowest rung that factorises -- for this matrix, for its neighbours under one-ulp perturbations (each a
+        different realisation of the rounding noise) and for every position in the wavefront's four rows;
+      * among those realisations the mask is non-monotone at least once (a rung fails above one that succeeds), and the two-pass rule
+        applied to the same masks picks another rung there -- the failure the round-3 tests missed;
+      * the sequential register ladder (ssa_robust_cholesky6_f64: IEEE square roots and divisions, another rounding realisation) and
+        the oracle agree with the fused kernel wherever the decision is not within rounding (their own rung factorises in the fused
+        arithmetic too, or is adjacent to it)."""
+    g = golden("ladder_nonmonotone.npz")
+    _, _, scale = orc.merwe_weights(1e-4, 2.0, -3)
+    rs = np.random.RandomState(271)
+    n_pert = 4096
+    P = np.tile(g["P"], (n_pert, 1, 1))
+    ulp = 2.220446049250313e-16
+    for k in range(1, n_pert):          # symmetric one-ulp perturbations; entry 0 is the captured matrix itself
+        e = rs.randint(-1, 2, size=(6, 6))
+        e = np.triu(e) + np.triu(e, 1).T
+        P[k] = P[k] * (1.0 + ulp * e)
+    A = hip.dev.as_dev(P)
+    rung, mask, U = hip.dev.ladder_probe(A, scale)
+    rung, mask = rung.cpu().numpy(), mask.cpu().numpy()
+    first = np.array([16 if (m & 0xFFFF) == 0 else int(m & 0xFFFF & -(m & 0xFFFF)).bit_length() - 1 for m in mask])
+    plain = (mask >> 16) & 1
+    want = np.where(plain == 1, -1, first)
+    assert np.array_equal(rung, want), (np.where(rung != want)[0][:8], rung[:8], want[:8])
+    # the factor the kernel leaves is the factor of the rung it reports
+    k0 = int(rung[0])
+    assert 0 <= k0 < 16
+    U0 = U[0].cpu().numpy()
+    M0 = scale * g["P"] + 10.0 ** (k0 - 6) * np.eye(6)
+    assert np.abs(U0.T @ U0 - M0).max() <= 1e-9 * np.abs(M0).max() and np.allclose(np.tril(U0, -1), 0.0)
+    # non-monotone realisations exist, and the two-pass rule fails on them
+    m16 = mask & 0xFFFF
+    def two_pass(m):
+        for grp in range(4):
+            if (m >> (4 * grp + 3)) & 1:
+                return next(i for i in range(4 * grp, 4 * grp + 4) if (m >> i) & 1)
+        return 16
+    nonmono = np.array([bool(((m >> (first[i] + 1)) ^ ((1 << (15 - first[i])) - 1)) & ((1 << (15 - first[i])) - 1)) if first[i] < 15 else False
+                        for i, m in enumerate(m16)])
+    tp = np.array([two_pass(int(m)) for m in m16])
+    print("[ladder] captured case: fused rung %d, mask %s; %d of %d one-ulp realisations are non-monotone; the two-pass search differs on %d"
+          % (k0, format(int(m16[0]), '016b')[::-1], nonmono.sum(), n_pert, (tp != first).sum()))
+    assert nonmono.any() and (tp != first).any()
+    assert bool(nonmono[0]) or bool((tp != first)[0]) or (tp != first).sum() >= 1
+    # the other two implementations of the ladder: another rounding realisation each
+    rung_seq = hip.dev.robust_cholesky(hip.dev.as_dev(scale * P))[1].cpu().numpy()
+    rung_orc = np.array([oracle.robust_cholesky(scale * Pk)[1] for Pk in P[:256]])
+    for name, other in (("sequential register ladder", rung_seq), ("oracle", rung_orc)):
+        r = rung[:len(other)]
+        same = np.mean(other == r)
+        near = np.mean(np.abs(other - r) <= 4)
+        print("[ladder] %s: same rung as the fused kernel on %.3f of the realisations, within the noise band (4 rungs) on %.3f" % (name, same, near))
+        assert near == 1.0          # all decisions inside the band where the jitter is below the pivots' rounding noise
+    # every row of the wavefront gives the same answer for the same matrix (the one-pass ladder serves the four rows side by side)
+    Q = np.tile(g["P"], (8, 1, 1))
+    Q[1::2] = np.diag([1e10] * 3 + [1e4] * 3)          # healthy neighbours in between
+    r2, m2, _ = hip.dev.ladder_probe(hip.dev.as_dev(Q), scale)
+    r2 = r2.cpu().numpy()
+    assert np.all(r2[0::2] == k0) and np.all(r2[1::2] == -1)
+
+
+def test_argmax_sigma_pos_on_every_one_launch_path(hip):
+    """np.argmax(sigma_pos) (the 'shaped' reward, ssa_tasker_simple_2.py:339-352) without the post kernel: the step kernel's per-tile
+    slots reduced by whoever folds the statistics -- fold kernel, deferred fold inside the next launch, the last wavefront
+    (SSA_LAUNCH_FOLD_INSIDE), the rollout's fold -- against numpy on the metrics and against the three-launch exact path; ties (first
+    index wins) and NaN (first NaN wins) included; ragged last tile; several envs of whole tiles; the multi-tile instance."""
+    torch, lib = hip.torch, hip.lib
+    for m, E in ((4, 1), (5, 1), (1003, 1), (20000, 1), (20484, 1), (24, 3), (20000, 2)):
+        xt, x, P, g = make_batch(m * E, seed=31 + m)
+        consts = hip.host.make_consts(g["Q"], g["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, g["obs_lla"], obs_type='aer', propagator='fg')
+        rs = np.random.RandomState(1)
+        zn = rs.normal(size=(E, 480, 1, 3)) * np.array([4.8e-6, 4.8e-6, 1e3])
+        def engine():
+            eng = hip.engine.HotPathEngine(consts, m, E, c2t(), zn, history=4, zn_stride_env=480 * 3, zn_stride_time=3, zn_stride_obj=0)
+            eng.load_state(0, xt, x, P)
+            eng.set_actions([1 % m] * E)
+            return eng
+        ref = engine()
+        for i in (1, 2, 3):
+            ref.launch_step(i - 1, i, i)                                   # exact path: step + post + final
+        torch.cuda.synchronize()
+        want = ref.stats[1:4].cpu().numpy()
+        sp = ref.metrics[1:4, :, 2].cpu().numpy()
+        assert np.array_equal(want[:, :, lib.STAT_ARGMAX_SPOS], np.argmax(sp, axis=2))
+        for mode in ("fold_kernel", "deferred", "inside", "rollout"):
+            eng = engine()
+            if mode == "rollout":
+                acts = torch.full((3, E), 1 % m, dtype=torch.int32, device="cuda")
+                eng.launch_rollout(0, 1, acts, argmax_spos=True)
+            else:
+                for i in (1, 2, 3):
+                    eng.launch_step(i - 1, i, i, fast_stats=True, defer_fold=(mode == "deferred"), fold_inside=(mode == "inside"), argmax_spos=True)
+                eng.flush_stats()
+            torch.cuda.synchronize()
+            got = eng.stats[1:4].cpu().numpy()
+            for col in (lib.STAT_ARGMAX_SPOS, lib.STAT_MAX_SPOS, lib.STAT_MAX_DPOS, lib.STAT_CNT_LT_1E4, lib.STAT_CNT_LT_1E7, lib.STAT_N_FAILED):
+                assert np.array_equal(got[:, :, col], want[:, :, col], equal_nan=True), (m, E, mode, col, got[:, :, col], want[:, :, col])
+    # ties and NaN: equal covariances give equal sigma_pos -> the first index; a NaN covariance ranks above everything
+    m = 64
+    xt, x, P, g = make_batch(m, seed=5)
+    consts = hip.host.make_consts(g["Q"], g["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, g["obs_lla"], obs_type='aer', propagator='fg')
+    zn = np.zeros((1, 480, m, 3))
+    for poison in (None, 37, 11):
+        eng = hip.engine.HotPathEngine(consts, m, 1, c2t(), zn, history=2)
+        xx, PP = x.copy(), P.copy()
+        xx[:] = xx[0]; xt2 = np.tile(xt[0], (m, 1))                         # identical objects: identical sigma_pos
+        eng.load_state(0, xt2, xx, PP)
+        st = np.zeros(m, dtype=np.int32)
+        if poison is not None:
+            st[poison] = lib.ST_PREDICT_NAN                                   # a failed filter passes through: give it a NaN covariance
+            eng.P_filter[0, poison] = float("nan")
+        eng.status.copy_(torch.as_tensor(st))
+        eng.set_actions([-1])
+        eng.launch_step(0, 1, 1, fast_stats=True, argmax_spos=True)
+        torch.cuda.synchronize()
+        s = eng.stats[1, 0].cpu().numpy()
+        spv = eng.metrics[1, 0, 2].cpu().numpy()
+        assert int(s[lib.STAT_ARGMAX_SPOS]) == int(np.argmax(spv)) == (0 if poison is None else poison)
+        assert np.array_equal(s[lib.STAT_MAX_SPOS], np.max(spv), equal_nan=True)
+    # envs that are not whole tiles: the library says so (the caller takes the three-launch path)
+    xt, x, P, g = make_batch(14, seed=3)
+    eng = hip.engine.HotPathEngine(consts, 7, 2, c2t(), np.zeros((2, 480, 7, 3)), history=2)
+    assert not eng.supports_argmax
+    with pytest.raises(lib.SsaHipError):
+        eng.launch_step(0, 1, 1, fast_stats=True, argmax_spos=True)
 
 
 def test_visibility_gate_and_no_update_paths(hip, oracle):
@@ -1091,6 +1225,23 @@ def test_graphed_sharded_steps_equal_eager_steps(hip):
             assert np.array_equal(dev_stats[:3], want[5][:3]) and dev_stats[hip.lib.STAT_N_FAILED] == want[5][hip.lib.STAT_N_FAILED]
             assert int(eng.env_time0.item()) == U * NU and int(gs.cursor.item()) == U * NU
             sh.close()
+        # a phase whose capture fails keeps the host and device bookkeeping in step (the eager unit ran; tick and k advanced) and is
+        # enqueued eagerly from then on: same results, no exception, `capture_failed` says why
+        eng, local, sh = fresh()
+        gs = parallel.GraphedShardedSteps(sh, U, sched, overlap=False)
+        gs.rewind()
+        gs._force_capture_failure = True
+        for _ in range(NU):
+            gs.run_unit()
+        sh.wait()
+        torch.cuda.synchronize()
+        assert gs.capture_failed is not None and all(v is False for v in gs._graphs.values()) and local.tick == U * NU and sh.k == U * NU
+        got = (eng.x_filter[local.tick % 2].cpu().numpy(), eng.P_filter[local.tick % 2].cpu().numpy(), eng.x_true[local.tick % 2].cpu().numpy(),
+               eng.status.cpu().numpy(), sh.global_obs().cpu().numpy(), sh.global_stats())
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b, equal_nan=True)
+        assert int(eng.env_time0.item()) == U * NU and int(gs.cursor.item()) == U * NU
+        sh.close()
     finally:
         if created:
             dist.destroy_process_group()
