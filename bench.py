@@ -227,7 +227,7 @@ def local_variant_rate(m, K, W, propagator, resample=False, seed=100):
     return out
 
 
-def closed_loop_rate(m, K, W, seed=100, persistent=True, chunk=120, agent=None):
+def closed_loop_rate(m, K, W, seed=100, persistent=True, chunk=120, agent=None, propagator='hybrid'):
     """closed loop WITHOUT the host: the reference's agent_visible_greedy (agents.py:36: arg-max of trace(P) over the visible
     objects) chooses every step's action on the device.  persistent: ssa_env_closed_loop_f64 -- `chunk` steps and their decisions
     per launch, the wavefronts agree on the next action among themselves while the next predicts already run; else the
@@ -236,7 +236,7 @@ def closed_loop_rate(m, K, W, seed=100, persistent=True, chunk=120, agent=None):
     import torch
     from ssa_gym_amd import _lib, engine, host
     pb = build_problem(m, seed=seed)
-    consts = host.make_consts(pb["Q"], pb["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, pb["obs_lla"], obs_type='aer', propagator='fg')
+    consts = host.make_consts(pb["Q"], pb["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, pb["obs_lla"], obs_type='aer', propagator=propagator)
     gen = torch.Generator(device="cuda").manual_seed(1)
     zn = torch.randn((1, 480, m, 3), dtype=torch.float64, device="cuda", generator=gen) * torch.as_tensor(pb["z_sigma"], device="cuda")
     eng = engine.HotPathEngine(consts, m, 1, pb["trans"], zn, history=2)
@@ -298,7 +298,7 @@ def closed_loop_rate(m, K, W, seed=100, persistent=True, chunk=120, agent=None):
         raise RuntimeError("ssa_env_closed_loop_f64 gave up on a timeout")
     chosen = picks[W + 1:W + K + 1, 0].cpu().numpy()
     return {"value": round(K / el * (m / 20000.0), 2), "ms_per_step": round(1e3 * el / K, 5), **spread(K, m / 20000.0, el, lo, hi, reps),
-            "agent": "agent_visible_greedy (device)", "distinct_objects_selected": int(len(set(chosen.tolist()))),
+            "agent": "agent_visible_greedy (device)", "propagator": propagator, "distinct_objects_selected": int(len(set(chosen.tolist()))),
             "failed_filters": int((eng.status != 0).sum().item()),
             "note": ("closed loop in ONE persistent launch per %d steps (ssa_env_closed_loop_f64): state resident in LDS, the decision made "
                      "between the wavefronts while the next predicts run; no host round trip" % chunk) if persistent else
@@ -492,8 +492,9 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--objects", type=int, default=20000, help="objects per GPU")
-    ap.add_argument("--propagator", default="fg", choices=["fg", "elements", "j2", "hybrid"],
-                    help="fg / elements: two-body Farnocchia (parity-checked); j2: J2+RK4 extension (no reference counterpart)")
+    ap.add_argument("--propagator", default="hybrid", choices=["hybrid", "fg", "elements", "j2"],
+                    help="hybrid (the env default: behaviour-faithful) / fg / elements: two-body Farnocchia (parity-checked); "
+                         "j2: J2+RK4 extension (no reference counterpart)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rollout", type=int, default=60,
                     help="steps per launch of the additional open-loop rollout measurement (0 = skip); never `value`")
@@ -797,8 +798,8 @@ def main():
     legs = {}
     if rank == 0 and world == 1 and not use_dist and not args.no_legs:
         Kl, Wl = min(max(K, 200), 1000), min(max(W, 50), 100)   # (legs: at least 200 steps per timed block)
-        for name, kw in (("j2", dict(propagator="j2")), ("elements", dict(propagator="elements")), ("hybrid", dict(propagator="hybrid")),
-                         ("resample", dict(propagator=args.propagator, resample=True))):
+        for name, kw in (("fg", dict(propagator="fg")), ("hybrid", dict(propagator="hybrid")), ("j2", dict(propagator="j2")),
+                         ("elements", dict(propagator="elements")), ("resample", dict(propagator=args.propagator, resample=True))):
             if name == args.propagator:
                 continue
             legs[name] = local_variant_rate(m, Kl, Wl, **kw)
@@ -806,9 +807,13 @@ def main():
             legs["j2"].update(note="EXTENSION without reference counterpart (SURVEY section 0): two-body + J2, RK4, 4 sub-steps")
         legs["resample"].update(note="predict() redraws the sigma points from the prior (SSA_FLAG_RESAMPLE); `value` keeps the "
                                      "propagated points; which of the two the reference's unpinned filterpy does is unverifiable offline")
-        legs["closed_loop_per_step_launches"] = closed_loop_rate(m, Kl, Wl, persistent=False)
+        if "fg" in legs:
+            legs["fg"].update(note="SSA_PROP_FG: every conic through one universal-variable equation -- more accurate than the reference on diverged "
+                                   "states, so its filters survive where the reference's fail (`episode_failures`): the explicitly named accuracy / "
+                                   "speed option (fx_xyz_farnocchia_fg); `value` of rounds 1-3 was measured on it")
+        legs["closed_loop_per_step_launches"] = closed_loop_rate(m, Kl, Wl, persistent=False, propagator=args.propagator)
         if m <= 20160:      # (one wavefront per four objects + the service wavefronts must all be resident: ssa_env_closed_loop_f64)
-            legs["closed_loop"] = closed_loop_rate(m, max(Kl, 480), Wl)
+            legs["closed_loop"] = closed_loop_rate(m, max(Kl, 480), Wl, propagator=args.propagator)
         else:
             legs["closed_loop"] = dict(legs["closed_loop_per_step_launches"], note="more than 20 160 objects: ssa_env_closed_loop_f64 declines "
                                        "(SSA_E_UNSUPPORTED), the closed loop runs as step + ssa_agent_select_f64 launches")
@@ -836,8 +841,9 @@ def main():
                        "oracle": episode_failures_oracle(),
                        "elements": episode_failures_hip("elements"), "hybrid": episode_failures_hip("hybrid"), "fg": episode_failures_hip("fg"),
                        "note": "failed filters (status != 0) at the given steps.  oracle = CPU restatement in the reference's order of operations; "
-                               "elements / hybrid (with the reference's covariance arithmetic, their default) are the BEHAVIOUR-FAITHFUL variants; "
-                               "fg (the default, `value`) is more accurate on diverged states and its filters survive (tests/test_episode_failures.py)"}
+                               "hybrid (the env default, `value`) and elements (with the reference's covariance arithmetic) are the BEHAVIOUR-FAITHFUL "
+                               "variants; fg is more accurate on diverged states and its filters survive (tests/test_episode_failures.py: five workloads, "
+                               "pooled counts, failed-set overlap, population, first-failure distribution)"}
 
     if rank == 0:
         steps_per_s = K / elapsed
@@ -851,10 +857,13 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "ssa_tasker_simple-v2 hot path: %d objects/GPU x %d GPU, %s + "
                                    "UKF predict (13 sigma points) + 1 az-el-range update/step%s" %
-                                   (m, world, {"fg": "two-body Farnocchia (fg)", "elements": "two-body Farnocchia (elements)", "hybrid": "two-body Farnocchia (hybrid)",
+                                   (m, world, {"fg": "two-body Farnocchia (fg)", "elements": "two-body Farnocchia (elements)", "hybrid": "two-body Farnocchia (hybrid: behaviour-faithful)",
                                                "j2": "two-body + J2 RK4 propagator (EXTENSION, no reference counterpart; 4 sub-steps)"}[args.propagator],
                                     (", sharded env with one RCCL all-gather per step of %s + reward statistics" % ("per-object trace P (BASELINE config 4)" if obs_cols == 1 else "the (az,el,range,trP) observation block")) if use_dist else ""),
                        "objects_per_gpu": m, "objects_total": m * world, "alpha": 1e-4, "dt_s": 20.0,
+                       "catalogue": "synthetic, drawn by the reference's recipe (envs/orbit_gen.py:30-70: regime probabilities and the visibility "
+                                    "acceptance rule; ssa-gym_amd/catalogue.py): 6 806 LEO / 2 162 equatorial / 1 149 circular rows of 20 000 "
+                                    "(the reference's file: 6 755 / 2 231 / 1 135), ecc <= 0.737",
                        "propagator": args.propagator, "parallelism": "object-shard x%d" % world,
                        "allgather": (("comm-stream (overlapped with the next step)" if state["overlap"] else "in-stream")
                                      if use_dist else None),
@@ -868,9 +877,12 @@ def main():
                        "rccl_ranks": (sharded._rccl.count() if (sharded is not None and sharded._rccl is not None)
                                       else (dist.get_world_size() if use_dist else None)),
                        "ukf_variant": "keep propagated sigma points for update() (default; PARITY-UNPINNED, see `resample`)",
-                       "behaviour": ("fg: per-step parity within the north_star tolerance; does NOT reproduce the reference's episode-level filter "
-                                     "failures (see `episode_failures`; the behaviour-faithful variants are `elements` and `hybrid`)"
-                                     if args.propagator in ("fg", "j2") else "behaviour-faithful variant (the reference's episode-level failures)")},
+                       "behaviour": ("%s: per-step parity within the north_star tolerance; does NOT reproduce the reference's episode-level filter "
+                                     "failures (see `episode_failures`; the behaviour-faithful variants are `hybrid` -- the env default -- and `elements`)" % args.propagator
+                                     if args.propagator in ("fg", "j2") else
+                                     "%s: the BEHAVIOUR-FAITHFUL variant%s -- per-step parity within the north_star tolerance AND the reference's episode-level "
+                                     "filter failures (`episode_failures`, tests/test_episode_failures.py over five workloads)"
+                                     % (args.propagator, " and the env default (what `fx_xyz_farnocchia` resolves to)" if args.propagator == "hybrid" else ""))},
             "object_steps_per_sec": round(steps_per_s * m * world, 1),
             "failed_filters": n_failed,
             "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "episode_failures": ep_fail, "rollout": roll,

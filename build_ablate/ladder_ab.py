@@ -33,7 +33,14 @@ for i in range(1, 480):
         if len(bad):
             j = int(bad[0])
             print("first difference at step %d, object %d (%d objects differ); status here %d, other build %d" % (i, j, len(bad), st[i, j], ref["st"][i, j]))
-            np.savez(os.environ["OUT"], P=Pprev[j].cpu().numpy(), x=xprev[j].cpu().numpy(), step=i, obj=j)
+            t0 = 4 * (j // 4)          # the whole tile: the four objects one wavefront factorises side by side
+            np.savez(os.environ["OUT"], P=Pprev[j].cpu().numpy(), x=xprev[j].cpu().numpy(), step=i, obj=j,
+                     P_tile=Pprev[t0:t0 + 4].cpu().numpy(), x_tile=xprev[t0:t0 + 4].cpu().numpy(), status_tile=st[i - 1, t0:t0 + 4])
+            from ssa_gym_amd import device
+            _, _, scale = host.merwe_weights(1e-4, 2.0, -3)
+            for lib_name in ("this build",):
+                rung, mask, _ = device.ladder_probe(Pprev[t0:t0 + 4].contiguous(), scale)
+                print("ladder probe of the tile (%s): rung %s  masks %s" % (lib_name, rung.cpu().numpy().tolist(), [format(int(m) & 0x1ffff, '017b')[::-1] for m in mask.cpu().numpy()]))
             np.set_printoptions(precision=17, linewidth=200)
             print("prior covariance of that object:\n", Pprev[j].cpu().numpy())
             break

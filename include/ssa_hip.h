@@ -199,7 +199,23 @@ typedef struct ssa_step_params {
                                   exact on these paths too.  Needs whole tiles per env: n_env == 1 or n_obj % 4 == 0 (SSA_E_UNSUPPORTED otherwise:
                                   take the three-launch path, stat_shards = NULL).  Contents need no initialisation. */
     uint64_t *spos_tiles_prev; /* with SSA_LAUNCH_DEFER_FOLD: the slots the PREVIOUS step wrote (folded with stat_shards_prev), or NULL */
+    double *fail_log;          /* [fail_cap][SSA_FAIL_STRIDE] or NULL: the filter_error() bookkeeping (ssa_tasker_simple_2.py:369-382) written BY THE KERNEL.
+                                  A filter that fails in this step appends one record -- env, object, SSA_ST_* code, the step's time index and
+                                  error_failed() of the state it failed from (:376-378: |x - x_true| and sqrt(sum diag P) of position and velocity, taken
+                                  from the step's inputs) -- at index atomicAdd(fail_count, 1).  Meant for host-mapped pinned memory: the host reads the new
+                                  records (their number = the rise of stats[SSA_STAT_N_FAILED]) right after the step's synchronisation, with no
+                                  further copy -- the reference loses 2-3 % of its filters per episode, a few per step late in an episode, and a
+                                  status read-back plus gathers per step doubled the cost of a gym-style step (round 4) */
+    uint32_t *fail_count;      /* device word: records appended so far (the caller zeroes it when it resets its episode); NULL with fail_log NULL */
+    int32_t fail_cap;          /* capacity of fail_log in records (a record beyond it is counted but not written) */
+    int32_t reserved1;
 } ssa_step_params;
+#define SSA_FAIL_STRIDE 8
+#define SSA_FAIL_ENV 0
+#define SSA_FAIL_OBJ 1      /* index within the env */
+#define SSA_FAIL_STATUS 2
+#define SSA_FAIL_TIME 3     /* the step's time index i (env_time + time_offset) */
+#define SSA_FAIL_ERR 4      /* [4] delta_pos, delta_vel, sigma_pos, sigma_vel of the state the filter failed from */
 
 /* ---------------------------------------------------------------- fused hot path
  * One env step for every object of every env, every propagator:
@@ -317,6 +333,13 @@ int ssa_aer_obs_f64(const double *x, const double *P, const double *M, const ssa
 int ssa_agent_scores_f64(const double *x_true, const double *x_cur, const double *P_cur, const double *P_prev,
                          const double *M, const ssa_consts *c_host, double *scores, uint8_t *mask, int64_t n,
                          void *stream);
+/* The two primitives above for callers whose time index lives ON THE DEVICE (a policy evaluated inside a captured hipGraph: the graph
+ * advances the index between replays): the GCRS->ITRS matrix is row (env_time[0] + time_offset) % n_time of the table `trans`, as in the step. */
+int ssa_visible_mask_at_f64(const double *x_true, const double *trans, const int32_t *env_time, int32_t time_offset, int32_t n_time,
+                            const ssa_consts *c_host, uint8_t *mask, double *el, int64_t n, void *stream);
+int ssa_agent_scores_at_f64(const double *x_true, const double *x_cur, const double *P_cur, const double *P_prev, const double *trans,
+                            const int32_t *env_time, int32_t time_offset, int32_t n_time, const ssa_consts *c_host, double *scores,
+                            uint8_t *mask, int64_t n, void *stream);
 /* np.argmax(score[mask]) mapped back to object indices: out[0] = index of the first maximum of `score`
  * over entries with mask != 0 (mask may be NULL = all), or -1 when no entry is selected / n == 0;
  * NaN entries are skipped (the reference's agents run under np.errstate and np.argmax would return a

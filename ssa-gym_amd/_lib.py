@@ -36,6 +36,7 @@ class ssa_step_params(C.Structure):
         ("stat_shards_clear", c_dp), ("aer_cols", C.c_int32), ("action0", C.c_int32), ("obs_mirror", c_dp),
         ("inline_time", C.c_int32 * 8), ("inline_action", C.c_int32 * 8),
         ("spos_tiles", c_dp), ("spos_tiles_prev", c_dp),
+        ("fail_log", c_dp), ("fail_count", c_dp), ("fail_cap", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -75,6 +76,7 @@ LAUNCH_FOLD_INSIDE = 32
 LAUNCH_INLINE_ENVS = 64
 INLINE_ENVS = 8
 LOOP_ARGMAX_SPOS, LOOP_DEBUG_WITHHOLD = 1, 2
+FAIL_STRIDE, FAIL_ENV, FAIL_OBJ, FAIL_STATUS, FAIL_TIME, FAIL_ERR = 8, 0, 1, 2, 3, 4
 AGENT_NAIVE_GREEDY, AGENT_VISIBLE_GREEDY, AGENT_SHANNON, AGENT_POS_ERROR, AGENT_VEL_ERROR = range(5)
 STAT_STRIDE, STAT_MAX_DPOS, STAT_CNT_LT_1E4, STAT_CNT_LT_1E7, STAT_ARGMAX_SPOS, STAT_N_FAILED, STAT_MAX_SPOS = 8, 0, 1, 2, 3, 4, 5
 
@@ -105,6 +107,8 @@ SIGNATURES = {
     "ssa_visible_mask_f64": (C.c_int, [c_dp, c_dp, C.POINTER(ssa_consts), c_dp, c_dp, C.c_int64, c_dp]),
     "ssa_observe_f64": (C.c_int, [c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int64, c_dp]),
     "ssa_agent_scores_f64": (C.c_int, [c_dp, c_dp, c_dp, c_dp, c_dp, C.POINTER(ssa_consts), c_dp, c_dp, C.c_int64, c_dp]),
+    "ssa_visible_mask_at_f64": (C.c_int, [c_dp, c_dp, c_dp, C.c_int32, C.c_int32, C.POINTER(ssa_consts), c_dp, c_dp, C.c_int64, c_dp]),
+    "ssa_agent_scores_at_f64": (C.c_int, [c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int32, C.c_int32, C.POINTER(ssa_consts), c_dp, c_dp, C.c_int64, c_dp]),
     "ssa_masked_argmax_f64": (C.c_int, [c_dp, c_dp, C.c_int64, c_dp, c_dp]),
     "ssa_aer_obs_f64": (C.c_int, [c_dp, c_dp, c_dp, C.POINTER(ssa_consts), c_dp, C.c_int64, c_dp]),
     "ssa_agent_select_f64": (C.c_int, [C.POINTER(ssa_consts), C.c_int32, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int32, C.c_int32,

@@ -532,6 +532,20 @@ SSA_DEV void chol_step(const double (&a)[6], double (&uc)[6], int lc, bool& ok)
     if (J == 5) ok = ok && (y > 0.0) && (y <= 1.79769313486231570e308);
     uc[J] = (lc >= J) ? v * y : 0.0;              // lane J: ajj / sqrt(ajj) = the diagonal entry
 }
+// One entry of the matrix a rung factorises, in the REFERENCE's two roundings: sigma_points() hands robust_cholesky the product
+// (n + lambda) P already rounded, and the ladder adds its jitter to that (dynamics.py:410: cholesky(a + e)).  Written out with an
+// optimisation barrier between the two: under -ffp-contract=fast the compiler fused scale * p + jit into one fma at some call sites and -- where it could
+// share scale * p with a neighbouring factorisation of the same matrix -- not at others.  One rounding more or less in a diagonal entry
+// is nothing, except for the matrices the ladder exists for: (n + lambda) P of a diverged filter has condition 1e20, the factor's last
+// rows move by 1e-8 relative with that bit, and two builds of the same source parted over an episode (round 3's "two-pass" ladder
+// picked the SAME rungs as the sequential one -- ssa_ladder_probe_f64, tests/golden/ladder_nonmonotone.npz -- and still left
+// different filters: its second factorisation was the unfused instance).  Now every instance is the reference's arithmetic.
+SSA_DEV double scaled_entry(double scale, double pv, double jit)
+{
+    double sp = scale * pv;
+    SSA_OPAQUE(sp);              // (two roundings: the product is a value of its own before the jitter is added)
+    return sp + jit;
+}
 // factorises the matrix at Pg (row-major 6x6 in LDS) in the calling row `grow`; the factor's column lc stays in uc[]
 template <bool PLAIN>   // PLAIN: the jitter-free first attempt (no diagonal select / add on the common path)
 SSA_DEV bool chol_row_regs(const double* Pg, double scale, double jit, int grow, int l, double (&uc)[6])
@@ -545,7 +559,7 @@ SSA_DEV bool chol_row_regs(const double* Pg, double scale, double jit, int grow,
     for (int j = 0; j < 6; ++j) {
         const double pv = Pg[j * 6 + lc];
         ok = ok && (fabs(pv) <= 1.79769313486231570e308);
-        a[j] = PLAIN ? scale * pv : scale * pv + ((lc == j) ? jit : 0.0);
+        a[j] = (PLAIN || lc != j) ? scale * pv : scaled_entry(scale, pv, jit);
     }
     ok = ((__ballot(!ok) >> (grow * 16)) & 0xFFFFull) == 0;
     chol_step<0>(a, uc, lc, ok);
@@ -574,8 +588,9 @@ SSA_DEV void chol_store_rows(double* Ug, const double (&uc)[6], int l)
 __constant__ double JITTER[16] = {1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1.0, 10.0, 100.0, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9};
 // Does scale * P + jit * I factorise?  ONE lane decides, alone, in its own registers: the ladder's unit of work when every lane
 // of a row tries its own rung (robust_chol_row_lds below).  Operation by operation the arithmetic of chol_row_regs<false> --
-// the same fused multiply-adds in the same order, the same refined reciprocal square root -- so a rung succeeds here exactly
-// when it succeeds there (the round-3 library's results are reproduced bit for bit: profiles/r04_ab_against_round3.txt).
+// the same matrix entries (scaled_entry), the same fused multiply-adds in the same order, the same refined reciprocal square
+// root -- so a rung succeeds here exactly when it succeeds there (with round 3's fused diagonal the one-pass ladder reproduced the
+// round-3 library bit for bit over 20 000-object episodes of all three propagators: profiles/r04_ab_ladder_against_round3.txt).
 // Only the verdict leaves: an entry U[i][c] is dead once step c has used it, so at most nine entries are live at a time
 // (a lane that kept its whole factor, 42 registers, made the closed-loop kernels spill); the winning rung's factor is then
 // formed once more by the row (chol_row_regs<false>), which is where it is needed in the row-distributed layout anyway.
@@ -586,7 +601,7 @@ SSA_DEV bool chol_lane_ok(const double* Pg, double scale, double jit)
     double y = 0.0;
 #pragma unroll
     for (int J = 0; J < 6; ++J) {
-        double vp = fma(scale, Pg[J * 6 + J], jit);
+        double vp = scaled_entry(scale, Pg[J * 6 + J], jit);
 #pragma unroll
         for (int i = 0; i < J; ++i) vp = fma(-U[tri(i, J)], U[tri(i, J)], vp);
         y = rsqrt_nr(vp);               // NaN / inf when the pivot is <= 0 or NaN: poisons everything behind it (see chol_step)
@@ -1165,7 +1180,8 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
 #endif
         if (PROP == 3) {
             if (__any(!kep_ok)) {   // sigma points outside the strong-elliptic regime: the reference's branches (whole-wave branch)
-                __builtin_amdgcn_s_setprio(3);
+                // (no issue priority for the inline tier: late in an episode three wavefronts in four take it, and boosting the many
+                // only starves the few -- they became the launch's tail, 8-11 us in their Cholesky stage; the rare out-of-line call keeps it)
                 // second tier, inline: the conic branches for the general orientation (the strong-hyperbolic one -- where a diverged filter
                 // lives -- without a call); third tier, out of line: the complete restatement for rv2coe's special branches and NaN input
                 bool served = kep_ok;
@@ -1173,6 +1189,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
                     if (!kep_ok) served = kepler_conic_lean<1, true>(s, C.dt, o);
                 }
                 if (__any(!served)) {
+                    __builtin_amdgcn_s_setprio(3);
                     if (!served) {
                         Vec6 si;
 #pragma unroll
@@ -1535,6 +1552,28 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
             t.P[g * 36 + idx] = (a == b) ? (a < 3 ? X_FAILED_POS : X_FAILED_VEL) : 0.0;
         }
         if (l < 6) t.X[g * 6 + l] = (l < 3) ? X_FAILED_POS : X_FAILED_VEL;
+        if (p.fail_log && l == 0) {
+            // filter_error()'s record (:369-382): who, why, when, and error_failed() of the state the filter failed FROM (:376-378) -- the
+            // step's inputs, still in HBM (a rare, row-divergent branch: three loads per failing filter)
+            if (ACT::late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the closed loop stores the previous step's tile inside this one)
+            const double* xt = p.x_true_in + obj * 6;
+            const double* xf = p.x_in + obj * 6;
+            const double* Pd = p.P_in + obj * 36;
+            const double a0 = xf[0] - xt[0], a1 = xf[1] - xt[1], a2 = xf[2] - xt[2];
+            const double b0 = xf[3] - xt[3], b1 = xf[4] - xt[4], b2 = xf[5] - xt[5];
+            const unsigned at = atomicAdd(p.fail_count, 1u);
+            if ((int)at < p.fail_cap) {
+                double* rec = p.fail_log + (int64_t)at * SSA_FAIL_STRIDE;
+                rec[SSA_FAIL_ENV] = (double)e;
+                rec[SSA_FAIL_OBJ] = (double)(obj - (int64_t)e * p.n_obj);
+                rec[SSA_FAIL_STATUS] = (double)st_new;
+                rec[SSA_FAIL_TIME] = (double)((ACT::late ? p.env_time[0] : env_time_of<INL>(p, e)) + p.time_offset);
+                rec[SSA_FAIL_ERR + 0] = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+                rec[SSA_FAIL_ERR + 1] = sqrt(b0 * b0 + b1 * b1 + b2 * b2);
+                rec[SSA_FAIL_ERR + 2] = sqrt(Pd[0] + Pd[7] + Pd[14]);
+                rec[SSA_FAIL_ERR + 3] = sqrt(Pd[21] + Pd[28] + Pd[35]);
+            }
+        }
     }
     if (valid && st_in != SSA_ST_OK) {  // already failed: the filter state passes through unchanged (:272)
         if (ACT::late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (its previous state left for HBM earlier in THIS step)
@@ -2216,11 +2255,20 @@ __global__ void residual_kernel(const double* __restrict__ a, const double* __re
     residual_z_aer(aa, bb, cc);
     c[i * 3] = cc[0]; c[i * 3 + 1] = cc[1]; c[i * 3 + 2] = cc[2];
 }
-__global__ void visible_kernel(const double* __restrict__ x, const double* __restrict__ M, GeoK g,
-                               uint8_t* __restrict__ mask, double* __restrict__ el, int64_t n)
+// (tix: optional device word; with it M is the TABLE and the matrix is row (tix[0] + tix_off) % n_time -- for callers inside a captured
+// graph, whose time index lives on the device)
+SSA_DEV const double* matrix_at(const double* M, const int32_t* tix, int32_t tix_off, int32_t n_time)
+{
+    if (!tix) return M;
+    const int t = tix[0] + tix_off;
+    return M + (int64_t)((n_time > 0) ? ((t % n_time) + n_time) % n_time : 0) * 9;
+}
+__global__ void visible_kernel(const double* __restrict__ x, const double* __restrict__ M0, GeoK g,
+                               uint8_t* __restrict__ mask, double* __restrict__ el, int64_t n, const int32_t* __restrict__ tix, int32_t tix_off, int32_t n_time)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const double* M = matrix_at(M0, tix, tix_off, n_time);
     double Mm[9], xx[3], zz[3];
 #pragma unroll
     for (int c = 0; c < 9; ++c) Mm[c] = M[c];
@@ -2354,11 +2402,13 @@ SSA_DEV bool agent_score_rows(const double* __restrict__ xt, const double* __res
     return agent_score_core<WANT>(xtv, xv, A, ld_p, M, g, sc, nullptr);
 }
 __global__ void agent_scores_kernel(const double* __restrict__ xt, const double* __restrict__ x, const double* __restrict__ Pc,
-                                    const double* __restrict__ Pp, const double* __restrict__ M, GeoK g,
-                                    double* __restrict__ scores, uint8_t* __restrict__ mask, int64_t n)
+                                    const double* __restrict__ Pp, const double* __restrict__ M0, GeoK g,
+                                    double* __restrict__ scores, uint8_t* __restrict__ mask, int64_t n, const int32_t* __restrict__ tix,
+                                    int32_t tix_off, int32_t n_time)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const double* M = mask ? matrix_at(M0, tix, tix_off, n_time) : M0;
     double sc[4];
     bool vis;
     if (mask) vis = agent_score_rows<31>(xt, x, Pc, Pp, M, g, i, sc);
@@ -3086,6 +3136,7 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
     if ((p->launch_mask & SSA_LAUNCH_FOLD_INSIDE) &&
         (!p->stat_shards || !p->stats || (p->launch_mask & SSA_LAUNCH_DEFER_FOLD))) return SSA_E_INVALID;
     if (p->spos_tiles && !p->stat_shards) return SSA_E_INVALID;
+    if (p->fail_log && (!p->fail_count || p->fail_cap <= 0)) return SSA_E_INVALID;
     if ((p->spos_tiles || p->spos_tiles_prev) && p->n_env > 1 && (p->n_obj % OBJ_PER_WAVE) != 0) return SSA_E_UNSUPPORTED;   // whole tiles per env
     if (c->obs_type != SSA_OBS_AER && c->obs_type != SSA_OBS_XYZ) return SSA_E_INVALID;
     if (p->aer_cols != 0 && p->aer_cols != 1 && p->aer_cols != 4) return SSA_E_INVALID;
@@ -3406,7 +3457,17 @@ int ssa_visible_mask_f64(const double* x_true, const double* M, const ssa_consts
 {
     if (!x_true || !M || !c || !mask || n < 0) return SSA_E_INVALID;
     if (n == 0) return SSA_OK;
-    hipLaunchKernelGGL(visible_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, x_true, M, make_geo(c), mask, el, n);
+    hipLaunchKernelGGL(visible_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, x_true, M, make_geo(c), mask, el, n,
+                       (const int32_t*)nullptr, 0, 0);
+    return launch_status();
+}
+int ssa_visible_mask_at_f64(const double* x_true, const double* trans, const int32_t* env_time, int32_t time_offset, int32_t n_time,
+                            const ssa_consts* c, uint8_t* mask, double* el, int64_t n, void* stream)
+{
+    if (!x_true || !trans || !env_time || n_time <= 0 || !c || !mask || n < 0) return SSA_E_INVALID;
+    if (n == 0) return SSA_OK;
+    hipLaunchKernelGGL(visible_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, x_true, trans, make_geo(c), mask, el, n,
+                       env_time, time_offset, n_time);
     return launch_status();
 }
 
@@ -3432,7 +3493,17 @@ int ssa_agent_scores_f64(const double* x_true, const double* x_cur, const double
     if (n == 0) return SSA_OK;
     if (!x_true || !x_cur || !P_cur || !scores || !c || n < 0 || (mask && !M)) return SSA_E_INVALID;
     hipLaunchKernelGGL(agent_scores_kernel, dim3(nblk(n, 64)), dim3(64), 0, (hipStream_t)stream, x_true, x_cur, P_cur, P_prev, M,
-                       make_geo(c), scores, mask, n);
+                       make_geo(c), scores, mask, n, (const int32_t*)nullptr, 0, 0);
+    return launch_status();
+}
+int ssa_agent_scores_at_f64(const double* x_true, const double* x_cur, const double* P_cur, const double* P_prev, const double* trans,
+                            const int32_t* env_time, int32_t time_offset, int32_t n_time, const ssa_consts* c, double* scores, uint8_t* mask,
+                            int64_t n, void* stream)
+{
+    if (n == 0) return SSA_OK;
+    if (!x_true || !x_cur || !P_cur || !scores || !c || n < 0 || !trans || !env_time || n_time <= 0 || !mask) return SSA_E_INVALID;
+    hipLaunchKernelGGL(agent_scores_kernel, dim3(nblk(n, 64)), dim3(64), 0, (hipStream_t)stream, x_true, x_cur, P_cur, P_prev, trans,
+                       make_geo(c), scores, mask, n, env_time, time_offset, n_time);
     return launch_status();
 }
 

@@ -18,6 +18,16 @@ constexpr double TWO_PI = 6.283185307179586;
 constexpr double NEWTON_TOL = 1.48e-08;   // farnocchia.py:337
 
 #define SSA_DEV __device__ __forceinline__
+// An optimisation barrier on a double: what follows cannot be contracted with what produced it (under -ffp-contract=fast a pragma inside
+// an inlined function did not keep `scale * p + jit` from becoming ONE fma -- measured: tests/test_hip_step.py::
+// test_ladder_on_the_ill_conditioned_tile).  No instruction: the value merely passes through a register the compiler cannot see into.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SSA_OPAQUE(x) asm volatile("" : "+v"(x))
+#elif defined(__x86_64__)
+#define SSA_OPAQUE(x) asm volatile("" : "+x"(x))
+#else
+#define SSA_OPAQUE(x) asm volatile("" : "+r"(x))
+#endif
 
 SSA_DEV double dot3(const double* a, const double* b) { return fma(a[2], b[2], fma(a[1], b[1], a[0] * b[0])); }
 
@@ -733,7 +743,11 @@ SSA_DEV bool chol6_upper(const double* A, double jit, double* U)
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-        double ajj = A[tri(j, j)] + jit;
+        // (the jitter is ADDED to the entry as given -- dynamics.py:410 cholesky(a + e) -- never fused with a product that formed the entry in
+        // the caller: see scaled_entry in ssa_kernels.hip)
+        double a0 = A[tri(j, j)];
+        SSA_OPAQUE(a0);
+        double ajj = a0 + jit;
 #pragma unroll
         for (int i = 0; i < j; ++i) ajj = fma(-U[tri(i, j)], U[tri(i, j)], ajj);
         ok = ok && (ajj > 0.0);

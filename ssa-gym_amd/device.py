@@ -196,6 +196,31 @@ def agent_scores(x_true, x_cur, P_cur, P_prev, M, consts, want_mask=True):
     return scores, mask
 
 
+def agent_scores_at(x_true, x_cur, P_cur, P_prev, trans, env_time, time_offset, consts):
+    """agent_scores() with the GCRS -> ITRS matrix picked ON THE DEVICE: row (env_time[0] + time_offset) % n_time of the table `trans`
+    (callers inside a captured graph, whose time index the graph advances between replays)."""
+    lib = _lib.load()
+    n = x_cur.shape[0]
+    scores = torch.empty((4, n), dtype=f64, device=x_cur.device)
+    mask = torch.empty(n, dtype=torch.uint8, device=x_cur.device)
+    _lib.check(lib.ssa_agent_scores_at_f64(_chk(x_true, "x_true"), _chk(x_cur, "x_cur"), _chk(P_cur, "P_cur"),
+                                           _chk(P_prev, "P_prev") if P_prev is not None else None, _chk(trans, "trans"),
+                                           _chk(env_time, "env_time", torch.int32), int(time_offset), int(trans.shape[0]), C.byref(consts),
+                                           _chk(scores, "scores"), _chk(mask, "mask", torch.uint8), n, _stream()), "ssa_agent_scores_at_f64")
+    return scores, mask
+
+
+def visible_mask_at(x_true, trans, env_time, time_offset, consts):
+    """visible_mask() with the matrix picked on the device (see agent_scores_at)"""
+    lib = _lib.load()
+    n = x_true.shape[0]
+    mask = torch.empty(n, dtype=torch.uint8, device=x_true.device)
+    _lib.check(lib.ssa_visible_mask_at_f64(_chk(x_true, "x_true"), _chk(trans, "trans"), _chk(env_time, "env_time", torch.int32), int(time_offset),
+                                           int(trans.shape[0]), C.byref(consts), _chk(mask, "mask", torch.uint8), None, n, _stream()),
+               "ssa_visible_mask_at_f64")
+    return mask
+
+
 def masked_argmax(score, mask=None):
     """index of the first maximum of score[mask != 0] (NaN skipped), -1 if nothing is selected."""
     lib = _lib.load()

@@ -78,6 +78,12 @@ class HotPathEngine:
         self._stats_ws = device.stats_workspace(self.E, d)
         self.work = torch.zeros(self._lib.ssa_env_step_work_bytes(self.m, self.E) // 4, dtype=torch.int32, device=d)
         self._p.work, self._p.stat_ws, self._p.launch_mask = self.work.data_ptr(), self._stats_ws.data_ptr(), 0
+        # filter_error()'s records written by the kernels themselves into host-mapped pinned memory (ssa_step_params.fail_log): one record
+        # per filter that fails, capacity = every filter once per episode; the counter is a device word, zeroed with the episode
+        self.fail_log_host = torch.zeros((N, _lib.FAIL_STRIDE), dtype=f64).pin_memory()
+        self.fail_log = self.fail_log_host.numpy()
+        self.fail_count = torch.zeros(1, dtype=torch.int32, device=d)
+        self._p.fail_log, self._p.fail_count, self._p.fail_cap = self.fail_log_host.data_ptr(), self.fail_count.data_ptr(), N
         # statistics accumulators of the atomics path; two sets, alternated when the fold is deferred
         self._shard_sets = torch.zeros((2, self.E, _lib.STAT_SHARDS, _lib.STAT_SHARD_WORDS), dtype=torch.int64, device=d)
         self.stat_shards = self._shard_sets[0]
@@ -109,6 +115,7 @@ class HotPathEngine:
         self.x_filter[slot].copy_(device.as_dev(np.asarray(x_filter).reshape(N, 6), self.dev))
         self.P_filter[slot].copy_(device.as_dev(np.asarray(P_filter).reshape(N, 6, 6), self.dev))
         self.status.zero_()
+        self.fail_count.zero_()
         for e in range(self.E):
             sl = slice(e * self.m, (e + 1) * self.m)
             device.observe(self.x_true[slot, sl], self.x_filter[slot, sl], self.P_filter[slot, sl],
@@ -141,15 +148,17 @@ class HotPathEngine:
         self.metrics[slot].copy_(met)
         self.stats[slot].copy_(st)
         self.status.zero_()
+        self.fail_count.zero_()
 
     def snapshot_state(self, slot):
         """a history slot AND the per-object status words: what a launch that may have to be undone (the persistent closed loop
         when it gives up) restores"""
-        return self.snapshot(slot) + (self.status.clone(),)
+        return self.snapshot(slot) + (self.status.clone(), self.fail_count.clone())
 
     def restore_state(self, slot, snap):
         self.restore(slot, snap[:6])
         self.status.copy_(snap[6])
+        self.fail_count.copy_(snap[7])
 
     # ------------------------------------------------------------------ one step
     def _spos_ptr(self, k):
@@ -363,10 +372,13 @@ class HotPathEngine:
             return
         s = torch.cuda.current_stream().cuda_stream if stream is None else stream
         k, dst, argmax = self._fold_pending
-        rc = self._lib.ssa_stats_fold_spos_f64(self._shard_sets[k].data_ptr(), self._spos_ptr(k) if argmax else 0, dst, self.m, self.E, s)
+        if argmax:
+            rc = self._lib.ssa_stats_fold_spos_f64(self._shard_sets[k].data_ptr(), self._spos_ptr(k), dst, self.m, self.E, s)
+        else:
+            rc = self._lib.ssa_stats_fold_f64(self._shard_sets[k].data_ptr(), dst, self.E, s)
         self._fold_pending = None
         if rc:
-            raise _lib.SsaHipError("ssa_stats_fold_spos_f64 failed with code %d" % rc)
+            raise _lib.SsaHipError("ssa_stats_fold_f64 failed with code %d" % rc)
 
     def set_actions(self, actions):
         a = torch.as_tensor(np.asarray(actions, dtype=np.int32).reshape(self.E))

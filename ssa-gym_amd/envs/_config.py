@@ -8,12 +8,12 @@ _MODELS = {(("hx", "aer"), ("mean_z", "uvw"), ("residual_z", "aer")): 'aer',
 
 
 def resolve_kernel_variant(config):
-    """(measurement model 'aer' | 'xyz', propagator 'fg' | 'elements' | 'j2') of a config dict.
+    """(measurement model 'aer' | 'xyz', propagator 'hybrid' | 'fg' | 'elements' | 'j2') of a config dict.
 
     The propagator comes from config['propagator'] when given, else from the `fx` token (dynamics.fx_xyz_farnocchia
-    -> 'fg', fx_xyz_farnocchia_elements -> 'elements', fx_xyz_j2_rk4 -> 'j2'); the reference's own function object
-    of that name maps to 'fg'.  Foreign callables and hx / mean_z / residual_z combinations without a fused kernel
-    raise NotImplementedError (there is no CPU fallback)."""
+    -> 'hybrid', the behaviour-faithful variant; fx_xyz_farnocchia_fg -> 'fg', fx_xyz_farnocchia_elements -> 'elements',
+    fx_xyz_j2_rk4 -> 'j2'); the reference's own function object of that name maps to 'hybrid'.  Foreign callables and
+    hx / mean_z / residual_z combinations without a fused kernel raise NotImplementedError (there is no CPU fallback)."""
     fx_id = dynamics.kernel_id_of(config['fx'], "fx")
     ids = tuple(dynamics.kernel_id_of(config[k], k) for k in ("hx", "mean_z", "residual_z"))
     dynamics.kernel_id_of(config['msqrt'], "msqrt")
@@ -22,7 +22,7 @@ def resolve_kernel_variant(config):
         raise NotImplementedError("hx/mean_z/residual_z combination %s has no fused kernel" % (ids,))
     if fx_id != ("fx", "farnocchia"):
         raise NotImplementedError("fx %r has no fused kernel" % (config['fx'],))
-    propagator = config.get('propagator', getattr(dynamics.unwrap_partial(config['fx']), 'propagator', 'fg'))
+    propagator = config.get('propagator', getattr(dynamics.unwrap_partial(config['fx']), 'propagator', 'hybrid'))
     if propagator not in ('fg', 'elements', 'j2', 'hybrid'):
         raise NotImplementedError("unknown propagator %r" % (propagator,))
     return model, propagator

@@ -178,9 +178,15 @@ class _FxCowell(_FxFarnocchia):
         return device.propagate_j2(xd, float(dt), j2, r_eq, nsub).cpu().numpy().reshape(6)
 
 
-fx_xyz_farnocchia = _FxFarnocchia('fg')            # default: reduced strong-elliptic form (SSA_PROP_FG)
+# `fx_xyz_farnocchia` -- the env default, what the reference's own token resolves to -- is the BEHAVIOUR-FAITHFUL variant: the series
+# solver on strong-elliptic states, the reference's conic branches elsewhere, the reference's covariance arithmetic (SSA_PROP_HYBRID +
+# SSA_FLAG_REFERENCE_COV): an episode loses filters the way the reference's does (tests/test_episode_failures.py).  Until round 4 the
+# default was the universal-variable form (`fx_xyz_farnocchia_fg` now): more accurate than the reference on diverged states, its filters
+# survive where the reference's fail -- the explicitly named accuracy / speed option.
+fx_xyz_farnocchia = _FxFarnocchia('hybrid')
+fx_xyz_farnocchia_hybrid = fx_xyz_farnocchia
+fx_xyz_farnocchia_fg = _FxFarnocchia('fg')             # every conic through ONE universal-variable equation (SSA_PROP_FG)
 fx_xyz_farnocchia_elements = _FxFarnocchia('elements')  # operation-by-operation variant (SSA_PROP_ELEMENTS)
-fx_xyz_farnocchia_hybrid = _FxFarnocchia('hybrid')  # series solver on strong-elliptic states, the reference's branches elsewhere (SSA_PROP_HYBRID)
 fx_xyz_j2_rk4 = _FxFarnocchia('j2')                # EXTENSION: two-body + J2, RK4 (no reference counterpart)
 fx_xyz_cowell = _FxCowell()                        # envs/dynamics.py:168: Cowell with a pluggable acceleration (default ad_none)
 hx_aer_erfa = _HxAer()

@@ -93,6 +93,41 @@ class _Sparse:
         return np.stack([self[i] for i in range(self.shape[0])])
 
 
+class _FailureMessages:
+    """`failed_filters_msg` of the reference (ssa_tasker_simple_2.py:147, 380): a list of m entries, "None" until filter j fails, then
+    [message].  The message -- 'Object j failed on predict step i, LinAlgError. [dpos dvel spos svel]' -- is FORMATTED WHEN IT IS READ, from the
+    record the kernel wrote at the failure: an episode of the default env loses a few filters per step late on, and formatting each as it
+    happened cost a gym-style step tens of microseconds."""
+    KINDS = {_lib.ST_PREDICT_NAN: ('predict', ', predict returned nan. '), _lib.ST_PREDICT_LINALG: ('predict', ', LinAlgError. '),
+             _lib.ST_UPDATE_NAN: ('update', ', update returned nan. '), _lib.ST_UPDATE_LINALG: ('update', ', LinAlgError. ')}
+
+    def __init__(self, m):
+        self._m, self._rec = int(m), {}
+
+    def record(self, j, step, status, err):
+        self._rec[j] = (step, status, err)
+
+    def __len__(self):
+        return self._m
+
+    def __getitem__(self, j):
+        if isinstance(j, slice):
+            return [self[k] for k in range(*j.indices(self._m))]
+        j = int(j)
+        if j < 0:
+            j += self._m
+        if not 0 <= j < self._m:
+            raise IndexError(j)
+        r = self._rec.get(j)
+        if r is None:
+            return "None"
+        activity, error_type = self.KINDS[r[1]]
+        return ["".join(['Object ', str(j), ' failed on ', activity, ' step ', str(r[0]), error_type, str(np.round(r[2], 2))])]
+
+    def __iter__(self):
+        return (self[j] for j in range(self._m))
+
+
 class SSA_Tasker_Env(Env):
     metadata = {'render.modes': ['live', 'none']}
     visualization = None
@@ -154,7 +189,7 @@ class SSA_Tasker_Env(Env):
         self.filters = []   # the reference keeps one filterpy object per RSO; state lives in HBM here
         self.rewards = np.empty(self.n)
         self.failed_filters_id = []
-        self.failed_filters_msg = ["None"] * self.m
+        self.failed_filters_msg = _FailureMessages(self.m)
         self.actions = np.empty(self.n, dtype=int)
         self.obs_taken = np.empty(self.n, dtype=bool)
         self.x_failed = np.copy(host.X_FAILED)
@@ -275,7 +310,7 @@ class SSA_Tasker_Env(Env):
         self._engine.load_state(0, x_true0, x_filter0, np.broadcast_to(self.P_0, (m, 6, 6)))
         # tracking variables (:222-231)
         self.actions[:], self.obs_taken[:], self.failed_filters_id, self.visibility = -1, False, [], []
-        self.failed_filters_msg = ["None"] * self.m
+        self.failed_filters_msg = _FailureMessages(self.m)
         self.rewards[:] = 0
         self.sigmas_h[:] = 0
         if self.S is not None:
@@ -287,6 +322,9 @@ class SSA_Tasker_Env(Env):
         self.y = _Sparse(self, self._y, (3,))
         self.z_true = _Sparse(self, self._z_true, (3,))
         self._n_failed = 0
+        self._fail_read, self._fail_pending, self._fail_chunk_total = 0, {}, 0      # records of the kernel's failure log consumed so far
+        self._engine.fail_log[:] = 0.0             # (time index 0 = "not written": steps count from 1)
+        self._ring_head = None
         self._argmax_sigma_prev = None
         self.i = 0
         self._fetch_small(0)
@@ -312,6 +350,7 @@ class SSA_Tasker_Env(Env):
         step_s = time.time()
         assert self.action_space.contains(a), "%r (%s) invalid" % (a, type(a))
         self._argmax_sigma_prev = self._argmax_sigma
+        self._ring_head = None
         self.i += 1
         i = self.i
         self.actions[i] = np.copy(a)
@@ -422,9 +461,11 @@ class SSA_Tasker_Env(Env):
             i0 = self.i
             act = torch.as_tensor(actions[pos:pos + kk].astype(np.int32)).view(kk, 1).to(e.dev)
             e.launch_rollout(i0 % e.H, i0 + 1, act, argmax_spos=shaped)
+            self._ring_head = i0 + kk
             slots = [(i0 + 1 + k) % e.H for k in range(kk)]
             stats = e.stats[slots, 0].cpu().numpy()          # synchronises the stream
             upd = e.upd[slots, 0].cpu().numpy()
+            self._fail_chunk_total = int(stats[-1][_lib.STAT_N_FAILED])
             for k in range(kk):
                 self.i += 1
                 i, a = self.i, int(actions[pos + k])
@@ -535,6 +576,8 @@ class SSA_Tasker_Env(Env):
                 stats = e.stats[slots, 0].cpu().numpy()          # synchronises the stream
                 upd = e.upd[slots, 0].cpu().numpy()
             acts = log[pos:pos + kk].cpu().numpy()
+            self._ring_head = i0 + kk
+            self._fail_chunk_total = int(stats[-1][_lib.STAT_N_FAILED])
             for k in range(kk):
                 self.i += 1
                 i, a = self.i, int(acts[k])
@@ -570,18 +613,12 @@ class SSA_Tasker_Env(Env):
         """what a device-side policy sees at decision time: CUDA tensors of the env's CURRENT state (views of the history slot --
         valid until the next step is launched; nothing is copied, nothing crosses PCIe)."""
 
-        def __init__(self, env, i, tix_dev=None):
+        def __init__(self, env, i, tix_off=None):
             self.env, self.i = env, i
-            # inside a captured graph the step's time index lives on the DEVICE (the graph advances it between replays): the GCRS -> ITRS
-            # matrix of the decision is then gathered by it instead of being picked by a host integer that a capture would freeze
-            self._tix_dev = tix_dev
-
-        def _M(self):
-            e = self.env._engine
-            if self._tix_dev is None:
-                return e.trans[self.i % e.n_time].reshape(3, 3)
-            import torch
-            return torch.index_select(e.trans, 0, torch.remainder(self._tix_dev, e.n_time)).reshape(3, 3)
+            # inside a captured graph the step's time index lives on the DEVICE (engine.env_time0, which the graph advances between
+            # replays) and this decision sits `tix_off` steps behind it: the GCRS -> ITRS matrix is then picked by the kernels themselves
+            # (ssa_*_at_f64) instead of by a host integer that a capture would freeze
+            self._tix_off = tix_off
 
         # (views are formed on access: a tensor slice costs the host 1-2 us, and most policies read one or two of them)
         obs = property(lambda s: s.env._engine.obs[s.i % s.env._engine.H])            # [m, 12]: x_filter | diag P   (results.py:61)
@@ -593,12 +630,20 @@ class SSA_Tasker_Env(Env):
         def visible(self):
             """uint8 CUDA mask [m]: object_visibility() of the true states (ssa_tasker_simple_2.py:427-434)"""
             from .. import device
-            return device.visible_mask(self.x_true, self._M(), self.env._consts)
+            e = self.env._engine
+            if self._tix_off is not None:
+                return device.visible_mask_at(self.x_true, e.trans, e.env_time0, self._tix_off, self.env._consts)
+            return device.visible_mask(self.x_true, e.trans[self.i % e.n_time].reshape(3, 3), self.env._consts)
 
         def scores(self):
             """(scores[4, m], mask[m]) of the reference's heuristic agents (trace P, visible, log-det ratio, delta_pos)"""
             from .. import device
-            return device.agent_scores(self.x_true, self.x_filter, self.P_filter, self.P_filter_prev, self._M(), self.env._consts)
+            e = self.env._engine
+            if self._tix_off is not None:
+                return device.agent_scores_at(self.x_true, self.x_filter, self.P_filter, self.P_filter_prev, e.trans, e.env_time0, self._tix_off,
+                                              self.env._consts)
+            return device.agent_scores(self.x_true, self.x_filter, self.P_filter, self.P_filter_prev, e.trans[self.i % e.n_time].reshape(3, 3),
+                                       self.env._consts)
 
     # ---- run_policy as a replayed hipGraph: K x [the policy's kernels + the step launch] captured once, replayed per chunk
     GRAPH_CHUNK = 32
@@ -621,17 +666,19 @@ class SSA_Tasker_Env(Env):
         acts_d = torch.full((K,), -1, dtype=torch.int32, device=e.dev)
         shaped = self.reward_type == 'shaped'
 
+        acts_t = []          # the policy's K action tensors: they live in the graph's memory pool, at the same addresses in every replay
+
         def enqueue():
-            base = e.env_time0.to(torch.int64)
             for k in range(K):
                 i = i0 + k + 1
-                a = policy(self.PolicyView(self, i - 1, tix_dev=base + k))
+                a = policy(self.PolicyView(self, i - 1, tix_off=k))
                 if not (isinstance(a, torch.Tensor) and a.is_cuda and a.dtype == torch.int32 and a.numel() == 1):
                     raise TypeError("run_policy: the policy must return a CUDA int32 tensor with one element (the action)")
-                acts_d[k:k + 1].copy_(a.reshape(1))
-                e.launch_step((i - 1) % e.H, i % e.H, k + 1, actions_ptr=acts_d.data_ptr() + 4 * k, fast_stats=True, defer_fold=True,
+                acts_t.append(a)          # (read by the step below; gathered into acts_d ONCE per replay, behind the graph)
+                e.launch_step((i - 1) % e.H, i % e.H, k + 1, actions_ptr=a.data_ptr(), fast_stats=True, defer_fold=True,
                               stats_out=stats_d[k].data_ptr(), upd_out=upd_d[k].data_ptr(), argmax_spos=shaped)
             e.flush_stats()
+            torch.cat([a.reshape(1) for a in acts_t], out=acts_d)
             e.env_time0.add_(K)
         stream = torch.cuda.Stream(device=e.dev)
         g = torch.cuda.CUDAGraph()
@@ -701,6 +748,8 @@ class SSA_Tasker_Env(Env):
             upd = upd_d.cpu().numpy()
             acts = acts_d.cpu().numpy()
             e.env_time0.zero_()
+            self._ring_head = i0 + G
+            self._fail_chunk_total = int(stats[-1][_lib.STAT_N_FAILED])
             for k in range(G):
                 self.i += 1
                 i, a = self.i, int(acts[k])
@@ -739,6 +788,8 @@ class SSA_Tasker_Env(Env):
             upd = upd_d.cpu().numpy()
             acts = torch.cat([a.reshape(1) for a in acts_d]).cpu().numpy()
             self.i = i0
+            self._ring_head = i0 + kk
+            self._fail_chunk_total = int(stats[-1][_lib.STAT_N_FAILED])
             for k in range(kk):
                 self.i += 1
                 i, a = self.i, int(acts[k])
@@ -762,30 +813,36 @@ class SSA_Tasker_Env(Env):
 
     # ------------------------------------------------------------------ failures (:369-382)
     def _record_failures(self, at_step=None):
-        """filter_error() bookkeeping (:369-382) for the filters that failed in step self.i.  Inside a rollout launch
-        (at_step given) the device status already reflects LATER steps of the launch as well: only the objects whose
-        state carries the failure sentinel in history slot `at_step` have failed by then."""
+        """filter_error() bookkeeping (:369-382) for the filters that failed in step self.i (at_step: the step being booked after a rollout
+        / closed-loop / policy launch that ran several).  The KERNEL wrote the records -- object, status code, step, error_failed() of the
+        state it failed from -- into host-mapped memory (ssa_step_params.fail_log) as the filters failed: nothing is copied here.  The
+        reference loses 2-3 % of its filters over an episode (and so does this env's default, the behaviour-faithful variant): a few per
+        step late in an episode."""
         s = time.time()
-        status = self._engine.status.cpu().numpy()
-        if at_step is not None:
-            status = np.where(self.x_filter[at_step][:, 0] == host.X_FAILED[0], status, 0)
-        kinds = {_lib.ST_PREDICT_NAN: ('predict', ', predict returned nan. '),
-                 _lib.ST_PREDICT_LINALG: ('predict', ', LinAlgError. '),
-                 _lib.ST_UPDATE_NAN: ('update', ', update returned nan. '),
-                 _lib.ST_UPDATE_LINALG: ('update', ', LinAlgError. ')}
-        for j in np.where(status != 0)[0]:
-            j = int(j)
-            if j in self.failed_filters_id:
-                continue
-            activity, error_type = kinds[int(status[j])]
-            prev = self.i - 1
-            msg = ["".join(['Object ', str(j), ' failed on ', activity, ' step ', str(self.i), error_type,
-                            str(np.round(error_failed(state=self.x_true[prev, j], x=self.x_filter[prev, j],
-                                                      P=np.diag(self.P_filter[prev, j])), 2))])]
-            self.failed_filters_msg[j] = copy(msg)
-            self.failed_filters_id.append(j)
+        e = self._engine
+        step = self.i if at_step is None else at_step
+        total = int(self._stats[_lib.STAT_N_FAILED])               # filters failed by the END of `step`
+        # records appended since the last call (a multi-step launch appends in the order its wavefronts reach the failures, not by step)
+        n_dev = max(total, self._fail_read) if at_step is None else self._fail_chunk_total
+        while self._fail_read < n_dev:
+            r = e.fail_log[self._fail_read]
+            if r[_lib.FAIL_TIME] == 0.0:         # (not written: a status word set from outside the kernels is counted in the statistics but has no record)
+                break
+            self._fail_pending.setdefault(int(r[_lib.FAIL_TIME]), []).append(r.copy())
+            self._fail_read += 1
+        for t in sorted(k for k in self._fail_pending if k <= step):
+            for r in self._fail_pending.pop(t):
+                j = int(r[_lib.FAIL_OBJ])
+                self.failed_filters_msg.record(j, t, int(r[_lib.FAIL_STATUS]), r[_lib.FAIL_ERR:_lib.FAIL_ERR + 4])
+                self.failed_filters_id.append(j)
         self._n_failed = len(self.failed_filters_id)
         self.runtime['filter_error'] += time.time() - s
+
+    def _latest_resident(self):
+        """the newest step the device history holds (a rollout / closed-loop launch has advanced the rings beyond self.i while the
+        host is still booking its steps one by one)"""
+        head = getattr(self, "_ring_head", None)
+        return self.i if head is None else head
 
     def anees(self):
         """:436-446 -- average normalised estimation error squared over the episode so far: NEES on the device for every

@@ -364,9 +364,16 @@ def test_vector_env_honours_the_fx_token(envs, fx_name, prop):
         assert np.array_equal(vec.x_true(0), one.x_true[k])                      # truth: the propagator alone
         never = np.array([j not in [kk % 9 for kk in range(1, k + 1)] for j in range(9)])
         assert np.array_equal(vec.x_filter(0)[never], one.x_filter[k][never])    # predict-only objects: bit-identical
-    # and the default token still means FG, for both classes
+    # the default token means the behaviour-faithful variant (series solver + the reference's conic branches + the reference's covariance
+    # arithmetic), for both classes; the universal-variable form is the explicitly named option
     cfg['fx'] = D.fx_xyz_farnocchia
-    assert SSA_Tasker_VecEnv(cfg, 1, seed=5)._consts.propagator == _lib.PROP_FG
+    for env_ in (SSA_Tasker_VecEnv(cfg, 1, seed=5), envs.make(config=cfg)):
+        assert env_._consts.propagator == _lib.PROP_HYBRID and env_._consts.flags & _lib.FLAG_REFERENCE_COV
+    cfg['fx'] = D.fx_xyz_farnocchia_fg
+    for env_ in (SSA_Tasker_VecEnv(cfg, 1, seed=5), envs.make(config=cfg)):
+        assert env_._consts.propagator == _lib.PROP_FG and not env_._consts.flags & _lib.FLAG_REFERENCE_COV
+    assert envs.make(config=dict(cfg, fx=D.fx_xyz_farnocchia, propagator='fg'))._consts.propagator == _lib.PROP_FG      # config['propagator'] wins
+    cfg['fx'] = D.fx_xyz_farnocchia
     bad = dict(cfg)
     bad.update(hx=D.hx_xyz)                       # xyz measurement with the aer mean / residual: no fused kernel
     with pytest.raises(NotImplementedError):

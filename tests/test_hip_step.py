@@ -360,70 +360,84 @@ def test_fused_ladder_picks_the_reference_rung_for_every_rung(hip, oracle_ld):
     assert dP.min() > 2e-3, dP.min()       # (20 x the tolerance: a rung off by one cannot hide)
 
 
-def test_ladder_first_success_on_the_non_monotone_case(hip, oracle):
-    """robust_cholesky's answer is the FIRST rung that factorises (dynamics.py:406-414) -- also where success is not monotone in the
-    jitter.  tests/golden/ladder_nonmonotone.npz is the prior covariance on which round 3's two-pass search (reverted) parted from the
-    sequential ladder: (n + lambda) P with condition 1e20, the low rungs decided by the last bits of the pivots.  ssa_ladder_probe_f64
-    runs the fused kernels' ladder (robust_chol_row_lds) on it and reports, per rung, whether it factorises in that arithmetic:
-      * the fused rung IS the lowest rung that factorises -- for this matrix, for its neighbours under one-ulp perturbations (each a
-        different realisation of the rounding noise) and for every position in the wavefront's four rows;
-      * among those realisations the mask is non-monotone at least once (a rung fails above one that succeeds), and the two-pass rule
-        applied to the same masks picks another rung there -- the failure the round-3 tests missed;
-      * the sequential register ladder (ssa_robust_cholesky6_f64: IEEE square roots and divisions, another rounding realisation) and
-        the oracle agree with the fused kernel wherever the decision is not within rounding (their own rung factorises in the fused
-        arithmetic too, or is adjacent to it)."""
-    g = golden("ladder_nonmonotone.npz")
+def test_ladder_on_the_ill_conditioned_tile(hip, oracle):
+    """robust_cholesky's answer is the FIRST rung that factorises (dynamics.py:406-414), of the matrix the reference factorises:
+    round((n + lambda) P) + jitter, two roundings (:410).  tests/golden/ladder_illconditioned_tile.npz is the wavefront (four prior
+    covariances) at which round 3's two-pass ladder build parted from the sequential one over an episode: (n + lambda) P of its row 1 has
+    condition 1e20.  ssa_ladder_probe_f64 runs the fused kernels' ladder on it and reports, per rung, whether it factorises in that
+    arithmetic:
+      * the fused rung IS the lowest rung that factorises -- for this tile (rung 1: the plain attempt and rung 0 fail), for 4 096 one-ulp
+        perturbations of it (each a different realisation of the rounding noise) and whatever the neighbours in the wavefront are;
+        success is monotone in the jitter in every one of them (round 3's explanation of the two-pass failure does not hold: the two-pass
+        rule applied to these masks picks the same rungs);
+      * THE PIN: the factor the ladder leaves is bit for bit the plain factor of the matrix round(scale * P) + jitter * I formed on the
+        host in two roundings -- not of the fused fma(scale, P, jitter), which differs from it in a diagonal entry of this matrix and whose
+        factor differs in its last rows by ~1e-8 relative (computed here: that is how two builds of the same source parted);
+      * the sequential register ladder (ssa_robust_cholesky6_f64: IEEE square roots and divisions, another rounding realisation) and the
+        oracle pick the same rung on this tile, and rungs within the noise band on the perturbed ensemble."""
+    from fractions import Fraction
+    g = golden("ladder_illconditioned_tile.npz")
     _, _, scale = orc.merwe_weights(1e-4, 2.0, -3)
+    P4 = g["P_tile"]
+    j = int(g["obj"]) % 4
+    rung, mask, U = hip.dev.ladder_probe(hip.dev.as_dev(P4), scale)
+    rung, mask, U = rung.cpu().numpy(), mask.cpu().numpy(), U.cpu().numpy()
+    assert rung.tolist() == [-1, 1, -1, -1] and j == 1
+    assert (mask[j] >> 16) & 1 == 0 and (mask[j] & 0xFFFF) == 0xFFFE           # plain and rung 0 fail, rungs 1 .. 15 factorise: monotone
+    # ---- the pin: two roundings
+    jit = 10.0 ** (int(rung[j]) - 6)
+    A2 = scale * P4[j] + jit * np.eye(6)                                       # numpy: round(scale * p), then + jitter -- the reference's arithmetic
+    fused = np.array([[float(Fraction(scale) * Fraction(float(P4[j][r, c])) + (Fraction(jit) if r == c else 0)) for c in range(6)] for r in range(6)])
+    assert (np.diag(A2) != np.diag(fused)).any() and np.array_equal(A2 - np.diag(np.diag(A2)), fused - np.diag(np.diag(fused)))
+    tile = np.stack([np.eye(6), A2, fused, np.eye(6)])
+    r1, m1, U1 = hip.dev.ladder_probe(hip.dev.as_dev(tile), 1.0)              # scale 1: the plain attempt factorises the matrix as given
+    r1, U1 = r1.cpu().numpy(), U1.cpu().numpy()
+    assert r1.tolist() == [-1, -1, -1, -1]
+    assert np.array_equal(U1[1].view(np.int64), U[j].view(np.int64))           # the ladder's factor == the factor of the two-rounding matrix
+    rel = np.abs(U1[2] - U1[1])[3:, 3:].max() / np.abs(U1[1])[3:, 3:].max()
+    print("[ladder] tile of object %d at step %d: rung %s; diagonal entries where fma(scale, p, jit) != round(scale p) + jit: %d of 6; the fused matrix's "
+          "factor differs from the reference-arithmetic one by %.1e relative in its last rows" % (int(g["obj"]), int(g["step"]), rung.tolist(),
+                                                                                               int((np.diag(A2) != np.diag(fused)).sum()), rel))
+    assert 1e-12 < rel < 1e-4                                                  # (one rounding, amplified by the conditioning)
+    M0 = scale * P4[j] + jit * np.eye(6)
+    assert np.abs(U[j].T @ U[j] - M0).max() <= 4e-16 * np.abs(M0).max() and np.allclose(np.tril(U[j], -1), 0.0)
+    # ---- first success over an ensemble of rounding realisations; monotone masks; every position in the wavefront
     rs = np.random.RandomState(271)
     n_pert = 4096
-    P = np.tile(g["P"], (n_pert, 1, 1))
+    P = np.tile(P4[j], (n_pert, 1, 1))
     ulp = 2.220446049250313e-16
     for k in range(1, n_pert):          # symmetric one-ulp perturbations; entry 0 is the captured matrix itself
         e = rs.randint(-1, 2, size=(6, 6))
         e = np.triu(e) + np.triu(e, 1).T
         P[k] = P[k] * (1.0 + ulp * e)
-    A = hip.dev.as_dev(P)
-    rung, mask, U = hip.dev.ladder_probe(A, scale)
-    rung, mask = rung.cpu().numpy(), mask.cpu().numpy()
-    first = np.array([16 if (m & 0xFFFF) == 0 else int(m & 0xFFFF & -(m & 0xFFFF)).bit_length() - 1 for m in mask])
-    plain = (mask >> 16) & 1
-    want = np.where(plain == 1, -1, first)
-    assert np.array_equal(rung, want), (np.where(rung != want)[0][:8], rung[:8], want[:8])
-    # the factor the kernel leaves is the factor of the rung it reports
-    k0 = int(rung[0])
-    assert 0 <= k0 < 16
-    U0 = U[0].cpu().numpy()
-    M0 = scale * g["P"] + 10.0 ** (k0 - 6) * np.eye(6)
-    assert np.abs(U0.T @ U0 - M0).max() <= 1e-9 * np.abs(M0).max() and np.allclose(np.tril(U0, -1), 0.0)
-    # non-monotone realisations exist, and the two-pass rule fails on them
-    m16 = mask & 0xFFFF
+    rg, mk, _ = hip.dev.ladder_probe(hip.dev.as_dev(P), scale)
+    rg, mk = rg.cpu().numpy(), mk.cpu().numpy()
+    m16 = mk & 0xFFFF
+    first = np.array([16 if m == 0 else int(m & -m).bit_length() - 1 for m in m16])
+    want = np.where((mk >> 16) & 1 == 1, -1, first)
+    assert np.array_equal(rg, want), (np.where(rg != want)[0][:8], rg[:8], want[:8])
+    nonmono = np.array([first[i] < 16 and int(m16[i]) != (0xFFFF >> first[i]) << first[i] for i in range(n_pert)])
+
     def two_pass(m):
         for grp in range(4):
             if (m >> (4 * grp + 3)) & 1:
                 return next(i for i in range(4 * grp, 4 * grp + 4) if (m >> i) & 1)
         return 16
-    nonmono = np.array([bool(((m >> (first[i] + 1)) ^ ((1 << (15 - first[i])) - 1)) & ((1 << (15 - first[i])) - 1)) if first[i] < 15 else False
-                        for i, m in enumerate(m16)])
     tp = np.array([two_pass(int(m)) for m in m16])
-    print("[ladder] captured case: fused rung %d, mask %s; %d of %d one-ulp realisations are non-monotone; the two-pass search differs on %d"
-          % (k0, format(int(m16[0]), '016b')[::-1], nonmono.sum(), n_pert, (tp != first).sum()))
-    assert nonmono.any() and (tp != first).any()
-    assert bool(nonmono[0]) or bool((tp != first)[0]) or (tp != first).sum() >= 1
-    # the other two implementations of the ladder: another rounding realisation each
+    print("[ladder] %d one-ulp realisations: rungs %s; non-monotone masks %d; the two-pass rule differs on %d"
+          % (n_pert, dict(zip(*np.unique(rg, return_counts=True))), nonmono.sum(), (tp != first).sum()))
+    assert not nonmono.any() and np.array_equal(tp, first)
     rung_seq = hip.dev.robust_cholesky(hip.dev.as_dev(scale * P))[1].cpu().numpy()
     rung_orc = np.array([oracle.robust_cholesky(scale * Pk)[1] for Pk in P[:256]])
+    assert rung_seq[0] == rg[0] == rung_orc[0] == 1
     for name, other in (("sequential register ladder", rung_seq), ("oracle", rung_orc)):
-        r = rung[:len(other)]
-        same = np.mean(other == r)
-        near = np.mean(np.abs(other - r) <= 4)
-        print("[ladder] %s: same rung as the fused kernel on %.3f of the realisations, within the noise band (4 rungs) on %.3f" % (name, same, near))
-        assert near == 1.0          # all decisions inside the band where the jitter is below the pivots' rounding noise
-    # every row of the wavefront gives the same answer for the same matrix (the one-pass ladder serves the four rows side by side)
-    Q = np.tile(g["P"], (8, 1, 1))
-    Q[1::2] = np.diag([1e10] * 3 + [1e4] * 3)          # healthy neighbours in between
-    r2, m2, _ = hip.dev.ladder_probe(hip.dev.as_dev(Q), scale)
-    r2 = r2.cpu().numpy()
-    assert np.all(r2[0::2] == k0) and np.all(r2[1::2] == -1)
+        r = rg[:len(other)]
+        print("[ladder] %s: same rung as the fused kernel on %.3f of the realisations" % (name, np.mean(other == r)))
+        assert np.abs(other - r).max() <= 4          # all decisions inside the band where the jitter is below the pivots' rounding noise
+    Q = np.tile(P4[j], (8, 1, 1))
+    Q[1::2] = np.diag([1e10] * 3 + [1e4] * 3)          # healthy neighbours in between: every row position
+    r2 = hip.dev.ladder_probe(hip.dev.as_dev(Q), scale)[0].cpu().numpy()
+    assert np.all(r2[0::2] == 1) and np.all(r2[1::2] == -1)
 
 
 def test_argmax_sigma_pos_on_every_one_launch_path(hip):
