@@ -750,8 +750,12 @@ def main():
         if os.path.exists(tj):      # (PMC passes cannot run inside this process: the figure is the committed profile's, labelled as such)
             try:
                 tjd = json.load(open(tj))
-                traffic = tjd.get("%s_%d" % (args.propagator, m))
-                traffic_src = "profiles/traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, NOT measured in this run" % tjd.get("collected", "committed profile")
+                tkey = "%s_%d" % (args.propagator, m)
+                traffic = tjd.get(tkey)
+                rnd = tjd.get("collected", {})
+                rnd = rnd.get(tkey, "committed profile") if isinstance(rnd, dict) else rnd
+                traffic_src = ("profiles/traffic.json[%s] (collected in %s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, NOT measured "
+                               "in this run" % (tkey, rnd)) if traffic is not None else None
             except Exception:  # noqa: BLE001
                 traffic = None
         fp64_tflops = FP64_FLOP_PER_OBJECT_STEP * m / (kern_ms * 1e-3) / 1e12

@@ -7,6 +7,7 @@ TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
+export TAG
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $R/bench.py --steps 958 --warmup 0 --no-cpu-baseline --no-legs --rollout 60 > $OUT/prof_bench.json 2> $OUT/prof.err
 for c in FETCH_SIZE WRITE_SIZE; do

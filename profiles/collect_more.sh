@@ -8,6 +8,7 @@ TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/${TAG}_more
 mkdir -p $OUT
+export TAG
 cd /tmp && export TMPDIR=/tmp
 for cfg in "fg 160000" "j2 20000" "elements 20000" "hybrid 20000"; do
   set -- $cfg; export PROP=$1 M=$2

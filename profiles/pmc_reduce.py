@@ -22,14 +22,18 @@ fs = fe['step'][20:]; ws = wr['step'][20:]
 f = sum(fs) / len(fs) * 1024; w = sum(ws) / len(ws) * 1024
 cf = out['calib_observe']['fetch_ratio']; cw = out['calib_observe']['write_ratio']
 out['step_raw'] = {'fetch_counter_bytes': f, 'write_counter_bytes': w, 'launches': len(fs)}
-key = '%s_%s' % (os.environ.get('PROP', 'fg'), os.environ.get('M', '20000'))
+key = '%s_%s' % (os.environ.get('PROP', 'hybrid'), os.environ.get('M', '20000'))     # (pmc_workload.py's defaults: the env default variant)
 out[key] = round(f / cf + w / cw)      # corrected HBM(+Infinity-Cache-side) bytes per launch
-out['algorithmic_bytes'] = 896 * 20000
+out['algorithmic_bytes'] = 896 * int(os.environ.get('M', '20000'))
 print(json.dumps(out, indent=1))
+# every configuration is merged into the committed file under its own key (bench.py looks its own key up); `collected` says which round's
+# passes each key comes from (TAG = the round, as collect.sh passes it)
 dst = os.path.join(ROOT, 'profiles', 'traffic.json')
-if key != 'fg_20000' and os.path.exists(dst):      # the other configurations are merged into the file (bench.py looks its own key up)
-    old = json.load(open(dst))
-    old[key] = out[key]
-    old.setdefault('other_configurations', {})[key] = {'step_raw': out['step_raw'], 'calib_observe': out['calib_observe']}
-    out = old
-json.dump(out, open(dst, 'w'), indent=1)
+old = json.load(open(dst)) if os.path.exists(dst) else {}
+old[key] = out[key]
+old.setdefault('other_configurations', {})[key] = {'step_raw': out['step_raw'], 'calib_observe': out['calib_observe'], 'calib_propagate': out['calib_propagate']}
+if not isinstance(old.get('collected'), dict):
+    old['collected'] = {}
+old['collected'][key] = os.environ.get('TAG', 'unlabelled')
+old['algorithmic_bytes_20000'] = 896 * 20000
+json.dump(old, open(dst, 'w'), indent=1)

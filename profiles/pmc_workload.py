@@ -19,7 +19,7 @@ from ssa_gym_amd import host, engine, parallel, device
 
 m = int(os.environ.get('M', '20000'))            # M / PROP: the other configurations of profiles/traffic.json (collect_more.sh)
 pb = bench.build_problem(m, seed=100)
-consts = host.make_consts(pb["Q"], pb["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, pb["obs_lla"], obs_type='aer', propagator=os.environ.get('PROP', 'fg'))
+consts = host.make_consts(pb["Q"], pb["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, pb["obs_lla"], obs_type='aer', propagator=os.environ.get('PROP', 'hybrid'))
 z = torch.zeros((1, 480, m, 3), dtype=torch.float64, device='cuda')
 eng = engine.HotPathEngine(consts, m, 1, pb["trans"], z, history=2)
 eng.load_state(0, pb["x_true"], pb["x"], np.broadcast_to(pb["P0"], (m, 6, 6)))
