@@ -365,8 +365,13 @@ def torch_policy_rate(m, n=192):
             a, _, _ = env.run_policy(pol, n, graph=graph)
             picked.extend(a.tolist())
         return timed_repeats(block, lambda: None, prepare=prepare)
+    def policy_head(view):          # the same rule with the env's one-launch arg-max head instead of torch.where + torch.argmax + a cast
+        sc, mask = view.scores()
+        return view.argmax(sc[0], mask)
     el0, _, _, _ = measure(fixed_policy, False)     # the env's side alone: a policy that returns a preallocated tensor
+    elg0, _, _, _ = measure(fixed_policy, True)
     ele, _, _, _ = measure(policy, False)
+    elh, _, _, _ = measure(policy_head, True)
     picked.clear()
     el, lo, hi, reps = measure(policy, True)
     dt = el / n
@@ -376,9 +381,15 @@ def torch_policy_rate(m, n=192):
                       "note": "the same policy with every kernel enqueued from the host (run_policy(graph=False): round 3's form)"},
             "env_side_only": {"value": round(n / el0 * (m / 20000.0), 2), "ms_per_step": round(1e3 * el0 / n, 5),
                               "note": "eager, with a policy that returns a preallocated tensor: what run_policy itself costs (step launch + bookkeeping)"},
+            "env_side_only_graph": {"value": round(n / elg0 * (m / 20000.0), 2), "ms_per_step": round(1e3 * elg0 / n, 5),
+                                    "note": "the same from replayed graphs: the step launches alone, bookkeeping of chunk c hidden behind chunk c + 1"},
+            "argmax_head": {"value": round(n / elh * (m / 20000.0), 2), "ms_per_step": round(1e3 * elh / n, 5),
+                            "note": "graph replay; the policy = view.scores() + view.argmax(score, mask) (PolicyView.argmax: the arg-max head as ONE launch of the "
+                                    "library, np.argmax semantics) instead of torch.where + torch.argmax + .to(int32), which are 4 launches and 25 us of the 45 a step "
+                                    "of the torch expression keeps the GPU busy (profiles/r04_run_policy_timeline.txt)"},
             "note": "SSA_Tasker_Env.run_policy(): %d steps per call = %d replays of a 32-step hipGraph holding, per step, the policy's torch kernels "
                     "(scores kernel + where + argmax + cast) and the step launch that reads their action word from device memory; the time index "
-                    "advances on the device; bookkeeping of the steps on the host after each chunk" % (n, n // 32)}
+                    "advances on the device; the host books chunk c while the GPU runs chunk c + 1" % (n, n // 32)}
 
 
 def vec_env_rate(m, E=8, n=60, obs_device=False, zero_copy=False):
@@ -621,7 +632,9 @@ def main():
     graph_note = None
     # (more than one rank: opt-in with SSA_BENCH_GRAPH_SHARDED=1 -- the capture of RCCL's collective has only ever run on ONE rank here,
     # the per-step enqueue is the form the multi-rank logic was built and tested around)
-    want_graph = not args.eager_sharded and (world == 1 or os.environ.get("SSA_BENCH_GRAPH_SHARDED") == "1")
+    # (the peer-store exchange is plain kernels: its units are captured at any world size)
+    want_graph = not args.eager_sharded and (world == 1 or os.environ.get("SSA_BENCH_GRAPH_SHARDED") == "1"
+                                             or (sharded is not None and sharded._peer is not None))
     if sharded is not None and want_graph and divs:
         unit = max(divs)
         cyc = np.arange(plan.m_total)
@@ -629,7 +642,7 @@ def main():
         try:
             if os.environ.get("SSA_BENCH_FORCE_GRAPH_FAIL"):      # (rehearsal of the fallback)
                 raise RuntimeError("forced")
-            for ov in ((False, True) if (world > 1 or os.environ.get("SSA_BENCH_PROBE_OVERLAP")) else (False,)):
+            for ov in ((False, True) if ((world > 1 or os.environ.get("SSA_BENCH_PROBE_OVERLAP")) and sharded._peer is None) else (False,)):
                 local.reset_episode(snap, ep_len)
                 gs = parallel.GraphedShardedSteps(sharded, unit, cyc, overlap=ov)
                 gs.rewind()
@@ -871,8 +884,10 @@ def main():
                        "propagator": args.propagator, "parallelism": "object-shard x%d" % world,
                        "allgather": (("comm-stream (overlapped with the next step)" if state["overlap"] else "in-stream")
                                      if use_dist else None),
-                       "allgather_api": (("RCCL ncclAllGather enqueued directly in the compute/communication stream"
-                                          if sharded._rccl is not None else "torch.distributed.all_gather_into_tensor")
+                       "allgather_api": (("direct peer stores through hipIpc-mapped pointers (ssa_peer_push_f64 / ssa_peer_wait: plain kernels, no collective; "
+                                           "SSA_ALLGATHER=peer)" if sharded._peer is not None else
+                                           "RCCL ncclAllGather enqueued directly in the compute/communication stream"
+                                           if sharded._rccl is not None else "torch.distributed.all_gather_into_tensor")
                                          if sharded is not None else None),
                        "allgather_warmup_probe": allgather_probe,
                        "sharded_enqueue": (("hipGraph replay, %d steps per graph (episodes of whole units)" % graphed.U) if graphed is not None

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SSA_ABI_VERSION 21
+#define SSA_ABI_VERSION 22
 #define SSA_INLINE_ENVS 8
 
 /* error codes */
@@ -429,6 +429,23 @@ typedef struct ssa_closed_loop_params {
                                      give-up path (tests/test_env_gpu.py): the grid must drain, `error` must be set, later launches must work */
 int ssa_env_closed_loop_f64(const ssa_consts *c_host, const ssa_step_params *first, const ssa_closed_loop_params *r, void *stream);
 int64_t ssa_closed_loop_workspace_bytes(int64_t n_obj, int32_t n_env);
+
+/* ------------------------------------------------ all-gather by direct peer stores (SURVEY 8e "Collective")
+ * The reference runs one env per process and has no exchange step; the sharded env of this library (one env's objects spread over the
+ * GPUs of a node) reassembles every step's observation block + statistics words on every rank.  These two entry points do that without a
+ * collective library: after the step kernel of step k a rank PUSHES its payload (n_words doubles at src) into the slot it owns in each of
+ * n_peer receive buffers -- dst[r], device pointers the host obtained once by mapping every peer's buffer over hipIpc (its own buffer
+ * included: dst of the own rank is a local pointer) -- and then stores the step number into flag[r] (release, system scope).  A consumer
+ * WAITS until the n_src flag words of its own buffer have reached the step number.  The step number of a launch is seq_base[0] + seq_off:
+ * seq_base lives in device memory so that a replayed hipGraph can advance it (as ssa_step_params.env_time does for the time index).
+ * Plain kernels: capturable at any world size, no rendezvous inside the launch, no RCCL communicator.  The wait is bounded: a source that
+ * has not arrived after timeout_ticks of the 100 MHz wall clock (0 = 2 s) sets error[0] = 1 + its index (if error != NULL) and the kernel
+ * ends.  Flags only grow; the caller rotates >= 2 receive buffers (ssa-gym_amd/parallel.py: 3) and pushes step k only after it has waited
+ * for step k - 1 of every peer (their readers of the slot being overwritten have then passed, in their stream order). */
+int ssa_peer_push_f64(const double *src, int64_t n_words, double *const *dst, uint64_t *const *flag, int32_t n_peer,
+                      const uint64_t *seq_base, uint64_t seq_off, void *stream);
+int ssa_peer_wait(const uint64_t *flags, int32_t n_src, const uint64_t *seq_base, uint64_t seq_off, int64_t timeout_ticks, int32_t *error,
+                  void *stream);
 
 /* library identification */
 int ssa_abi_version(void);

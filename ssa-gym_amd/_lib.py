@@ -60,7 +60,7 @@ class ssa_closed_loop_params(C.Structure):
 
 # constants of include/ssa_hip.h
 E_INVALID, E_LAUNCH, E_UNSUPPORTED = -1, -2, -3
-ABI_VERSION = 21
+ABI_VERSION = 22
 ST_OK, ST_PREDICT_NAN, ST_PREDICT_LINALG, ST_UPDATE_NAN, ST_UPDATE_LINALG = range(5)
 OBS_AER, OBS_XYZ = 0, 1
 PROP_ELEMENTS, PROP_FG, PROP_J2_RK4, PROP_HYBRID = 0, 1, 2, 3
@@ -110,6 +110,8 @@ SIGNATURES = {
     "ssa_visible_mask_at_f64": (C.c_int, [c_dp, c_dp, c_dp, C.c_int32, C.c_int32, C.POINTER(ssa_consts), c_dp, c_dp, C.c_int64, c_dp]),
     "ssa_agent_scores_at_f64": (C.c_int, [c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int32, C.c_int32, C.POINTER(ssa_consts), c_dp, c_dp, C.c_int64, c_dp]),
     "ssa_masked_argmax_f64": (C.c_int, [c_dp, c_dp, C.c_int64, c_dp, c_dp]),
+    "ssa_peer_push_f64": (C.c_int, [c_dp, C.c_int64, c_dp, c_dp, C.c_int32, c_dp, C.c_uint64, c_dp]),
+    "ssa_peer_wait": (C.c_int, [c_dp, C.c_int32, c_dp, C.c_uint64, C.c_int64, c_dp, c_dp]),
     "ssa_aer_obs_f64": (C.c_int, [c_dp, c_dp, c_dp, C.POINTER(ssa_consts), c_dp, C.c_int64, c_dp]),
     "ssa_agent_select_f64": (C.c_int, [C.POINTER(ssa_consts), C.c_int32, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int32, C.c_int32,
                                        c_dp, c_dp, c_dp, c_dp, C.c_int64, C.c_int32, c_dp]),

@@ -3087,6 +3087,53 @@ static inline int launch_status()
 }
 static inline unsigned nblk(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
+
+// ---- all-gather by direct peer stores (SURVEY 8e "Collective"): every rank writes its payload of one step straight into the slot it owns
+// in every peer's receive buffer (pointers mapped once over hipIpc, host side: ssa-gym_amd/peer.py) and then raises a per-source flag word
+// next to it; a consumer waits for the flags of the step it wants.  Nothing here is a collective: no communicator, no rendezvous inside the
+// launch, plain kernels a hipGraph captures at any world size.  The step number a launch stands for is seq_base[0] + seq_off (seq_base in
+// device memory: a replayed graph advances it on the device, as the time index of the step launches).
+//   ordering: every lane's stores, a system-scope fence, the workgroup barrier, then ONE release store of the flag (system scope): a peer
+//   that reads the flag >= seq with an acquire load sees the whole payload.  Flags only grow (a 64-bit step counter).
+__global__ void __launch_bounds__(1024) peer_push_kernel(const double* __restrict__ src, int64_t n_words, double* const* __restrict__ dst,
+                                                         unsigned long long* const* __restrict__ flag,
+                                                         const unsigned long long* __restrict__ seq_base, unsigned long long seq_off)
+{
+    double* __restrict__ d = dst[blockIdx.x];
+    const int64_t n2 = n_words >> 1;
+    const bool wide = ((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
+    if (wide) {
+        const double2* __restrict__ s2 = reinterpret_cast<const double2*>(src);
+        double2* __restrict__ d2 = reinterpret_cast<double2*>(d);
+        for (int64_t i = threadIdx.x; i < n2; i += blockDim.x) d2[i] = s2[i];
+        if ((n_words & 1) && threadIdx.x == 0) d[n_words - 1] = src[n_words - 1];
+    } else {
+        for (int64_t i = threadIdx.x; i < n_words; i += blockDim.x) d[i] = src[i];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_store(flag[blockIdx.x], seq_base[0] + seq_off, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// one wavefront: lane r waits for source r's flag to reach the step; `error` (optional) is set to 1 + r of a source that did not arrive
+// within timeout_ticks of the 100 MHz wall clock -- the wait ALWAYS ends (a peer that died must not hang the queue).
+__global__ void __launch_bounds__(64) peer_wait_kernel(const unsigned long long* __restrict__ flags, int32_t n_src,
+                                                       const unsigned long long* __restrict__ seq_base, unsigned long long seq_off,
+                                                       long long timeout_ticks, int32_t* __restrict__ error)
+{
+    const unsigned long long want = seq_base[0] + seq_off;
+    const long long t0 = (long long)wall_clock64();
+    for (int r = threadIdx.x; r < n_src; r += 64) {
+        while (__hip_atomic_load(&flags[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+            if ((long long)wall_clock64() - t0 > timeout_ticks) {
+                if (error) atomicMax(error, 1 + r);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+}
+
 }  // namespace ssa
 
 // ============================================================================= C ABI
@@ -3571,6 +3618,27 @@ int ssa_masked_argmax_f64(const double* score, const uint8_t* mask, int64_t n, i
 {
     if (!out || n < 0 || (n > 0 && !score)) return SSA_E_INVALID;
     hipLaunchKernelGGL(masked_argmax_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, score, mask, n, out);
+    return launch_status();
+}
+
+// ---- all-gather by direct peer stores (include/ssa_hip.h): no collective, plain kernels
+int ssa_peer_push_f64(const double* src, int64_t n_words, double* const* dst, uint64_t* const* flag, int32_t n_peer,
+                      const uint64_t* seq_base, uint64_t seq_off, void* stream)
+{
+    if (n_peer < 0 || n_words < 0 || !seq_base || (n_peer > 0 && (!dst || !flag || (n_words > 0 && !src)))) return SSA_E_INVALID;
+    if (n_peer == 0) return SSA_OK;
+    hipLaunchKernelGGL(peer_push_kernel, dim3(n_peer), dim3(1024), 0, (hipStream_t)stream, src, n_words, dst,
+                       (unsigned long long* const*)flag, (const unsigned long long*)seq_base, (unsigned long long)seq_off);
+    return launch_status();
+}
+int ssa_peer_wait(const uint64_t* flags, int32_t n_src, const uint64_t* seq_base, uint64_t seq_off, int64_t timeout_ticks, int32_t* error,
+                  void* stream)
+{
+    if (n_src < 0 || !seq_base || (n_src > 0 && !flags)) return SSA_E_INVALID;
+    if (n_src == 0) return SSA_OK;
+    hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned long long*)flags, n_src,
+                       (const unsigned long long*)seq_base, (unsigned long long)seq_off,
+                       (long long)(timeout_ticks > 0 ? timeout_ticks : 200000000ll), error);
     return launch_status();
 }
 

@@ -230,6 +230,17 @@ def masked_argmax(score, mask=None):
     return int(out[0].item())
 
 
+def masked_argmax_action(score, mask=None):
+    """the arg-max head of a device-side policy: np.argmax of `score` over the entries with mask != 0 (first maximum; NaN skipped; -1 when
+    nothing is selected) as an int32 CUDA tensor [1] -- the action word the next step launch reads.  ONE launch, nothing leaves the device
+    (the kernel writes an int64 pair; its low word IS the int32 action: little endian)."""
+    lib = _lib.load()
+    out = torch.empty(2, dtype=torch.int64, device=score.device)
+    _lib.check(lib.ssa_masked_argmax_f64(_chk(score, "score"), _chk(mask, "mask", torch.uint8) if mask is not None else None,
+                                         score.shape[0], out.data_ptr(), _stream()), "ssa_masked_argmax_f64")
+    return out.view(torch.int32)[:1]
+
+
 def env_step(consts, params):
     """E1: the fused step.  `params` is a filled _lib.ssa_step_params."""
     lib = _lib.load()

@@ -635,6 +635,13 @@ class SSA_Tasker_Env(Env):
                 return device.visible_mask_at(self.x_true, e.trans, e.env_time0, self._tix_off, self.env._consts)
             return device.visible_mask(self.x_true, e.trans[self.i % e.n_time].reshape(3, 3), self.env._consts)
 
+        def argmax(self, score, mask=None):
+            """the policy's arg-max head in ONE launch: np.argmax(score[mask != 0]) mapped back to object indices (first maximum, NaN
+            skipped, -1 when nothing is selected) as the int32 CUDA tensor [1] run_policy expects.  torch.argmax + a cast are two launches
+            and 16 us at 20 000 objects (profiles/r04_run_policy_timeline.txt); this is 3-4."""
+            from .. import device
+            return device.masked_argmax_action(score, mask)
+
         def scores(self):
             """(scores[4, m], mask[m]) of the reference's heuristic agents (trace P, visible, log-det ratio, delta_pos)"""
             from .. import device
@@ -680,7 +687,12 @@ class SSA_Tasker_Env(Env):
             e.flush_stats()
             torch.cat([a.reshape(1) for a in acts_t], out=acts_d)
             e.env_time0.add_(K)
-        stream = torch.cuda.Stream(device=e.dev)
+        if getattr(self, "_policy_streams", None) is None:      # capture / replay stream and the copy stream of the pipelined chunks: one pair per env
+            self._policy_streams = (torch.cuda.Stream(device=e.dev), torch.cuda.Stream(device=e.dev))
+        stream, copy_stream = self._policy_streams
+        # two sets of pinned host buffers for the replay's results (statistics, update records, actions): chunk c is booked from one while
+        # the copy behind replay c + 1 fills the other
+        hosts = tuple(tuple(torch.empty(d.shape, dtype=d.dtype, pin_memory=True) for d in (stats_d, upd_d, acts_d)) for _ in range(2))
         g = torch.cuda.CUDAGraph()
         ok = True
         try:
@@ -704,7 +716,7 @@ class SSA_Tasker_Env(Env):
             self.policy_graph_error = repr(exc)
             e._fold_pending = None
         torch.cuda.current_stream().wait_stream(stream)
-        ent = (g, stats_d, upd_d, acts_d, stream) if ok else None
+        ent = (g, stats_d, upd_d, acts_d, stream, hosts, copy_stream) if ok else None
         self._policy_graphs[key] = ent
         return ent
 
@@ -732,23 +744,19 @@ class SSA_Tasker_Env(Env):
         use_graph = bool(graph) and self.reward_type == 'trinary' and G % e.H == 0
         if not hasattr(self, "_policy_graphs"):
             self._policy_graphs, self.policy_graph_error = {}, None
-        while use_graph and K - pos >= G:
-            i0 = self.i
-            ent = self._policy_graph(policy, G, i0)
-            if ent is None:
-                break
-            g, stats_d, upd_d, acts_d, stream = ent
-            e.flush_stats()
-            e.env_time0.fill_(i0)
-            stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(stream):
-                g.replay()
-            torch.cuda.current_stream().wait_stream(stream)
-            stats = stats_d.cpu().numpy()                  # synchronises
-            upd = upd_d.cpu().numpy()
-            acts = acts_d.cpu().numpy()
-            e.env_time0.zero_()
-            self._ring_head = i0 + G
+        # The chunks are PIPELINED: replay c + 1 is enqueued before the host books chunk c.  A replay writes its statistics / update records /
+        # actions at fixed device addresses, so right behind every replay a copy stream moves them into one of two pinned host buffers
+        # (12 KB), and the next replay waits for that copy alone; the host then fills in chunk c's bookkeeping (5 us per step) while the
+        # GPU runs chunk c + 1.  (Round 4 measurement, profiles/r04_run_policy_timeline.txt: inside a replay the GPU idles < 1 us between
+        # kernels, but synchronise - copy - book - replay left it idle for 16 us per step at chunk boundaries.)  An invalid action is
+        # therefore reported one chunk late: the steps enqueued behind it have run (with no update: the kernel ignores an action out of range).
+        pend = None            # (i0, host arrays, event) of the replay whose bookkeeping is outstanding
+        state = {"done": False}
+
+        def book(i0, host, ev):
+            ev.synchronize()
+            stats, upd, acts = host
+            self._ring_head = i_start + launched
             self._fail_chunk_total = int(stats[-1][_lib.STAT_N_FAILED])
             for k in range(G):
                 self.i += 1
@@ -760,14 +768,46 @@ class SSA_Tasker_Env(Env):
                 self._stats = stats[k]
                 if int(stats[k][_lib.STAT_N_FAILED]) != self._n_failed:
                     self._record_failures(at_step=i)
-                done = self._reward_done(i, a, stats[k], self._argmax_sigma) or (i + 1 >= self.n)
+                state["done"] = self._reward_done(i, a, stats[k], self._argmax_sigma) or (i + 1 >= self.n)
                 self._argmax_sigma = int(stats[k][_lib.STAT_ARGMAX_SPOS])
                 actions.append(a)
                 rewards.append(self.rewards[i] if (self.obs_returned == 'flatten' or np.isfinite(self.rewards[i])) else np.float64(0.5))
-                dones.append(done)
-            pos += G
-            if done:
-                break
+                dones.append(state["done"])
+        launched, i_start, gstream = 0, self.i, None      # steps enqueued by replays (self.i follows as the chunks are booked)
+        try:
+            while use_graph and K - launched >= G and not state["done"]:
+                i0 = i_start + launched
+                ent = self._policy_graph(policy, G, i0)
+                if ent is None:
+                    break
+                g, stats_d, upd_d, acts_d, gstream, hosts, copy_stream = ent
+                if launched == 0:
+                    e.flush_stats()
+                    e.env_time0.fill_(i0)
+                    gstream.wait_stream(torch.cuda.current_stream())
+                slot = (launched // G) % 2
+                with torch.cuda.stream(gstream):
+                    g.replay()
+                    ready = torch.cuda.Event()
+                    ready.record(gstream)
+                copy_stream.wait_event(ready)
+                with torch.cuda.stream(copy_stream):
+                    for h, d in zip(hosts[slot], (stats_d, upd_d, acts_d)):
+                        h.copy_(d, non_blocking=True)
+                    copied = torch.cuda.Event()
+                    copied.record(copy_stream)
+                gstream.wait_event(copied)         # the NEXT replay overwrites the device buffers only behind this copy
+                launched += G
+                if pend is not None:
+                    book(*pend)                    # chunk c - 1, while the GPU runs chunk c
+                pend = (i0, tuple(h.numpy() for h in hosts[slot]), copied)
+            if pend is not None:
+                book(*pend)
+        finally:
+            if gstream is not None:
+                torch.cuda.current_stream().wait_stream(gstream)
+                e.env_time0.zero_()
+        pos, done = launched, state["done"]
         while pos < K and not done:
             kk = (K - pos) if self.reward_type == 'trinary' else min(K - pos, e.H - 1)
             i0 = self.i

@@ -78,6 +78,31 @@ def _direct_communicator(dev, group):
     return None
 
 
+def _peer_exchange(plan, width, dev, group, use_dist):
+    """the peer-store exchange, or None on EVERY rank when any rank could not map its peers (the caller then takes the collective);
+    every rank takes part in the handle exchange inside peer.PeerExchange whatever happens to it afterwards."""
+    import warnings
+    from . import peer
+    px, err = None, None
+    try:
+        px = peer.PeerExchange(plan.world if use_dist else 1, plan.rank if use_dist else 0, width, dev, group)
+    except Exception as exc:  # noqa: BLE001
+        err = exc
+    if not use_dist:
+        if px is None:
+            raise err
+        return px
+    ok = torch.tensor([1 if px is not None else 0], dtype=torch.int32, device=dev if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) == 1:
+        return px
+    if px is not None:
+        px.close()
+    warnings.warn("peer-store all-gather unavailable on at least one rank (%s); every rank uses the collective"
+                  % (err if err is not None else "another rank failed"))
+    return None
+
+
 class ShardedStepper:
     """one env of m_total objects, one rank per shard.
 
@@ -90,10 +115,17 @@ class ShardedStepper:
 
     NB = 3
 
-    def __init__(self, plan, local, group=None, direct_rccl=True, obs_cols=4):
+    def __init__(self, plan, local, group=None, direct_rccl=True, obs_cols=4, exchange=None):
         assert obs_cols in (1, 4)
         self.plan, self.local, self.group, self.cols = plan, local, group, int(obs_cols)
         self._rccl = None
+        # exchange: 'rccl' (the all-gather collective: default) | 'peer' (direct peer stores over hipIpc-mapped pointers, peer.py: plain
+        # kernels, no collective -- GPU only; also the environment variable SSA_ALLGATHER).  Every rank must ask for the same one.
+        import os
+        exchange = exchange or os.environ.get("SSA_ALLGATHER") or "rccl"
+        if exchange not in ("rccl", "peer"):
+            raise ValueError("ShardedStepper: exchange must be 'rccl' or 'peer', not %r" % (exchange,))
+        self._peer, self._waited = None, 0
         dev = local.device
         # payload of one rank: [ aer block 4 * m_pad | 8 folded statistics | 256 raw statistics words (uint64 bit patterns) ]
         # A local stepper with `raw_shards` (the HIP engine) lets the step kernel accumulate straight into the raw words of
@@ -122,8 +154,14 @@ class ShardedStepper:
             self._pending = [False] * self.NB
             # the all-gather enqueued by RCCL itself in our stream (no ProcessGroup stream hops, rccl.py); the
             # torch.distributed collective remains the fallback
-            if direct_rccl and dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl":
+            if exchange == "peer":
+                self._peer = _peer_exchange(plan, self.width, torch.device(dev), group, self._use_dist)
+            if self._peer is not None:
+                self.recv = self._peer.recv          # (the receive buffers ARE the rank's arena the peers store into)
+            elif direct_rccl and dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl":
                 self._rccl = _direct_communicator(torch.device(dev), group)
+        elif exchange == "peer":
+            raise ValueError("ShardedStepper: the peer-store exchange moves device memory (HIP stepper on a GPU)")
 
     def _all_gather(self, recv, send, stream):
         if self._rccl is not None:
@@ -152,7 +190,14 @@ class ShardedStepper:
         else:
             self.local.step(p.local_action(global_action), self._v_obs[b], self._v_stats[b], **kw)
         self._raw[b] = raw
-        if not use_dist:   # single process without a process group
+        if self._peer is not None:
+            # in the step's own stream: wait for every peer's payload of the PREVIOUS step (normally there already; it also orders this
+            # push behind the peers' readers of the slot it overwrites, peer.py), then store this step's payload into every arena
+            if self.k >= 1 and self._waited < self.k:
+                self._peer.wait((self.k - 1) % self.NB, self.k, cur.cuda_stream)
+                self._waited = self.k
+            self._peer.push(send, b, self.k + 1, cur.cuda_stream)
+        elif not use_dist:   # single process without a process group
             recv.copy_(send)
         elif overlap:
             self._ready[b].record(cur)
@@ -177,9 +222,17 @@ class ShardedStepper:
             torch.cuda.synchronize()
             self._rccl.close()
             self._rccl = None
+        if self._peer is not None:
+            self._peer.close()
+            self._peer = None
 
     def wait(self):
         """make the current stream wait for every all-gather issued so far."""
+        if self._peer is not None:
+            if self.k >= 1 and self._waited < self.k:
+                self._peer.wait((self.k - 1) % self.NB, self.k, torch.cuda.current_stream().cuda_stream)
+                self._waited = self.k
+            return
         if self._gpu:
             for b in range(self.NB):
                 if self._pending[b]:
@@ -259,7 +312,7 @@ class GraphedShardedSteps:
             raise ValueError("graphed sharded steps: one env, history depth 2")
         if not self.sh._gpu or not getattr(self.local, "raw_shards", False):
             raise ValueError("graphed sharded steps need the HIP stepper")
-        if self.sh._use_dist and self.sh._rccl is None:
+        if self.sh._use_dist and self.sh._rccl is None and self.sh._peer is None:
             # (a ProcessGroup collective is not captured here: gloo's runs on the host, and a capture that fails half way leaves
             # the backend's internal streams in capture mode -- refuse BEFORE anything is captured, the caller enqueues per step)
             raise ValueError("graphed sharded steps need the direct RCCL all-gather (rccl.py); this group has none")
@@ -299,7 +352,11 @@ class GraphedShardedSteps:
                             shards_out=sh._v_shards[b].data_ptr(), shards_clear=sh._v_shards[bn].data_ptr(), aer_cols=sh.cols,
                             stream=cur.cuda_stream)
             sh._raw[b] = True
-            if self.overlap:
+            if sh._peer is not None:      # plain kernels in the unit's stream; step numbers relative to the device-side base
+                if k0 + j >= 1:
+                    sh._peer.wait((k0 + j - 1) % sh.NB, k0 + j, cur.cuda_stream)
+                sh._peer.push(sh.send[b], b, k0 + j + 1, cur.cuda_stream)
+            elif self.overlap:
                 ev = torch.cuda.Event()
                 ev.record(cur)
                 sh.comm.wait_event(ev)
@@ -309,11 +366,13 @@ class GraphedShardedSteps:
                 done.append(dn)
             else:
                 sh._all_gather(sh.recv[b], sh.send[b], cur)
-        if self.overlap:
+        if self.overlap and sh._peer is None:
             for dn in done[-2:]:
                 cur.wait_event(dn)                   # join: the unit ends when its last all-gathers have
         eng.env_time0.add_(U)
         self.cursor.add_(U)
+        if sh._peer is not None:
+            sh._peer.advance_on_device(U)
 
     def _end_stray_capture(self):
         """after a failed capture: no stream of ours may be left in capture mode (hipStreamIsCapturing / hipStreamEndCapture)"""
@@ -343,6 +402,15 @@ class GraphedShardedSteps:
         # (host bookkeeping first: whatever happens below, U steps of this rank's state and U all-gathers have been / will be enqueued)
         local.tick += self.U
         sh.k += self.U
+        try:
+            self._run_unit(g, key, cur, tick0, k0)
+        finally:
+            if sh._peer is not None:       # (the device-side base of the step numbers moved by U: the host's copy follows)
+                sh._peer.advanced(self.U)
+                sh._waited = max(sh._waited, sh.k - 1)
+
+    def _run_unit(self, g, key, cur, tick0, k0):
+        sh = self.sh
         if g is False:                 # this phase could not be captured: per-step enqueue
             self._enqueue_unit(tick0, k0)
             return

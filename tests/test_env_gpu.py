@@ -613,7 +613,7 @@ def test_run_policy_replayed_from_a_graph_equals_the_eager_loop(envs):
     to the eager loop with the same results."""
     import torch
     cfg = dict(envs.env_config)
-    cfg.update(rso_count=41, steps=120, reward_type='trinary', obs_returned='flatten', seed=13, obs_limit=5.0, history=2)
+    cfg.update(rso_count=41, steps=200, reward_type='trinary', obs_returned='flatten', seed=13, obs_limit=5.0, history=2)
 
     def visible_greedy(view):
         sc, mask = view.scores()
@@ -625,25 +625,37 @@ def test_run_policy_replayed_from_a_graph_equals_the_eager_loop(envs):
         j = int(torch.argmax(view.obs[:, 6:].sum(dim=1)).item())
         return torch.full((1,), j, dtype=torch.int32, device="cuda")
 
-    for policy, capturable in ((visible_greedy, True), (syncing, False)):
+    def with_the_argmax_head(view):          # the same rule with the env's one-launch arg-max head (np.argmax semantics, mask included)
+        sc, mask = view.scores()
+        return torch.clamp(view.argmax(sc[0], mask), min=0)
+
+    picked = {}
+    for policy, capturable in ((visible_greedy, True), (with_the_argmax_head, True), (syncing, False)):
         a, b = envs.make(config=cfg), envs.make(config=cfg)
-        ra = a.run_policy(policy, 75, graph=True)            # 2 replays of 32 + 11 eager steps
-        rb = b.run_policy(policy, 75, graph=False)
+        ra = a.run_policy(policy, 107, graph=True)           # 3 replays of 32 (pipelined: chunk c is booked while c + 1 runs) + 11 eager steps
+        rb = b.run_policy(policy, 107, graph=False)
+        picked[policy.__name__] = ra[0]
         assert (a.policy_graph_error is None) == capturable, a.policy_graph_error
         assert len(a._policy_graphs) == 1 and (next(iter(a._policy_graphs.values())) is not None) == capturable
         for u, v in zip(ra, rb):
             assert np.array_equal(u, v)
-        assert a.i == b.i == 75 and len(set(ra[0].tolist())) > 3
+        assert a.i == b.i == 107 and len(set(ra[0].tolist())) > 3
         for name in ("x_filter", "P_filter", "x_true"):
-            assert np.array_equal(np.asarray(getattr(a, name)[75]), np.asarray(getattr(b, name)[75])), name
-        assert np.array_equal(a.obs_taken[:76], b.obs_taken[:76]) and np.array_equal(a.rewards[:76], b.rewards[:76])
-        assert np.array_equal(np.asarray(a.z_true[1:76]), np.asarray(b.z_true[1:76]), equal_nan=True)
-        ra2, rb2 = a.run_policy(policy, 40, graph=True), b.run_policy(policy, 40, graph=False)      # the cached graph again (other phase: 75 is odd)
+            assert np.array_equal(np.asarray(getattr(a, name)[107]), np.asarray(getattr(b, name)[107])), name
+        assert np.array_equal(a.obs_taken[:108], b.obs_taken[:108]) and np.array_equal(a.rewards[:108], b.rewards[:108])
+        assert np.array_equal(np.asarray(a.z_true[1:108]), np.asarray(b.z_true[1:108]), equal_nan=True)
+        ra2, rb2 = a.run_policy(policy, 72, graph=True), b.run_policy(policy, 72, graph=False)      # a graph for the other phase (107 is odd): 2 replays + 8
         for u, v in zip(ra2, rb2):
             assert np.array_equal(u, v)
         o1, r1, _, _ = a.step(3)
         o2, r2, _, _ = b.step(3)
         assert np.array_equal(o1, o2) and r1 == r2
+    assert np.array_equal(picked["visible_greedy"], picked["with_the_argmax_head"])
+    # an action out of range surfaces as ValueError (graph form: when its chunk is booked, one chunk behind the GPU)
+    bad = envs.make(config=cfg)
+    out_of_range = torch.full((1,), 41, dtype=torch.int32, device="cuda")
+    with pytest.raises(ValueError, match="chose action 41"):
+        bad.run_policy(lambda view: out_of_range, 70, graph=True)
 
 
 def test_anees_and_nis_of_an_episode(envs):

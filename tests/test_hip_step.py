@@ -1239,6 +1239,44 @@ def test_graphed_sharded_steps_equal_eager_steps(hip):
             assert np.array_equal(dev_stats[:3], want[5][:3]) and dev_stats[hip.lib.STAT_N_FAILED] == want[5][hip.lib.STAT_N_FAILED]
             assert int(eng.env_time0.item()) == U * NU and int(gs.cursor.item()) == U * NU
             sh.close()
+        # the all-gather by direct peer stores (peer.py; at one rank the "peer" is the rank's own arena): per step and as replayed units,
+        # the same bits; the wait on a step nobody pushed ends at its bound and says which source is missing
+        def fresh_peer():
+            eng = hip.engine.HotPathEngine(consts, m, 1, c2t(), torch.as_tensor(zn_h).cuda()[None].contiguous(), history=2)
+            eng.load_state(0, xt, x, P)
+            local = parallel.HipLocalStepper(eng, consts, fast_stats=True)
+            return eng, local, parallel.ShardedStepper(plan, local, obs_cols=1, exchange="peer")
+        for graphed in (False, True):
+            eng, local, sh = fresh_peer()
+            assert sh._peer is not None and sh._rccl is None
+            if graphed:
+                gs = parallel.GraphedShardedSteps(sh, U, sched)
+                gs.rewind()
+                for _ in range(NU):
+                    gs.run_unit()
+                assert gs.capture_failed is None and len(gs._graphs) == 3
+            else:
+                for k in range(U * NU):
+                    sh.step(int(sched[k]))
+            sh.wait()
+            torch.cuda.synchronize()
+            sh._peer.check()
+            assert int(sh._peer.flags.max().item()) == U * NU and sh._peer.seq0_host == (U * NU if graphed else 0) == int(sh._peer.seq0.item())
+            got = (eng.x_filter[local.tick % 2].cpu().numpy(), eng.P_filter[local.tick % 2].cpu().numpy(), eng.x_true[local.tick % 2].cpu().numpy(),
+                   eng.status.cpu().numpy(), sh.global_obs().cpu().numpy(), sh.global_stats())
+            for a, b in zip(got, want):
+                assert np.array_equal(a, b, equal_nan=True), graphed
+            if not graphed:
+                sh._peer.timeout_ticks = 100000          # 1 ms
+                sh._peer.wait(0, U * NU + 5, torch.cuda.current_stream().cuda_stream)      # a step that was never pushed
+                torch.cuda.synchronize()
+                with pytest.raises(hip.lib.SsaHipError, match="rank 0's payload did not arrive"):
+                    sh._peer.check()
+                sh.step(int(sched[0]))                   # (the exchange still works afterwards)
+                sh.wait()
+                torch.cuda.synchronize()
+                sh._peer.check()
+            sh.close()
         # a phase whose capture fails keeps the host and device bookkeeping in step (the eager unit ran; tick and k advanced) and is
         # enqueued eagerly from then on: same results, no exception, `capture_failed` says why
         eng, local, sh = fresh()
