@@ -18,7 +18,7 @@ def reduce(d):
     # the marker launches (ssa::propagate_kernel on 7 states) bracket the sections
     marks = [i for i, r in enumerate(rows) if "propagate_kernel" in r[2]]
     names = ["graph replay, torch policy", "eager, torch policy", "graph replay, preallocated action", "eager, preallocated action",
-             "graph replay, masked_scores + argmax (int64 action)"]
+             "graph replay, view.scores() + view.argmax() (the arg-max head of the library)"]
     for s in range(len(marks) - 1):
         seg = rows[marks[s] + 1:marks[s + 1]]
         if not seg:
@@ -67,11 +67,12 @@ def trivial(view):
 
 
 def lean(view):
-    return torch.argmax(view.masked_scores()[0]).reshape(1)
+    sc, mask = view.scores()
+    return view.argmax(sc[0], mask)
 
 
 cases = [(policy, True), (policy, False), (trivial, True), (trivial, False)]
-if hasattr(env.PolicyView, "masked_scores"):
+if hasattr(env.PolicyView, "argmax"):
     cases.append((lean, True))
 for pol, graph in cases:
     env.reset(); env.run_policy(pol, 64, graph=graph)        # captures, first launches

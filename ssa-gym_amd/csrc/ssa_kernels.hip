@@ -2930,45 +2930,55 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) closed_loop_kernel(const L
     if (asrc.pend >= 0) closed_loop_store((const LoopK*)kp, t, lane, asrc.pend, base, cnt);
 }
 
-// first maximum of score over mask (single block; 8 loads in flight per thread)
+// first maximum of score over mask: ONE workgroup of 16 wavefronts (a policy's arg-max head sits between two step launches: a second launch
+// for a cross-workgroup fold would cost more than it saves at 20 000 entries).  16 loads in flight per thread (20 000 entries = two rounds),
+// the fold by wavefront shuffles + one LDS exchange of the 16 wavefront results: 3-4 us where the first version (8 loads per round, a
+// 10-level __syncthreads tree over 1 024 LDS slots) took 11.8 (profiles/r04_run_policy_timeline.txt).
 __global__ void __launch_bounds__(1024) masked_argmax_kernel(const double* __restrict__ score, const uint8_t* __restrict__ mask,
                                                              int64_t n, int64_t* __restrict__ out)
 {
     const int t = threadIdx.x;
     double best = 0.0;
     long long arg = -1;
-    for (int64_t b0 = 0; b0 < n; b0 += 1024 * 8) {
-        double v[8];
-        bool ok[8];
+    constexpr int Q = 16;
+    for (int64_t b0 = 0; b0 < n; b0 += 1024 * Q) {
+        double v[Q];
+        bool ok[Q];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            int64_t i = b0 + (int64_t)q * 1024 + t;
-            bool in = i < n;
+        for (int q = 0; q < Q; ++q) {
+            const int64_t i = b0 + (int64_t)q * 1024 + t;
+            const bool in = i < n;
             v[q] = in ? score[i] : 0.0;
             ok[q] = in && (mask ? mask[i] != 0 : true);
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            int64_t i = b0 + (int64_t)q * 1024 + t;
+        for (int q = 0; q < Q; ++q) {    // (ascending indices per thread: `>` keeps the first maximum)
+            const int64_t i = b0 + (int64_t)q * 1024 + t;
             if (ok[q] && v[q] == v[q] && (arg < 0 || v[q] > best)) { best = v[q]; arg = i; }
         }
     }
-    __shared__ double sb[1024];
-    __shared__ long long sa[1024];
-    sb[t] = best; sa[t] = arg;
-    __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
-        if (t < w) {
-            long long a2 = sa[t + w];
-            double b2 = sb[t + w];
-            bool take = a2 >= 0 && (sa[t] < 0 || b2 > sb[t] || (b2 == sb[t] && a2 < sa[t]));
-            if (take) { sb[t] = b2; sa[t] = a2; }
-        }
-        __syncthreads();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double b2 = __shfl_down(best, off, 64);
+        const long long a2 = __shfl_down(arg, off, 64);
+        agent_merge(best, arg, b2, a2);
     }
-    if (t == 0) {
-        out[0] = sa[0];
-        out[1] = __double_as_longlong(sb[0]);
+    __shared__ AgentPart part[16];
+    if ((t & 63) == 0) { part[t >> 6].best = best; part[t >> 6].arg = arg; }
+    __syncthreads();
+    if (t < 64) {
+        best = (t < 16) ? part[t].best : 0.0;
+        arg = (t < 16) ? part[t].arg : -1;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            const double b2 = __shfl_down(best, off, 64);
+            const long long a2 = __shfl_down(arg, off, 64);
+            agent_merge(best, arg, b2, a2);
+        }
+        if (t == 0) {
+            out[0] = arg;
+            out[1] = __double_as_longlong(best);
+        }
     }
 }
 

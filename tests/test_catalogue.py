@@ -85,3 +85,25 @@ def test_every_row_passes_orbit_gens_acceptance_rule():
     assert small.shape == (60, 6) and rule(small).all()
     free = synthetic_catalogue(2000, seed=3, visibility=False)
     assert rule(free).mean() < 0.5                   # (the rule is a real constraint: most unconstrained draws fail it)
+
+
+def test_regime_order_is_a_permutation_sorted_by_semi_major_axis_and_dealt_over_the_xcds():
+    """catalogue.regime_order: the layout hint of round 4 (objects of one regime share wavefronts; every XCD's run of tiles gets the same
+    share of every regime).  A permutation; chunk c of the sorted list sits in tile (c % 8) * q + c // 8."""
+    from ssa_gym_amd.catalogue import regime_order, MU
+    cat = synthetic_catalogue(20000, seed=0)
+    order = regime_order(cat)
+    assert sorted(order.tolist()) == list(range(20000))
+    a = 1.0 / (2.0 / np.linalg.norm(cat[:, :3], axis=1) - np.sum(cat[:, 3:] ** 2, axis=1) / MU)
+    q = 5000 // 8
+    chunks = np.empty(20000, dtype=np.int64)
+    for c in range(5000):
+        t = (c % 8) * q + c // 8
+        chunks[4 * c:4 * c + 4] = order[4 * t:4 * t + 4]
+    assert np.all(np.diff(a[chunks]) >= 0)                       # undone the dealing: ascending semi-major axis
+    leo = a[order].reshape(5000, 4) < 8.4e6                      # LEO objects sit in whole tiles (all four or none, but for one boundary tile)
+    assert np.sum(leo.any(axis=1) & ~leo.all(axis=1)) <= 1
+    per_xcd = leo.all(axis=1).reshape(8, q).sum(axis=1)
+    assert per_xcd.max() - per_xcd.min() <= 1
+    odd = regime_order(cat[:1003])                               # not a multiple of 32: the plain sort
+    assert sorted(odd.tolist()) == list(range(1003)) and np.all(np.diff(a[:1003][odd]) >= 0)
