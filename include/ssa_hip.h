@@ -345,6 +345,14 @@ int ssa_agent_scores_at_f64(const double *x_true, const double *x_cur, const dou
  * NaN entries are skipped (the reference's agents run under np.errstate and np.argmax would return a
  * NaN's index; skipping is the documented deviation).  out[1] = the maximum (as double bits). */
 int ssa_masked_argmax_f64(const double *score, const uint8_t *mask, int64_t n, int64_t *out, void *stream);
+/* The same fold spread over the chip, for callers that own a workspace -- the arg-max head of a device-side policy between two step
+ * launches (SSA_Tasker_Env.run_policy, PolicyView.argmax): one workgroup reads 20 000 entries in 8.6 us (a single CU's share of the memory
+ * system), ceil(n / 2048) workgroups and a last-arrival fold take about 3.  `workspace`: ssa_masked_argmax_workspace_bytes(n) bytes of
+ * device memory, ZERO before the first call (the kernel leaves it zero-ticketed for the next), used by one call at a time (calls in one
+ * stream are).  NULL workspace or n <= 2048: the single-workgroup kernel. */
+int ssa_masked_argmax_ws_f64(const double *score, const uint8_t *mask, int64_t n, int64_t *out, void *workspace, int64_t workspace_bytes,
+                             void *stream);
+int64_t ssa_masked_argmax_workspace_bytes(int64_t n);
 
 /* ------------------------------------------------ closed loop on the device
  * The agent's choice for the NEXT step, made on the GPU from the state the step just wrote and stored into the int32

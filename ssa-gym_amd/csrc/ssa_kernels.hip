@@ -2982,6 +2982,74 @@ __global__ void __launch_bounds__(1024) masked_argmax_kernel(const double* __res
     }
 }
 
+// The same over many workgroups, for callers that own a small workspace (a policy's arg-max head inside a replayed graph): ONE workgroup
+// reads 20 000 entries at the ~40 GB/s a single CU gets (8.6 us, profiles/r04_run_policy_timeline.txt); here every workgroup of 256 lanes
+// folds 2 048 entries, stores its part (agent-scope stores), takes a ticket, and the LAST one to arrive folds the parts.  ws: [ticket | pad to
+// 64 bytes | parts]; the ticket wraps back to 0 with the last arrival (atomicInc), so the workspace needs zeroing ONCE.  One call at a time
+// per workspace (calls in one stream are).
+constexpr int AMAX_T = 256, AMAX_Q = 8;
+__global__ void __launch_bounds__(AMAX_T) masked_argmax_blocks_kernel(const double* __restrict__ score, const uint8_t* __restrict__ mask,
+                                                                      int64_t n, int64_t* __restrict__ out, unsigned long long* __restrict__ ws)
+{
+    const int t = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * (AMAX_T * AMAX_Q);
+    double best = 0.0;
+    long long arg = -1;
+    {
+        double v[AMAX_Q];
+        bool ok[AMAX_Q];
+#pragma unroll
+        for (int q = 0; q < AMAX_Q; ++q) {
+            const int64_t i = b0 + q * AMAX_T + t;
+            const bool in = i < n;
+            v[q] = in ? score[i] : 0.0;
+            ok[q] = in && (mask ? mask[i] != 0 : true);
+        }
+#pragma unroll
+        for (int q = 0; q < AMAX_Q; ++q) {
+            const int64_t i = b0 + q * AMAX_T + t;
+            if (ok[q] && v[q] == v[q] && (arg < 0 || v[q] > best)) { best = v[q]; arg = i; }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double b2 = __shfl_down(best, off, 64);
+        const long long a2 = __shfl_down(arg, off, 64);
+        agent_merge(best, arg, b2, a2);
+    }
+    __shared__ AgentPart part[AMAX_T / 64];
+    __shared__ int last;
+    if ((t & 63) == 0) { part[t >> 6].best = best; part[t >> 6].arg = arg; }
+    __syncthreads();
+    unsigned long long* parts = ws + 8;
+    if (t == 0) {
+        for (int w = 1; w < AMAX_T / 64; ++w) agent_merge(best, arg, part[w].best, part[w].arg);
+        __hip_atomic_store(parts + 2 * blockIdx.x, (unsigned long long)__double_as_longlong(best), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(parts + 2 * blockIdx.x + 1, (unsigned long long)arg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = atomicInc(reinterpret_cast<unsigned int*>(ws), gridDim.x - 1) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last || t >= 64) return;
+    __threadfence();
+    best = 0.0; arg = -1;
+    for (int i = t; i < (int)gridDim.x; i += 64) {     // (ascending block index per lane; ties go to the lower object index in agent_merge)
+        const double b2 = __longlong_as_double((long long)__hip_atomic_load(parts + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const long long a2 = (long long)__hip_atomic_load(parts + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        agent_merge(best, arg, b2, a2);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double b2 = __shfl_down(best, off, 64);
+        const long long a2 = __shfl_down(arg, off, 64);
+        agent_merge(best, arg, b2, a2);
+    }
+    if (t == 0) {
+        out[0] = arg;
+        out[1] = __double_as_longlong(best);
+    }
+}
+
 // ---- diagnostic reductions of SURVEY 8f-4 (ssa_tasker_simple_2.py:436-446, 750-775): NEES = d^T inv(P) d with
 // d = x_true - x_filter, NIS = y^T inv(S) y.  One lane per (step, object): Gaussian elimination with partial pivoting on
 // the augmented system [P | d] (the arithmetic class of numpy.linalg.inv's LU), then the dot product.
@@ -3628,6 +3696,24 @@ int ssa_masked_argmax_f64(const double* score, const uint8_t* mask, int64_t n, i
 {
     if (!out || n < 0 || (n > 0 && !score)) return SSA_E_INVALID;
     hipLaunchKernelGGL(masked_argmax_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, score, mask, n, out);
+    return launch_status();
+}
+
+int64_t ssa_masked_argmax_workspace_bytes(int64_t n)
+{
+    if (n < 0) return SSA_E_INVALID;
+    return 64 + 16 * ((n + AMAX_T * AMAX_Q - 1) / (AMAX_T * AMAX_Q) + 1);
+}
+int ssa_masked_argmax_ws_f64(const double* score, const uint8_t* mask, int64_t n, int64_t* out, void* workspace, int64_t workspace_bytes,
+                             void* stream)
+{
+    if (!out || n < 0 || (n > 0 && !score)) return SSA_E_INVALID;
+    const int64_t nb = (n + AMAX_T * AMAX_Q - 1) / (AMAX_T * AMAX_Q);
+    if (nb <= 1 || !workspace)      // (one workgroup's worth, or no workspace: the single-workgroup kernel)
+        return ssa_masked_argmax_f64(score, mask, n, out, stream);
+    if (workspace_bytes < ssa_masked_argmax_workspace_bytes(n) || nb > 0x7fffffff) return SSA_E_INVALID;
+    hipLaunchKernelGGL(masked_argmax_blocks_kernel, dim3((unsigned)nb), dim3(AMAX_T), 0, (hipStream_t)stream, score, mask, n, out,
+                       (unsigned long long*)workspace);
     return launch_status();
 }
 

@@ -230,14 +230,25 @@ def masked_argmax(score, mask=None):
     return int(out[0].item())
 
 
-def masked_argmax_action(score, mask=None):
+def masked_argmax_workspace(n, device):
+    """zeroed workspace of ssa_masked_argmax_ws_f64 for up to n entries (one call at a time: keep it with the stream that uses it)"""
+    lib = _lib.load()
+    return torch.zeros(int(lib.ssa_masked_argmax_workspace_bytes(int(n))) // 8, dtype=torch.int64, device=device)
+
+
+def masked_argmax_action(score, mask=None, workspace=None):
     """the arg-max head of a device-side policy: np.argmax of `score` over the entries with mask != 0 (first maximum; NaN skipped; -1 when
     nothing is selected) as an int32 CUDA tensor [1] -- the action word the next step launch reads.  ONE launch, nothing leaves the device
-    (the kernel writes an int64 pair; its low word IS the int32 action: little endian)."""
+    (the kernel writes an int64 pair; its low word IS the int32 action: little endian).  workspace (masked_argmax_workspace): the fold
+    spread over the chip instead of one workgroup (3 us instead of 8.6 at 20 000 entries)."""
     lib = _lib.load()
     out = torch.empty(2, dtype=torch.int64, device=score.device)
-    _lib.check(lib.ssa_masked_argmax_f64(_chk(score, "score"), _chk(mask, "mask", torch.uint8) if mask is not None else None,
-                                         score.shape[0], out.data_ptr(), _stream()), "ssa_masked_argmax_f64")
+    m = _chk(mask, "mask", torch.uint8) if mask is not None else None
+    if workspace is not None:
+        _lib.check(lib.ssa_masked_argmax_ws_f64(_chk(score, "score"), m, score.shape[0], out.data_ptr(), workspace.data_ptr(),
+                                                workspace.numel() * 8, _stream()), "ssa_masked_argmax_ws_f64")
+    else:
+        _lib.check(lib.ssa_masked_argmax_f64(_chk(score, "score"), m, score.shape[0], out.data_ptr(), _stream()), "ssa_masked_argmax_f64")
     return out.view(torch.int32)[:1]
 
 

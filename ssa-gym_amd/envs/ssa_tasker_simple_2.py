@@ -640,7 +640,10 @@ class SSA_Tasker_Env(Env):
             skipped, -1 when nothing is selected) as the int32 CUDA tensor [1] run_policy expects.  torch.argmax + a cast are two launches
             and 16 us at 20 000 objects (profiles/r04_run_policy_timeline.txt); this is 3-4."""
             from .. import device
-            return device.masked_argmax_action(score, mask)
+            env = self.env
+            if getattr(env, "_argmax_ws", None) is None or env._argmax_ws_n < score.shape[0]:     # (owned by the env: its launches share a stream)
+                env._argmax_ws, env._argmax_ws_n = device.masked_argmax_workspace(score.shape[0], score.device), score.shape[0]
+            return device.masked_argmax_action(score, mask, env._argmax_ws)
 
         def scores(self):
             """(scores[4, m], mask[m]) of the reference's heuristic agents (trace P, visible, log-det ratio, delta_pos)"""

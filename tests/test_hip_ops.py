@@ -289,3 +289,34 @@ def test_nees_nis_vs_numpy(hip):
     y = rs.normal(size=(n, 3)) * np.sqrt(np.einsum('kii->ki', S))
     nis = hip.dev.nis(hip.dev.as_dev(y), hip.dev.as_dev(S)).cpu().numpy()
     np.testing.assert_allclose(nis, [y[k] @ np.linalg.inv(S[k]) @ y[k] for k in range(n)], rtol=1e-9)
+
+
+def test_masked_argmax_kernels_vs_numpy(hip):
+    """ssa_masked_argmax_f64 (one workgroup) and ssa_masked_argmax_ws_f64 (every workgroup folds 2 048 entries, the last one to arrive
+    folds the parts; a workspace zeroed once, reused call after call) against np.argmax over the masked entries: first maximum on ties,
+    NaN entries skipped (the documented deviation of the agents' arg-max), -1 when nothing is selected; sizes around the workgroup
+    boundaries, the 20 000- and 160 000-object cases.  The int32 low word of the result is the action word of the next step."""
+    torch = hip.torch
+    rs = np.random.RandomState(5)
+    ws = hip.dev.masked_argmax_workspace(160000, "cuda")
+    assert int(ws.abs().sum().item()) == 0
+    for n in (1, 63, 2047, 2048, 2049, 4100, 20000, 160000):
+        sc = rs.normal(size=n)
+        mask = (rs.uniform(size=n) < 0.4).astype(np.uint8)
+        if n >= 63:
+            k = np.where(mask)[0]
+            sc[k[len(k) // 3]] = sc[k[-1]] = 50.0                # a tie on the maximum: the first index wins
+            sc[k[1]] = np.nan                                     # skipped
+            sc[np.where(mask == 0)[0][0]] = 99.0                  # not selected
+        for m_ in (mask, None):
+            if m_ is None:
+                valid = ~np.isnan(sc)
+            else:
+                valid = (m_ != 0) & ~np.isnan(sc)
+            want = int(np.where(valid)[0][np.argmax(sc[valid])]) if valid.any() else -1
+            for w in (None, ws, ws):                              # (the workspace twice: it must come back ready for the next call)
+                a = hip.dev.masked_argmax_action(hip.up(sc), hip.up(m_, torch.uint8) if m_ is not None else None, w)
+                assert a.dtype == torch.int32 and a.shape == (1,) and int(a.item()) == want, (n, m_ is None, w is None)
+        none = hip.dev.masked_argmax_action(hip.up(sc), hip.up(np.zeros(n, np.uint8), torch.uint8), ws)
+        assert int(none.item()) == -1
+    assert int(ws[0].item()) == 0                                 # the ticket wrapped back
