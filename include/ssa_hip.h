@@ -299,8 +299,9 @@ int ssa_kepler_elements_f64(const double *x_in, double *coe, int64_t n, double d
 int ssa_robust_cholesky6_f64(const double *A, double *U, int32_t *rung, int64_t n, void *stream);
 /* U2 as the FUSED step kernels run it (the row-distributed ladder of robust_chol_row_lds, four matrices per wavefront): rung[n] as above
  * from the kernel's one-pass ladder, mask[n] = bit i set when rung i (jitter 10^(i-6)) factorises in the kernel's arithmetic (bit 16: the
- * plain attempt) -- all sixteen rungs are actually tried, so rung[n] must be the lowest set bit of mask[n] whatever the pattern.  For
- * numerically rank-one (n + lambda) P -- a diverged filter -- success is NOT monotone in the jitter (tests/golden/ladder_nonmonotone.npz). */
+ * plain attempt) -- all sixteen rungs are actually tried, so rung[n] must be the lowest set bit of mask[n] whatever the pattern.  (On the
+ * numerically rank-one (n + lambda) P of a diverged filter that round 3 took for a non-monotone case -- tests/golden/
+ * ladder_illconditioned_tile.npz -- the mask is 0111...1, and so it is on 4 096 one-ulp perturbations: DESIGN.md section 6, Round 4.) */
 int ssa_ladder_probe_f64(const double *A, double scale, int32_t *rung, int32_t *mask, double *U, int64_t n, void *stream);
 /* U1  MerweScaledSigmaPoints.sigma_points(x, P): sig[n][13][6], fail[n] (0 / SSA_ST_PREDICT_LINALG). */
 int ssa_sigma_points_f64(const double *x, const double *P, double scale, double *sig, int32_t *fail,

@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/${TAG}_more
 mkdir -p $OUT
 export TAG
 cd /tmp && export TMPDIR=/tmp
-for cfg in "fg 160000" "j2 20000" "elements 20000" "hybrid 20000"; do
+for cfg in "hybrid 160000" "fg 20000" "fg 160000" "j2 20000" "elements 20000"; do
   set -- $cfg; export PROP=$1 M=$2
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${PROP}_${M}_$c -- python3 $R/profiles/pmc_workload.py > $OUT/pmc_${PROP}_${M}_$c.log 2>&1
@@ -19,7 +19,7 @@ for cfg in "fg 160000" "j2 20000" "elements 20000" "hybrid 20000"; do
   echo "traffic $PROP $M done"
 done
 unset PROP M
-for prop in elements j2 hybrid; do
+for prop in fg elements j2; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$prop -- python3 $R/bench.py --propagator $prop --steps 958 --warmup 0 --no-cpu-baseline --no-legs --rollout 60 > $OUT/prof_$prop.json 2> $OUT/prof_$prop.err
   find $OUT/prof_$prop -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_$prop.csv \;
   head -3 $OUT/kernel_stats_$prop.csv

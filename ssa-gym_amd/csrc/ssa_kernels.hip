@@ -538,7 +538,7 @@ SSA_DEV void chol_step(const double (&a)[6], double (&uc)[6], int lc, bool& ok)
 // share scale * p with a neighbouring factorisation of the same matrix -- not at others.  One rounding more or less in a diagonal entry
 // is nothing, except for the matrices the ladder exists for: (n + lambda) P of a diverged filter has condition 1e20, the factor's last
 // rows move by 1e-8 relative with that bit, and two builds of the same source parted over an episode (round 3's "two-pass" ladder
-// picked the SAME rungs as the sequential one -- ssa_ladder_probe_f64, tests/golden/ladder_nonmonotone.npz -- and still left
+// picked the SAME rungs as the sequential one -- ssa_ladder_probe_f64, tests/golden/ladder_illconditioned_tile.npz -- and still left
 // different filters: its second factorisation was the unfused instance).  Now every instance is the reference's arithmetic.
 SSA_DEV double scaled_entry(double scale, double pv, double jit)
 {
@@ -673,13 +673,13 @@ SSA_DEV int robust_chol_row_lds(Tiles& t, double scale, int g, int l)
             }
             int found = 16;
             if (__ballot(!finite) == 0ull) {
-                // (Group by group from the bottom, NOT by bisection: with (n + lambda) P ~ 1e14 -- a diverged filter -- the low rungs'
-                // jitter is below the rounding noise of the pivots, success is then NOT monotone in the jitter, and the reference's
-                // answer is the first rung that happens to succeed.  A two-pass search (last rung of each group, then the group)
-                // was tried: 1 object in 20 000 picks another rung every ~270 steps and three filters that used to survive an
-                // episode fail -- build_ablate/ladder_ab.py.)
-#ifdef SSA_LADDER_TWO_PASS   // diagnostic ONLY (tests/golden/gen_ladder_nonmonotone.py): the search round 3 tried and reverted -- last rung of
-                // each group of four, then the group.  It assumes success is monotone in the jitter; the committed fixture is a case where it is not.
+                // (Group by group from the bottom: the reference's answer is the FIRST rung that factorises.  Round 3 believed success was not
+                // monotone in the jitter for a diverged filter's (n + lambda) P ~ 1e14 and blamed a two-pass search for three lost filters per
+                // episode; measured in round 4 (ssa_ladder_probe_f64, tests/test_hip_step.py::test_ladder_on_the_ill_conditioned_tile) it IS
+                // monotone on that tile and 4 096 perturbations of it -- the two builds differed in ONE rounding of the diagonal entry,
+                // scaled_entry above.)
+#ifdef SSA_LADDER_TWO_PASS   // diagnostic ONLY (build_ablate/ladder_probe_tile.py, profiles/r04_ladder_case.txt): the search round 3 tried and
+                // reverted -- last rung of each group of four, then the group.  It assumes success is monotone in the jitter (it is, on every case seen).
                 const bool ok1 = chol_row_regs<false>(Pg, scale, JITTER[4 * g + 3], g, l, uc);
                 const unsigned long long won1 = __ballot(ok1);
                 if (won1 != 0ull) {
