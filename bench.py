@@ -227,6 +227,18 @@ def local_variant_rate(m, K, W, propagator, resample=False, seed=100, regime_sor
     out = {"value": round(K / el * (m / 20000.0), 2), "ms_per_step": round(1e3 * el / K, 5),
            "failed_filters": int((eng.status != 0).sum().item())}
     out.update(spread(K, m / 20000.0, el, lo, hi, reps))
+    # this variant's kernel against the same roofline as `roofline` prices the headline's: one whole episode of per-step launches, the
+    # dominant kernel timed by the event pair bound to each dispatch
+    from ssa_gym_amd import _lib
+    nl = min(479, _lib.PROFILE_SLOTS)
+    local.reset_episode(snap, 480)
+    torch.cuda.synchronize()
+    for k in range(nl):
+        local.step(-1, profile_slot=k)
+    sync()
+    kern_ms = sum(eng.profile_ms(k) for k in range(nl)) / nl
+    out["kernel_ms"] = round(kern_ms, 5)
+    out["roofline_frac"] = round(ALG_BYTES_PER_OBJECT_STEP * m / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
     del eng, local, zn
     return out
 

@@ -449,10 +449,14 @@ int64_t ssa_closed_loop_workspace_bytes(int64_t n_obj, int32_t n_env);
  * seq_base lives in device memory so that a replayed hipGraph can advance it (as ssa_step_params.env_time does for the time index).
  * Plain kernels: capturable at any world size, no rendezvous inside the launch, no RCCL communicator.  The wait is bounded: a source that
  * has not arrived after timeout_ticks of the 100 MHz wall clock (0 = 2 s) sets error[0] = 1 + its index (if error != NULL) and the kernel
- * ends.  Flags only grow; the caller rotates >= 2 receive buffers (ssa-gym_amd/parallel.py: 3) and pushes step k only after it has waited
- * for step k - 1 of every peer (their readers of the slot being overwritten have then passed, in their stream order). */
+ * ends.  Flags only grow; the caller rotates >= 2 receive buffers (ssa-gym_amd/parallel.py: 3) and pushes step k to a peer only after that
+ * peer's payload of step k - 1 has arrived (its readers of the slot being overwritten have then passed, in its stream order): pass the
+ * rank's own flag words of the previous step's buffer as prev_flags and the push waits for exactly that, per peer, inside its launch
+ * (bounded like ssa_peer_wait; NULL = the caller has waited).  tickets: n_peer zeroed 32-bit device words owned by this exchange (a push
+ * is several workgroups per peer; the last one to finish raises the flag and leaves the ticket at zero). */
 int ssa_peer_push_f64(const double *src, int64_t n_words, double *const *dst, uint64_t *const *flag, int32_t n_peer,
-                      const uint64_t *seq_base, uint64_t seq_off, void *stream);
+                      const uint64_t *seq_base, uint64_t seq_off, const uint64_t *prev_flags, int64_t timeout_ticks, int32_t *error,
+                      uint32_t *tickets, void *stream);
 int ssa_peer_wait(const uint64_t *flags, int32_t n_src, const uint64_t *seq_base, uint64_t seq_off, int64_t timeout_ticks, int32_t *error,
                   void *stream);
 

@@ -112,7 +112,7 @@ SIGNATURES = {
     "ssa_masked_argmax_f64": (C.c_int, [c_dp, c_dp, C.c_int64, c_dp, c_dp]),
     "ssa_masked_argmax_ws_f64": (C.c_int, [c_dp, c_dp, C.c_int64, c_dp, c_dp, C.c_int64, c_dp]),
     "ssa_masked_argmax_workspace_bytes": (C.c_int64, [C.c_int64]),
-    "ssa_peer_push_f64": (C.c_int, [c_dp, C.c_int64, c_dp, c_dp, C.c_int32, c_dp, C.c_uint64, c_dp]),
+    "ssa_peer_push_f64": (C.c_int, [c_dp, C.c_int64, c_dp, c_dp, C.c_int32, c_dp, C.c_uint64, c_dp, C.c_int64, c_dp, c_dp, c_dp]),
     "ssa_peer_wait": (C.c_int, [c_dp, C.c_int32, c_dp, C.c_uint64, C.c_int64, c_dp, c_dp]),
     "ssa_aer_obs_f64": (C.c_int, [c_dp, c_dp, c_dp, C.POINTER(ssa_consts), c_dp, C.c_int64, c_dp]),
     "ssa_agent_select_f64": (C.c_int, [C.POINTER(ssa_consts), C.c_int32, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int32, C.c_int32,

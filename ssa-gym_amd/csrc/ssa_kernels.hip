@@ -3173,25 +3173,55 @@ static inline unsigned nblk(int64_t n, int bs) { return (unsigned)((n + bs - 1) 
 // device memory: a replayed graph advances it on the device, as the time index of the step launches).
 //   ordering: every lane's stores, a system-scope fence, the workgroup barrier, then ONE release store of the flag (system scope): a peer
 //   that reads the flag >= seq with an acquire load sees the whole payload.  Flags only grow (a 64-bit step counter).
-__global__ void __launch_bounds__(1024) peer_push_kernel(const double* __restrict__ src, int64_t n_words, double* const* __restrict__ dst,
-                                                         unsigned long long* const* __restrict__ flag,
-                                                         const unsigned long long* __restrict__ seq_base, unsigned long long seq_off)
+//   a push is PEER_SPLIT workgroups per peer (one workgroup moves 160 KB at a single CU's ~40 GB/s: 4 us); each fences at system scope and
+//   takes a ticket, the last one raises the flag.  prev_flags (optional): the rank's OWN flag words of the previous step's buffer -- the
+//   workgroups that write to peer r first wait (bounded) until r's payload of step seq - 1 has arrived here, by which time r's readers of the
+//   slot about to be overwritten (step seq - 3) have passed in r's stream order: the reuse rule of the rotating buffers inside the push itself,
+//   one dispatch per step instead of two.
+constexpr int PEER_SPLIT = 8;
+__global__ void __launch_bounds__(256) peer_push_kernel(const double* __restrict__ src, int64_t n_words, double* const* __restrict__ dst,
+                                                        unsigned long long* const* __restrict__ flag,
+                                                        const unsigned long long* __restrict__ seq_base, unsigned long long seq_off,
+                                                        const unsigned long long* __restrict__ prev_flags, long long timeout_ticks,
+                                                        int32_t* __restrict__ error, unsigned int* __restrict__ tickets)
 {
-    double* __restrict__ d = dst[blockIdx.x];
-    const int64_t n2 = n_words >> 1;
-    const bool wide = ((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
-    if (wide) {
-        const double2* __restrict__ s2 = reinterpret_cast<const double2*>(src);
-        double2* __restrict__ d2 = reinterpret_cast<double2*>(d);
-        for (int64_t i = threadIdx.x; i < n2; i += blockDim.x) d2[i] = s2[i];
-        if ((n_words & 1) && threadIdx.x == 0) d[n_words - 1] = src[n_words - 1];
-    } else {
-        for (int64_t i = threadIdx.x; i < n_words; i += blockDim.x) d[i] = src[i];
+    const int r = blockIdx.x, sl = blockIdx.y, t = threadIdx.x;
+    const unsigned long long seq = seq_base[0] + seq_off;
+    if (prev_flags && seq >= 2ull) {
+        if (t == 0) {
+            const long long t0 = (long long)wall_clock64();
+            while (__hip_atomic_load(&prev_flags[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq - 1ull) {
+                if ((long long)wall_clock64() - t0 > timeout_ticks) {
+                    if (error) atomicMax(error, 1 + r);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        __syncthreads();
+    }
+    double* __restrict__ d = dst[r];
+    int64_t chunk = (n_words + gridDim.y - 1) / gridDim.y;
+    chunk += chunk & 1;                                          // (even: the slices keep the 16-byte alignment of the whole)
+    const int64_t lo = (int64_t)sl * chunk, hi = (lo + chunk < n_words) ? lo + chunk : n_words;
+    if (lo < hi) {
+        const bool wide = ((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
+        if (wide) {
+            const double2* __restrict__ s2 = reinterpret_cast<const double2*>(src + lo);
+            double2* __restrict__ d2 = reinterpret_cast<double2*>(d + lo);
+            const int64_t n2 = (hi - lo) >> 1;
+            for (int64_t i = t; i < n2; i += blockDim.x) d2[i] = s2[i];
+            if (((hi - lo) & 1) && t == 0) d[hi - 1] = src[hi - 1];
+        } else {
+            for (int64_t i = lo + t; i < hi; i += blockDim.x) d[i] = src[i];
+        }
     }
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0)
-        __hip_atomic_store(flag[blockIdx.x], seq_base[0] + seq_off, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (t == 0 && atomicInc(&tickets[r], gridDim.y - 1) == gridDim.y - 1) {     // (the ticket wraps back to 0 with the last arrival)
+        __threadfence_system();
+        __hip_atomic_store(flag[r], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 // one wavefront: lane r waits for source r's flag to reach the step; `error` (optional) is set to 1 + r of a source that did not arrive
 // within timeout_ticks of the 100 MHz wall clock -- the wait ALWAYS ends (a peer that died must not hang the queue).
@@ -3719,12 +3749,14 @@ int ssa_masked_argmax_ws_f64(const double* score, const uint8_t* mask, int64_t n
 
 // ---- all-gather by direct peer stores (include/ssa_hip.h): no collective, plain kernels
 int ssa_peer_push_f64(const double* src, int64_t n_words, double* const* dst, uint64_t* const* flag, int32_t n_peer,
-                      const uint64_t* seq_base, uint64_t seq_off, void* stream)
+                      const uint64_t* seq_base, uint64_t seq_off, const uint64_t* prev_flags, int64_t timeout_ticks, int32_t* error,
+                      uint32_t* tickets, void* stream)
 {
-    if (n_peer < 0 || n_words < 0 || !seq_base || (n_peer > 0 && (!dst || !flag || (n_words > 0 && !src)))) return SSA_E_INVALID;
+    if (n_peer < 0 || n_words < 0 || !seq_base || (n_peer > 0 && (!dst || !flag || !tickets || (n_words > 0 && !src)))) return SSA_E_INVALID;
     if (n_peer == 0) return SSA_OK;
-    hipLaunchKernelGGL(peer_push_kernel, dim3(n_peer), dim3(1024), 0, (hipStream_t)stream, src, n_words, dst,
-                       (unsigned long long* const*)flag, (const unsigned long long*)seq_base, (unsigned long long)seq_off);
+    hipLaunchKernelGGL(peer_push_kernel, dim3(n_peer, PEER_SPLIT), dim3(256), 0, (hipStream_t)stream, src, n_words, dst,
+                       (unsigned long long* const*)flag, (const unsigned long long*)seq_base, (unsigned long long)seq_off,
+                       (const unsigned long long*)prev_flags, (long long)(timeout_ticks > 0 ? timeout_ticks : 200000000ll), error, tickets);
     return launch_status();
 }
 int ssa_peer_wait(const uint64_t* flags, int32_t n_src, const uint64_t* seq_base, uint64_t seq_off, int64_t timeout_ticks, int32_t* error,

@@ -700,18 +700,29 @@ class SSA_Tasker_Env(Env):
         ok = True
         try:
             policy(self.PolicyView(self, i0))      # (eagerly once, result unused: lazy initialisation must not happen inside the capture)
+            # no garbage collection inside the capture: a collected CUDAGraph of an env that went out of scope is DESTROYED by its finaliser,
+            # hipGraphDestroy is not permitted while a stream captures, and the error thrown from that destructor ends the process
+            # (seen once in the GPU suite under -s; torch.cuda.graph() collects before it captures for the same reason)
+            import gc
+            gc.collect()
             torch.cuda.synchronize()
-            with torch.cuda.stream(stream):
-                g.capture_begin(capture_error_mode="thread_local")
-                try:
-                    enqueue()
-                    g.capture_end()
-                except BaseException:
+            gc_was_on = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.stream(stream):
+                    g.capture_begin(capture_error_mode="thread_local")
                     try:
+                        enqueue()
                         g.capture_end()
-                    except Exception:  # noqa: BLE001
-                        pass
-                    raise
+                    except BaseException:
+                        try:
+                            g.capture_end()
+                        except Exception:  # noqa: BLE001
+                            pass
+                        raise
+            finally:
+                if gc_was_on:
+                    gc.enable()
         except TypeError:
             raise
         except Exception as exc:  # noqa: BLE001  (not capture-safe: remembered, the eager loop takes over)

@@ -191,12 +191,9 @@ class ShardedStepper:
             self.local.step(p.local_action(global_action), self._v_obs[b], self._v_stats[b], **kw)
         self._raw[b] = raw
         if self._peer is not None:
-            # in the step's own stream: wait for every peer's payload of the PREVIOUS step (normally there already; it also orders this
-            # push behind the peers' readers of the slot it overwrites, peer.py), then store this step's payload into every arena
-            if self.k >= 1 and self._waited < self.k:
-                self._peer.wait((self.k - 1) % self.NB, self.k, cur.cuda_stream)
-                self._waited = self.k
-            self._peer.push(send, b, self.k + 1, cur.cuda_stream)
+            # in the step's own stream, ONE launch: per peer, wait until its payload of the PREVIOUS step has arrived (normally there already;
+            # it orders this push behind that peer's readers of the slot it overwrites, peer.py), then store this step's payload into its arena
+            self._peer.push(send, b, self.k + 1, cur.cuda_stream, after=((self.k - 1) % self.NB) if self.k >= 1 else None)
         elif not use_dist:   # single process without a process group
             recv.copy_(send)
         elif overlap:
@@ -353,9 +350,7 @@ class GraphedShardedSteps:
                             stream=cur.cuda_stream)
             sh._raw[b] = True
             if sh._peer is not None:      # plain kernels in the unit's stream; step numbers relative to the device-side base
-                if k0 + j >= 1:
-                    sh._peer.wait((k0 + j - 1) % sh.NB, k0 + j, cur.cuda_stream)
-                sh._peer.push(sh.send[b], b, k0 + j + 1, cur.cuda_stream)
+                sh._peer.push(sh.send[b], b, k0 + j + 1, cur.cuda_stream, after=((k0 + j - 1) % sh.NB) if k0 + j >= 1 else None)
             elif self.overlap:
                 ev = torch.cuda.Event()
                 ev.record(cur)
@@ -407,7 +402,6 @@ class GraphedShardedSteps:
         finally:
             if sh._peer is not None:       # (the device-side base of the step numbers moved by U: the host's copy follows)
                 sh._peer.advanced(self.U)
-                sh._waited = max(sh._waited, sh.k - 1)
 
     def _run_unit(self, g, key, cur, tick0, k0):
         sh = self.sh
@@ -429,7 +423,11 @@ class GraphedShardedSteps:
         # left capturing makes the next allocation or copy of the process fail.  Here a failed capture is ended, every stream
         # is checked, the current stream is restored, and the phase falls back to the eager enqueue.)
         g = torch.cuda.CUDAGraph()
-        torch.cuda.synchronize()
+        import gc
+        gc.collect()               # (no collection inside the capture: a CUDAGraph finalised there is destroyed while a stream captures -- not
+        torch.cuda.synchronize()   # permitted, and an error thrown from that destructor ends the process)
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
             with torch.cuda.stream(self._stream):
                 g.capture_begin(capture_error_mode="thread_local")
@@ -450,6 +448,9 @@ class GraphedShardedSteps:
             self._graphs[key] = False
             self.capture_failed = repr(exc)
             # (what the aborted capture recorded of the device-side advances never ran; the eager unit above did advance them once: consistent)
+        finally:
+            if gc_was_on:
+                gc.enable()
         cur.wait_stream(self._stream)
 
 

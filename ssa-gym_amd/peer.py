@@ -4,17 +4,20 @@ One process per GPU.  Every rank owns an arena in its HBM -- NB receive buffers 
 64-bit flag words -- and maps the arenas of all its peers once, over hipIpc (torch's CUDA-IPC reductions carry the handles through the
 process group; nothing else is ever sent through it).  After its step kernel a rank
 
-    push(b, k): writes its payload of step k into slot [b][rank] of EVERY arena (its own included) and then stores k into flag [b][rank] there
+    push(b, k): waits (per peer, inside the launch) until that peer's payload of step k - 1 has arrived, writes its payload of step k into slot
+                [b][rank] of EVERY arena (its own included) and then stores k into flag [b][rank] there
     wait(b, k): lets the stream wait until the `world` flags of buffer b in the OWN arena have reached k
 
-(`ssa_peer_push_f64`, `ssa_peer_wait`, include/ssa_hip.h).  No collective library, no communicator, no rendezvous inside a launch: two plain
+(`ssa_peer_push_f64`, `ssa_peer_wait`, include/ssa_hip.h).  No collective library, no communicator: plain
 kernels, capturable into a hipGraph at any world size; over xGMI a push is `world - 1` point-to-point writes of 160 KB (20 000 objects,
 covariance-trace payload), each over its own link.  The step number of a launch is seq0 (device memory) + an offset, so that a replayed graph
 advances it on the device.
 
 The reference has no counterpart (one env per process, no exchange step: SURVEY section 5 "distributed backend"); the oracle of this module is
-the all-gather it replaces: `tests/test_hip_step.py::test_peer_store_allgather_world2_on_one_card` runs two ranks on the one card of the test
-box and compares every step's reassembled payload, bit for bit, with torch.distributed's all_gather of the same buffers.
+the all-gather it replaces: `tests/test_parallel_gloo.py::test_sharded_hip_env_world2_shares_one_gpu[*-peer-*]` runs two ranks on the one card of
+the test box -- per step from the host and as replayed hipGraph units -- and compares every step's reassembled observations, statistics and
+states, bit for bit, with the unsharded engine and with the collective's path; `tests/test_hip_step.py::test_graphed_sharded_steps_equal_eager_steps`
+covers one rank, the forced capture failure and the bounded wait.
 """
 import torch
 import torch.distributed as dist
@@ -39,6 +42,7 @@ class PeerExchange:
         self.seq0 = torch.zeros(1, dtype=torch.int64, device=dev)               # the step number the offsets count from (device)
         self.seq0_host = 0                                                        # ... and what the host knows it to be
         self.error = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._tickets = torch.zeros(self.world, dtype=torch.int32, device=dev)   # (a push is several workgroups per peer: the last raises the flag)
         self.timeout_ticks = int(timeout_s * 1e8)
         self._peers = [None] * w
         self._peers[self.rank] = self.arena
@@ -69,9 +73,12 @@ class PeerExchange:
             dist.barrier(group=group)                                             # every rank has mapped every arena before the first push
 
     # seq = the 1-based number of the step; the offset handed to the kernels is relative to the device-side base
-    def push(self, send, b, seq, stream):
+    def push(self, send, b, seq, stream, after=None):
+        """after = the buffer of step seq - 1: the push to peer r starts when r's payload of that step has arrived here (the reuse rule of the
+        rotating buffers, inside the launch: no separate wait in front of it)"""
         _lib.check(self._lib.ssa_peer_push_f64(send.data_ptr(), self.width, self._dst_ptr[b], self._flg_ptr[b], self.world, self._seq_ptr,
-                                                seq - self.seq0_host, stream), "ssa_peer_push_f64")
+                                                seq - self.seq0_host, self._own_flags[after] if after is not None else None,
+                                                self.timeout_ticks, self._err_ptr, self._tickets.data_ptr(), stream), "ssa_peer_push_f64")
 
     def wait(self, b, seq, stream):
         _lib.check(self._lib.ssa_peer_wait(self._own_flags[b], self.world, self._seq_ptr, seq - self.seq0_host, self.timeout_ticks,

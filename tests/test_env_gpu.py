@@ -837,3 +837,44 @@ def test_observation_paths_agree(envs, mode):
         prev = (o, o.copy())
     if mode == 'aer':
         assert o is host.observation
+
+
+def test_graph_capture_survives_garbage_collection_of_older_graphs():
+    """A captured hipGraph that becomes garbage (an env that went out of scope: env <-> closure cycles, so only the cyclic collector frees it)
+    must not be finalised WHILE another capture is in progress: hipGraphDestroy is not permitted while a stream captures, and the error
+    thrown from the graph's destructor ends the process (seen once in the GPU suite of round 4).  The captures collect first and keep the
+    collector off until they end.  In a child process: the failure mode is an abort, not an exception."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r'''
+import gc, sys
+sys.path.insert(0, %r)
+import torch
+from ssa_gym_amd.envs import env_config, make
+cfg = dict(env_config)
+cfg.update(rso_count=41, steps=200, reward_type='trinary', obs_returned='flatten', seed=13, obs_limit=5.0, history=2)
+def policy(view):
+    sc, mask = view.scores()
+    return torch.clamp(view.argmax(sc[0], mask), min=0)
+old = [make(config=cfg) for _ in range(3)]
+for e in old:
+    e.run_policy(policy, 64, graph=True)
+    assert e.policy_graph_error is None
+    e._cycle = e                             # (a reference cycle: only the cyclic collector can free this env and its graphs)
+gc.collect()
+gc.disable()
+del old, e                                   # three captured graphs, now garbage reachable only through reference cycles: nothing frees them ...
+calls = {"n": 0}
+def collecting(view):                        # ... until a collection runs in the MIDDLE of the next capture (call 1 is the eager warm-up)
+    calls["n"] += 1
+    if calls["n"] == 4:
+        gc.collect()
+    return policy(view)
+env = make(config=cfg)
+a, _, _ = env.run_policy(collecting, 96, graph=True)
+assert env.policy_graph_error is None and len(a) == 96 and calls["n"] >= 33
+print("ok")
+''' % (ROOT,)
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.returncode, out.stderr[-1500:])
