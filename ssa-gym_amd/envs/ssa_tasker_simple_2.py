@@ -128,6 +128,16 @@ class _FailureMessages:
         return (self[j] for j in range(self._m))
 
 
+def _never_destroy(graph):
+    """a torch.cuda.CUDAGraph whose capture FAILED must not be finalised: capture_end() threw before the graph let go of the RNG generator
+    state it registered with, and in this torch build (2.10 + ROCm 7) its destructor then fails a TORCH_CHECK ("The graph should be registered
+    to the state") -- an exception out of a C++ destructor: the process aborts, whenever the object happens to be freed (at the return of the
+    capturing function, or later by the garbage collector).  One leaked reference keeps the few hundred bytes alive for the life of the
+    process (build_ablate/r04_run20.sh isolated it: tests/test_env_gpu.py::test_run_policy_replayed_from_a_graph_equals_the_eager_loop)."""
+    import ctypes
+    ctypes.pythonapi.Py_IncRef(ctypes.py_object(graph))
+
+
 class SSA_Tasker_Env(Env):
     metadata = {'render.modes': ['live', 'none']}
     visualization = None
@@ -729,6 +739,7 @@ class SSA_Tasker_Env(Env):
             ok = False
             self.policy_graph_error = repr(exc)
             e._fold_pending = None
+            _never_destroy(g)
         torch.cuda.current_stream().wait_stream(stream)
         ent = (g, stats_d, upd_d, acts_d, stream, hosts, copy_stream) if ok else None
         self._policy_graphs[key] = ent

@@ -447,6 +447,9 @@ class GraphedShardedSteps:
         except Exception as exc:  # noqa: BLE001
             self._graphs[key] = False
             self.capture_failed = repr(exc)
+            import ctypes
+            ctypes.pythonapi.Py_IncRef(ctypes.py_object(g))     # (a graph whose capture failed is never finalised: its destructor aborts the
+            #                                                      process in this torch build -- envs/ssa_tasker_simple_2.py::_never_destroy)
             # (what the aborted capture recorded of the device-side advances never ran; the eager unit above did advance them once: consistent)
         finally:
             if gc_was_on:
