@@ -226,6 +226,9 @@ class SSA_Tasker_Env(Env):
         self._consts, _ = kernel_consts(config, self.Q, self.R, self.dt, self.obs_limit, self.obs_lla)
         self._engine = None
         self._device_rng = bool(config.get('device_rng', False))
+        self._layout = config.get('layout')          # None (the reference's object order) | 'regime' (see reset())
+        if self._layout not in (None, 'regime'):
+            raise ValueError("config['layout'] must be None or 'regime', not %r" % (self._layout,))
         self._obs_buffers = config.get('obs_buffers', 2)
         # step() hands out a FRESH array per call for the 'flatten' and (m, 12) observations, as the reference does (:360-366: `.flatten()` /
         # a row of the history that no later step overwrites) -- a consumer may keep it as long as it likes (replay buffers, sample
@@ -302,6 +305,17 @@ class SSA_Tasker_Env(Env):
             for j in range(m):   # draw order of :206-209: (row, 6 normals) per object ...
                 x_true0[j] = self.orbits[self.np_random.randint(low=0, high=N), :]
                 self.x_noise[j] = self.np_random.normal(size=6) * self.x_sigma
+        # config['layout'] = 'regime' (opt-in, round 4): the SAME draws, stored in another order -- ascending semi-major axis, dealt tile by tile
+        # over the XCDs (catalogue.regime_order) -- so that objects of one regime share wavefronts: late in an episode the diverged filters
+        # are the LEO objects, and an env of 20 000 objects steps 13 % faster with them packed.  It RELABELS the
+        # objects: object j of this env is draw number object_order[j] of the reference's order (actions, observations, histories and
+        # failure ids all speak the env's own labels); results per object are bit-identical.  Default: the reference's order.
+        self.object_order = None
+        if self._layout == 'regime':
+            from ..catalogue import regime_order
+            self.object_order = regime_order(x_true0)
+            x_true0 = np.ascontiguousarray(x_true0[self.object_order])
+            self.x_noise[:] = self.x_noise[self.object_order]
         x_filter0 = x_true0 + self.x_noise
         # ... then n*m*3 normals (:219-221); RandomState.normal keeps its Box-Muller cache across
         # calls, so one bulk draw consumes the stream exactly like the reference's n*m size-3 draws
@@ -312,6 +326,8 @@ class SSA_Tasker_Env(Env):
             self.z_noise = None
         else:
             self.z_noise = self.np_random.normal(size=(n, m, 3)) * self.z_sigma
+            if self.object_order is not None:
+                self.z_noise = np.ascontiguousarray(self.z_noise[:, self.object_order])
             self._z_noise_dev = torch.as_tensor(self.z_noise, dtype=torch.float64).to("cuda")
         if self._engine is None:
             self._build_engine()

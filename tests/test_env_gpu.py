@@ -878,3 +878,30 @@ print("ok")
 ''' % (ROOT,)
     out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.returncode, out.stderr[-1500:])
+
+
+def test_regime_layout_relabels_the_objects_and_changes_nothing_else(envs):
+    """config['layout'] = 'regime' (opt-in): the same draws stored by regime (catalogue.regime_order) -- object j of that env is draw
+    object_order[j] of the default env.  Fed the relabelled actions it produces, object by object, the same bits: states, covariances,
+    observations, rewards, update records, failure ids."""
+    cfg = dict(envs.env_config)
+    cfg.update(rso_count=96, steps=60, reward_type='trinary', obs_returned='flatten', seed=21, history='full')
+    a = envs.make(config=cfg)
+    b = envs.make(config=dict(cfg, layout='regime'))
+    order = b.object_order
+    assert a.object_order is None and sorted(order.tolist()) == list(range(96)) and not np.array_equal(order, np.arange(96))
+    inv = np.empty(96, dtype=int)
+    inv[order] = np.arange(96)
+    assert np.array_equal(np.asarray(a.x_true[0])[order], np.asarray(b.x_true[0]))
+    rs = np.random.RandomState(3)
+    for k in range(40):
+        act = int(rs.randint(96))
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(int(inv[act]))
+        assert ra == rb and da == db and np.array_equal(oa.reshape(96, 12)[order], ob.reshape(96, 12))
+    for name in ("x_true", "x_filter", "P_filter", "delta_pos", "sigma_pos"):
+        assert np.array_equal(np.asarray(getattr(a, name)[40])[order], np.asarray(getattr(b, name)[40])), name
+    assert np.array_equal(inv[a.actions[1:41].astype(int)], b.actions[1:41].astype(int))
+    assert np.array_equal(np.asarray(a.z_true[1:41])[:, order], np.asarray(b.z_true[1:41]), equal_nan=True)
+    with pytest.raises(ValueError):
+        envs.make(config=dict(cfg, layout='sorted'))
