@@ -386,6 +386,12 @@ def torch_policy_rate(m, n=192):
             a, _, _ = env.run_policy(pol, n, graph=graph)
             picked.extend(a.tolist())
         return timed_repeats(block, lambda: None, prepare=prepare)
+    neg_inf = torch.full((), float("-inf"), dtype=torch.float64, device="cuda")
+
+    def policy_lean(view):          # the same rule written for the GPU: the -inf operand preallocated, torch.argmax's int64 handed back as it is
+        sc, mask = view.scores()
+        return torch.argmax(torch.where(mask.view(torch.bool), sc[0], neg_inf))
+
     def policy_head(view):          # the same rule with the env's one-launch arg-max head instead of torch.where + torch.argmax + a cast
         sc, mask = view.scores()
         return view.argmax(sc[0], mask)
@@ -393,6 +399,7 @@ def torch_policy_rate(m, n=192):
     elg0, _, _, _ = measure(fixed_policy, True)
     ele, _, _, _ = measure(policy, False)
     elh, _, _, _ = measure(policy_head, True)
+    ell, _, _, _ = measure(policy_lean, True)
     picked.clear()
     el, lo, hi, reps = measure(policy, True)
     dt = el / n
@@ -404,6 +411,9 @@ def torch_policy_rate(m, n=192):
                               "note": "eager, with a policy that returns a preallocated tensor: what run_policy itself costs (step launch + bookkeeping)"},
             "env_side_only_graph": {"value": round(n / elg0 * (m / 20000.0), 2), "ms_per_step": round(1e3 * elg0 / n, 5),
                                     "note": "the same from replayed graphs: the step launches alone, bookkeeping of chunk c hidden behind chunk c + 1"},
+            "lean_torch": {"value": round(n / ell * (m / 20000.0), 2), "ms_per_step": round(1e3 * ell / n, 5),
+                           "note": "graph replay; the same rule in two torch kernels less: the -inf operand preallocated (the scalar form launches a fill), "
+                                   "torch.argmax's int64 handed back as it is (run_policy reads its low word: no cast kernel)"},
             "argmax_head": {"value": round(n / elh * (m / 20000.0), 2), "ms_per_step": round(1e3 * elh / n, 5),
                             "note": "graph replay; the policy = view.scores() + view.argmax(score, mask) (PolicyView.argmax: the arg-max head as ONE launch of the "
                                     "library, np.argmax semantics) instead of torch.where + torch.argmax + .to(int32), which are 4 launches and 25 us of the 45 a step "

@@ -128,6 +128,19 @@ class _FailureMessages:
         return (self[j] for j in range(self._m))
 
 
+def _action_word(a):
+    """what a policy handed back, as the int32 word the next step launch reads: a CUDA int32 tensor with one element, or -- what torch.argmax
+    returns -- an int64 one, whose LOW word is the action (little endian; -1 stays -1): no cast kernel (5 us at 20 000 objects inside a replayed
+    graph, profiles/r04_run_policy_timeline.txt)."""
+    import torch
+    if isinstance(a, torch.Tensor) and a.is_cuda and a.numel() == 1:
+        if a.dtype == torch.int32:
+            return a
+        if a.dtype == torch.int64:
+            return a.reshape(1).view(torch.int32)[:1]
+    raise TypeError("run_policy: the policy must return a CUDA int32 (or int64) tensor with one element (the action)")
+
+
 def _never_destroy(graph):
     """a torch.cuda.CUDAGraph whose capture FAILED must not be finalised: capture_end() threw before the graph let go of the RNG generator
     state it registered with, and in this torch build (2.10 + ROCm 7) its destructor then fails a TORCH_CHECK ("The graph should be registered
@@ -707,9 +720,7 @@ class SSA_Tasker_Env(Env):
         def enqueue():
             for k in range(K):
                 i = i0 + k + 1
-                a = policy(self.PolicyView(self, i - 1, tix_off=k))
-                if not (isinstance(a, torch.Tensor) and a.is_cuda and a.dtype == torch.int32 and a.numel() == 1):
-                    raise TypeError("run_policy: the policy must return a CUDA int32 tensor with one element (the action)")
+                a = _action_word(policy(self.PolicyView(self, i - 1, tix_off=k)))
                 acts_t.append(a)          # (read by the step below; gathered into acts_d ONCE per replay, behind the graph)
                 e.launch_step((i - 1) % e.H, i % e.H, k + 1, actions_ptr=a.data_ptr(), fast_stats=True, defer_fold=True,
                               stats_out=stats_d[k].data_ptr(), upd_out=upd_d[k].data_ptr(), argmax_spos=shaped)
@@ -763,7 +774,7 @@ class SSA_Tasker_Env(Env):
 
     def run_policy(self, policy, n_steps, graph='auto'):
         """Closed loop with an ARBITRARY policy evaluated on the GPU (a torch module, a hand-written rule):
-            a = policy(view)          # view: SSA_Tasker_Env.PolicyView -- CUDA tensors; returns an int32 CUDA tensor [1]
+            a = policy(view)          # view: SSA_Tasker_Env.PolicyView -- CUDA tensors; returns an int32 (or int64: torch.argmax) CUDA tensor [1]
             step(a)
         repeated n_steps times with NO host round trip: the action never leaves the device (the step kernel reads it from the
         tensor the policy returned), the statistics and update records go to device rings, ONE synchronisation at the end, then the
@@ -857,9 +868,7 @@ class SSA_Tasker_Env(Env):
             acts_d = []
             for k in range(kk):
                 i = i0 + k + 1
-                a = policy(self.PolicyView(self, i - 1))
-                if not (isinstance(a, torch.Tensor) and a.is_cuda and a.dtype == torch.int32 and a.numel() == 1):
-                    raise TypeError("run_policy: the policy must return a CUDA int32 tensor with one element (the action)")
+                a = _action_word(policy(self.PolicyView(self, i - 1)))
                 acts_d.append(a)          # (kept alive until the launches that read it have run)
                 e.launch_step((i - 1) % e.H, i % e.H, i, actions_ptr=a.data_ptr(), fast_stats=True, defer_fold=True,
                               stats_out=stats_d[k].data_ptr(), upd_out=upd_d[k].data_ptr(), argmax_spos=shaped)

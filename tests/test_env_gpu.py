@@ -629,8 +629,13 @@ def test_run_policy_replayed_from_a_graph_equals_the_eager_loop(envs):
         sc, mask = view.scores()
         return torch.clamp(view.argmax(sc[0], mask), min=0)
 
+    def handing_back_int64(view):            # torch.argmax's own int64 (0-dim): run_policy reads its low word, no cast kernel
+        sc, mask = view.scores()
+        j = torch.argmax(torch.where(mask.view(torch.bool), sc[0], float("-inf")))
+        return torch.where(mask.view(torch.bool).any(), j, torch.zeros_like(j))
+
     picked = {}
-    for policy, capturable in ((visible_greedy, True), (with_the_argmax_head, True), (syncing, False)):
+    for policy, capturable in ((visible_greedy, True), (with_the_argmax_head, True), (handing_back_int64, True), (syncing, False)):
         a, b = envs.make(config=cfg), envs.make(config=cfg)
         ra = a.run_policy(policy, 107, graph=True)           # 3 replays of 32 (pipelined: chunk c is booked while c + 1 runs) + 11 eager steps
         rb = b.run_policy(policy, 107, graph=False)
@@ -651,6 +656,9 @@ def test_run_policy_replayed_from_a_graph_equals_the_eager_loop(envs):
         o2, r2, _, _ = b.step(3)
         assert np.array_equal(o1, o2) and r1 == r2
     assert np.array_equal(picked["visible_greedy"], picked["with_the_argmax_head"])
+    assert np.array_equal(picked["visible_greedy"], picked["handing_back_int64"])
+    with pytest.raises(TypeError, match="int32 .or int64. tensor"):
+        envs.make(config=cfg).run_policy(lambda view: torch.zeros(1, device="cuda"), 3)
     # an action out of range surfaces as ValueError (graph form: when its chunk is booked, one chunk behind the GPU)
     bad = envs.make(config=cfg)
     out_of_range = torch.full((1,), 41, dtype=torch.int32, device="cuda")
