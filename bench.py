@@ -76,22 +76,25 @@ def host_cpu_share():
     return n
 
 
-MIN_TIMED_S = 0.05      # every rate of the line is the median over repeats of its timed block, repeated until >= 50 ms in total
+MIN_TIMED_S = 0.05      # every timed block is repeated until the blocks add up to >= 50 ms (timed_repeats)
 MIN_REPEATS, MAX_REPEATS = 3, 400
 
 
-def timed_repeats(block, sync, agree=None, prepare=None):
+def timed_repeats(block, sync, agree=None, prepare=None, group=1):
     """`block()` enqueues EXACTLY the K steps of one timed block; `sync()` is the fence on both sides of it.  The block is
     repeated until the timed blocks add up to MIN_TIMED_S (a 20-step block of 14 us steps is 0.3 ms: one sample of it says
-    little); returns (mean, min, max, repeats) of the per-block elapsed seconds.  The MEAN, not the median (rounds 1-3): with the
-    behaviour-faithful default a step late in an episode costs twice a step early in it, the blocks of a run tile whole episodes, and
-    the sustained rate is total steps / total time -- the median block (the healthy part of the episode is the majority) read 10 %
-    high and below the kernel's own whole-episode mean.  A block beyond 4 x the median (a hiccup of the box, not the workload: the
-    workload's own spread is 2 x) counts as 4 x the median.  `agree(x)` makes a per-rank number
-    rank-uniform (MAX over ranks), so that every rank runs the same number of repeats.  `prepare()` runs untimed before
-    every block (e.g. an env reset when the episode would end inside the block)."""
+    little); returns (typical, min, max, repeats) of the per-block elapsed seconds.
+    `group`: how many CONSECUTIVE blocks make one sample -- callers whose blocks walk through an episode pass the number of blocks
+    that span one (ceil(479 / K)).  With the behaviour-faithful default a step late in an episode costs twice a step early in it;
+    the MEDIAN BLOCK (rounds 1-3) then reads the healthy majority (56.9 k with the driver's 20-step blocks where whole episodes run
+    at 51.7 k, below the kernel's own whole-episode mean), the plain MEAN is exact but takes every hiccup of a shared box at face
+    value.  typical = the median over the groups of the mean block time inside each group: every sample covers a whole episode,
+    and the median over samples keeps the robustness.  group = 1: the median block, as before.
+    `agree(x)` makes a per-rank number rank-uniform (MAX over ranks), so that every rank runs the same number of repeats.
+    `prepare()` runs untimed before every block (e.g. an env reset when the episode would end inside the block)."""
     agree = agree or (lambda v: v)
     prepare = prepare or (lambda: None)
+    group = max(1, int(group))
     el = []
     prepare()
     sync()
@@ -100,6 +103,8 @@ def timed_repeats(block, sync, agree=None, prepare=None):
     sync()
     el.append(agree(time.perf_counter() - t0))
     reps = int(min(MAX_REPEATS, max(MIN_REPEATS, np.ceil(MIN_TIMED_S / max(el[0], 1e-9)))))
+    if group > 1:                        # whole groups, at least three of them
+        reps = group * max(3, -(-reps // group))
     for _ in range(reps - 1):
         prepare()
         sync()
@@ -107,8 +112,13 @@ def timed_repeats(block, sync, agree=None, prepare=None):
         block()
         sync()
         el.append(agree(time.perf_counter() - t0))
-    med = float(np.median(el))
-    return float(np.mean(np.minimum(el, 4.0 * med))), float(min(el)), float(max(el)), len(el)
+    samples = np.asarray(el).reshape(-1, group).mean(axis=1)
+    return float(np.median(samples)), float(min(el)), float(max(el)), len(el)
+
+
+def episode_groups(steps_per_block, episode=479):
+    """blocks that span one episode (timed_repeats' `group`)"""
+    return max(1, -(-episode // max(1, int(steps_per_block))))
 
 
 def spread(K, scale, med, lo, hi, reps):
@@ -228,7 +238,7 @@ def local_variant_rate(m, K, W, propagator, resample=False, seed=100, regime_sor
     def sync():
         local.flush()
         torch.cuda.synchronize()
-    el, lo, hi, reps = timed_repeats(lambda: run(K), sync)
+    el, lo, hi, reps = timed_repeats(lambda: run(K), sync, group=episode_groups(K))
     out = {"value": round(K / el * (m / 20000.0), 2), "ms_per_step": round(1e3 * el / K, 5),
            "failed_filters": int((eng.status != 0).sum().item())}
     out.update(spread(K, m / 20000.0, el, lo, hi, reps))
@@ -314,7 +324,7 @@ def closed_loop_rate(m, K, W, seed=100, persistent=True, chunk=120, agent=None, 
     def block():
         st["n"] = W
         run(K)
-    el, lo, hi, reps = timed_repeats(block, sync)
+    el, lo, hi, reps = timed_repeats(block, sync, group=episode_groups(K))
     if persistent and int(eng.loop_error[0]) != 0:
         raise RuntimeError("ssa_env_closed_loop_f64 gave up on a timeout")
     chosen = picks[W + 1:W + K + 1, 0].cpu().numpy()
@@ -326,14 +336,14 @@ def closed_loop_rate(m, K, W, seed=100, persistent=True, chunk=120, agent=None, 
                     "closed loop on the device: step launch + ssa_agent_select_f64 (2 launches) per step, no host round trip"}
 
 
-def gym_api_rate(m, mode, n=200, obs_device=False, zero_copy=False):
+def gym_api_rate(m, mode, n=200, obs_device=False, zero_copy=False, obs_pool=64):
     """env.step() through the gym API (host in the loop: action in, launch, one sync, statistics + observation out over
     PCIe): the closed-loop rate an unmodified agents.py / RLlib worker sees.  Never `value`.  zero_copy: config['obs_zero_copy'] --
     step() hands out a view of the host-mapped ring instead of a fresh copy (the default, as the reference)."""
     from ssa_gym_amd.envs import env_config, make
     cfg = dict(env_config)
     cfg.update(rso_count=m, steps=480, reward_type='trinary', obs_returned=mode, seed=0, history=2, device_rng=True, obs_device=obs_device,
-               obs_zero_copy=zero_copy)
+               obs_zero_copy=zero_copy, obs_pool=obs_pool)
     env = make(config=cfg)
     for k in range(20):
         env.step(k % m)
@@ -765,7 +775,8 @@ def main():
     def timed_block():
         for k in range(W, W + K):
             one_step(k)
-    elapsed, el_min, el_max, repeats = timed_repeats(timed_block_graph if graphed is not None else timed_block, fence, agree=max_over_ranks)
+    elapsed, el_min, el_max, repeats = timed_repeats(timed_block_graph if graphed is not None else timed_block, fence, agree=max_over_ranks,
+                                                         group=episode_groups(K))
 
     # sanity: nothing diverged during the run
     n_failed = int((eng.status != 0).sum().item())
@@ -834,7 +845,7 @@ def main():
                 done += kk
         Kr = max(K, 4 * R)        # (at least four full launches per timed block, whatever --steps was)
         roll_steps(max(W, R))
-        el, lo, hi, reps = timed_repeats(lambda: roll_steps(Kr), torch.cuda.synchronize)
+        el, lo, hi, reps = timed_repeats(lambda: roll_steps(Kr), torch.cuda.synchronize, group=episode_groups(Kr))
         roll = {"steps_per_launch": R, "steps": Kr, "value": round(Kr / el * (m / 20000.0), 2), "ms_per_step": round(1e3 * el / Kr, 5),
                 **spread(Kr, m / 20000.0, el, lo, hi, reps),
                 "failed_filters": int((eng.status != 0).sum().item()),
@@ -873,9 +884,13 @@ def main():
                                        "(SSA_E_UNSUPPORTED), the closed loop runs as step + ssa_agent_select_f64 launches")
         legs["gym_api"] = {"flatten": gym_api_rate(m, 'flatten'), "aer": gym_api_rate(m, 'aer'),
                            "flatten_zero_copy": gym_api_rate(m, 'flatten', zero_copy=True),
+                           "flatten_copy": gym_api_rate(m, 'flatten', obs_pool=0),
                            "flatten_device_obs": gym_api_rate(m, 'flatten', obs_device=True),
                            "note": "SSA_Tasker_Env.step() per call, host in the loop, PCIe + one sync inclusive (20 000 objects).  flatten: the default "
-                                   "-- a FRESH observation array per step, as the reference (1.92 MB host copy); flatten_zero_copy: config['obs_zero_copy'] "
+                                   "-- a FRESH observation array per step, as the reference, WITHOUT a copy: a pinned buffer nobody holds, written by the "
+                                   "kernel, taken back when the consumer drops the array (envs/_obspool.py); flatten_copy: what a consumer that keeps more "
+                                   "than config['obs_pool'] = 64 observations alive gets (a 1.92 MB host copy per step; obs_pool = 0 here); "
+                                   "flatten_zero_copy: config['obs_zero_copy'] "
                                    "-- a view of the two-deep host-mapped ring the kernel writes; aer: the reference's one persistent array; "
                                    "flatten_device_obs: config['obs_device'] -- the observation stays on the GPU as a CUDA tensor (a policy that "
                                    "lives there), reward / done still cross PCIe"}
@@ -907,7 +922,7 @@ def main():
             "unit": "env-steps/s (20 000-object UKF+propagate steps, summed over GPUs)",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 5),
             "repeats": repeats, "value_spread": [round(K / el_max * world * (m / 20000.0), 2), round(K / el_min * world * (m / 20000.0), 2)],
-            "timing": "mean over `repeats` timed blocks of exactly `steps` steps, each between two fences (repeated until >= 50 ms in total)",
+            "timing": "`repeats` timed blocks of exactly `steps` steps, each between two fences (repeated until >= 50 ms in total and at least three whole episodes); value = the median over episode-long groups of consecutive blocks of the mean block inside each group",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "ssa_tasker_simple-v2 hot path: %d objects/GPU x %d GPU, %s + "
                                    "UKF predict (13 sigma points) + 1 az-el-range update/step%s" %

@@ -248,6 +248,7 @@ class SSA_Tasker_Env(Env):
         # collectors, GAE targets).  config['obs_zero_copy'] = True (opt-in): a VIEW of the host-mapped ring the kernel writes, valid until
         # `obs_buffers` (default 2) further steps have been taken -- no 1.9 MB host copy per step at 20 000 objects
         self._obs_zero_copy = bool(config.get('obs_zero_copy', False))
+        self._obs_pool_cap = config.get('obs_pool', 64)      # (pinned buffers that may be out with the consumer at once; beyond: copies)
         # the persistent closed loop's bound on any wait inside the launch (100 MHz ticks; 0 = the library's 2 s)
         self._loop_wait_ticks = int(config.get('closed_loop_wait_ticks', 0))
         self._loop_debug_withhold = False
@@ -298,6 +299,10 @@ class SSA_Tasker_Env(Env):
         self._upd_ptr, self._stats_ptr = self._upd_host.data_ptr(), self._stats_host.data_ptr()
         if aer:
             self.observation = self._obs_ring_np[0]
+        # default hand-out of the 'flatten' / (m, 12) observation: a buffer nobody holds, written by the kernel, returned as a fresh array,
+        # taken back when the consumer lets go of it (envs/_obspool.py) -- the reference's semantics without the copy
+        from ._obspool import ObsPool
+        self._obs_pool = None if (aer or self._obs_zero_copy or self._obs_device) else ObsPool(nobs, shape, cap=int(self._obs_pool_cap))
         self.x_true = _History(self, e.x_true, self.m, (6,))
         self.x_filter = _History(self, e.x_filter, self.m, (6,))
         self.P_filter = _History(self, e.P_filter, self.m, (6, 6))
@@ -410,8 +415,11 @@ class SSA_Tasker_Env(Env):
                           fast_stats=True, fold_inside=True, argmax_spos=shaped)
             obs_np = self._aer_dev if aer else (e.obs[i % e.H].reshape(-1) if self.obs_returned == 'flatten' else e.obs[i % e.H])
         else:
+            pool = self._obs_pool
+            kp = pool.acquire() if pool is not None else None
             e.launch_step((i - 1) % e.H, i % e.H, i, action=int(a),
-                          aer_out=self._obs_ring_ptr[0] if aer else 0, obs_mirror=0 if aer else self._obs_ring_ptr[k],
+                          aer_out=self._obs_ring_ptr[0] if aer else 0,
+                          obs_mirror=0 if aer else (pool.ptrs[kp] if kp is not None else self._obs_ring_ptr[k]),
                           stats_out=self._stats_ptr, upd_out=self._upd_ptr, stream=cur.cuda_stream,
                           fast_stats=True, fold_inside=True, argmax_spos=shaped)
             obs_np = self._obs_ring_np[k]
@@ -430,7 +438,12 @@ class SSA_Tasker_Env(Env):
             done = True
         # 'aer' hands out its ONE persistent array refreshed in place, as the reference does (:362-363: self.observation); the other
         # modes a fresh copy unless config['obs_zero_copy']
-        obs = obs_np if (aer or self._obs_device or self._obs_zero_copy) else obs_np.copy()
+        if aer or self._obs_device or self._obs_zero_copy:
+            obs = obs_np
+        elif kp is not None:
+            obs = self._obs_pool.hand_out(kp)       # fresh array, no copy: the buffer comes back when the consumer drops it
+        else:
+            obs = obs_np.copy()                     # (more than `obs_pool` observations alive at once)
         e_t = time.time()
         self.runtime['Observations and Reward'] += e_t - t_dev
         self.runtime['step'] += e_t - step_s

@@ -71,6 +71,10 @@ class SSA_Tasker_VecEnv:
         self._obs_ring = [torch.zeros(self.E * per, dtype=torch.float64).pin_memory() for _ in range(2)]
         self._obs_ring_np = [b.numpy().reshape(oshape) for b in self._obs_ring]
         self._obs_ring_ptr = [b.data_ptr() for b in self._obs_ring]
+        # default hand-out: a buffer nobody holds, written by the kernel, returned as a fresh array and taken back when the consumer lets go
+        # of it (envs/_obspool.py) -- fresh-array semantics without the 5 MB copy per step
+        from ._obspool import ObsPool
+        self._obs_pool = None if (self._obs_zero_copy or self._obs_device) else ObsPool(self.E * per, oshape, cap=int(config.get('obs_pool', 16)))
         self.i = np.zeros(self.E, dtype=np.int64)       # per-env step index
         self.tick = 0
         self.rewards_sum = np.zeros(self.E)
@@ -153,7 +157,9 @@ class SSA_Tasker_VecEnv:
         if self._obs_device:
             aer_out, mirror = (self._aer.data_ptr() if aer else 0), 0
         else:
-            aer_out, mirror = (self._obs_ring_ptr[k] if aer else 0), (0 if aer else self._obs_ring_ptr[k])
+            kp = self._obs_pool.acquire() if self._obs_pool is not None else None
+            dst = self._obs_pool.ptrs[kp] if kp is not None else self._obs_ring_ptr[k]
+            aer_out, mirror = (dst if aer else 0), (0 if aer else dst)
         if self._inline:
             cur = self._stream
             e.launch_step(sin, sout, 0, aer_out=aer_out, obs_mirror=mirror, stats_out=self._stats_host.data_ptr(), stream=cur.cuda_stream,
@@ -189,7 +195,14 @@ class SSA_Tasker_VecEnv:
         else:
             rewards, dones = np.zeros(self.E), np.zeros(self.E, dtype=bool)
         self.rewards_sum += rewards
-        obs = self._obs(sout) if self._obs_device else (self._obs_ring_np[k] if self._obs_zero_copy else self._obs_ring_np[k].copy())
+        if self._obs_device:
+            obs = self._obs(sout)
+        elif self._obs_zero_copy:
+            obs = self._obs_ring_np[k]
+        elif kp is not None:
+            obs = self._obs_pool.hand_out(kp)       # fresh array, no copy
+        else:
+            obs = self._obs_ring_np[k].copy()       # (more than `obs_pool` observations alive at once)
         infos = [{} for _ in range(self.E)]
         if dones.any():   # auto-reset in place; the returned observation of a finished env is its new first one
             for d in np.where(dones)[0]:

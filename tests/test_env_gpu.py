@@ -526,8 +526,10 @@ def test_persistent_closed_loop_gives_up_cleanly_and_the_env_recovers(envs):
 
 def test_step_hands_out_observations_a_consumer_may_keep(envs):
     """the reference returns a fresh `.flatten()` per step (ssa_tasker_simple_2.py:360-362): an observation kept across later steps
-    (a replay buffer, GAE targets) must not change.  Default: copies.  config['obs_zero_copy']: views of the two-deep host-mapped ring
-    the kernel writes -- documented to last until step i + 2 -- for loops that consume the observation at once."""
+    (a replay buffer, GAE targets) must not change.  Default: a buffer nobody holds, written by the kernel, handed out as a fresh array
+    WITHOUT a copy and taken back when the consumer has dropped the array and every view of it (envs/_obspool.py); beyond `obs_pool`
+    observations alive at once: copies.  config['obs_zero_copy']: views of the two-deep host-mapped ring the kernel writes -- documented
+    to last until step i + 2 -- for loops that consume the observation at once."""
     cfg = dict(envs.env_config)
     cfg.update(rso_count=30, steps=40, reward_type='trinary', obs_returned='flatten', seed=2)
     env = envs.make(config=cfg)
@@ -537,6 +539,26 @@ def test_step_hands_out_observations_a_consumer_may_keep(envs):
         kept.append((o, o.copy(), env.i))
     for o, snap, i in kept:
         assert np.array_equal(o, snap) and np.array_equal(o, env.obs[i].reshape(-1))
+    pool = env._obs_pool
+    assert len(pool) == 5 and len(pool._free) == 0 and not kept[0][0].flags.owndata     # five observations out, five buffers, no copy
+    view = kept[1][0][12:24]                            # a consumer's slice keeps ITS buffer, and only that one
+    snap1 = kept[1][1]
+    del kept, o, snap
+    import gc
+    gc.collect()
+    assert len(pool._free) == 4
+    for k in range(5, 12):                              # the loop that consumes each observation at once: buffers go round, none is added
+        o, _, _, _ = env.step(k)
+        del o
+    assert len(pool) == 5 and np.array_equal(view, snap1[12:24])
+    del view
+    assert len(pool._free) == 5
+    small = envs.make(config=dict(cfg, obs_pool=2))     # a consumer that hoards: copies beyond the cap, still never overwritten
+    hoard = []
+    for k in range(6):
+        o, _, _, _ = small.step(k)
+        hoard.append((o, o.copy()))
+    assert len(small._obs_pool) == 2 and sum(o.flags.owndata for o, _ in hoard) == 4 and all(np.array_equal(o, c) for o, c in hoard)
     zc = envs.make(config=dict(cfg, obs_zero_copy=True))
     o1, _, _, _ = zc.step(0)
     s1 = o1.copy()
@@ -550,7 +572,9 @@ def test_step_hands_out_observations_a_consumer_may_keep(envs):
     for k in range(4):
         o, _, _, _ = ve.step([k, k + 1])
         kept.append((o, o.copy()))
-    assert all(np.array_equal(o, c) for o, c in kept)
+    assert all(np.array_equal(o, c) for o, c in kept) and len(ve._obs_pool) == 4
+    del kept, o
+    assert len(ve._obs_pool._free) == 4
 
 
 @pytest.mark.parametrize("hist,reward", [(2, 'trinary'), ('full', 'trinary'), (3, 'jones'), (2, 'shaped')])
