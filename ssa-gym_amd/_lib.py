@@ -37,6 +37,7 @@ class ssa_step_params(C.Structure):
         ("inline_time", C.c_int32 * 8), ("inline_action", C.c_int32 * 8),
         ("spos_tiles", c_dp), ("spos_tiles_prev", c_dp),
         ("fail_log", c_dp), ("fail_count", c_dp), ("fail_cap", C.c_int32), ("reserved1", C.c_int32),
+        ("obj_ids", c_dp),
     ]
 
 

@@ -100,7 +100,7 @@ struct alignas(16) Tiles {
     double Q[36];                      // @1152  process noise (read per covariance entry with a lane-dependent index)
     double Z[8];                       // @1440  six zeros: the "factor row" of the lanes that add nothing (sigma_0, truth, idle)
     int St[OBJ_PER_WAVE];              // @1504
-    int pad0[4];                       // @1520
+    int Oid[OBJ_PER_WAVE];             // @1520  the caller's index of each row's object (ssa_step_params.obj_ids; else unused)
     double X[OBJ_PER_WAVE * 6];        // @1536  x_in, then sigma_0', then x_out
     double pad1[8];                    // @1728
     double T[OBJ_PER_WAVE * 6];        // @1792  x_true_in, later x_true_out
@@ -246,7 +246,10 @@ SSA_DEV void store_tile(const Tiles& t, const ssa_step_params& p, int lane, int6
             }
             if (NT) __builtin_nontemporal_store(pair, reinterpret_cast<v2d*>(dst));
             else *reinterpret_cast<v2d*>(dst) = pair;
-            if (p.obs_mirror) *reinterpret_cast<v2d*>(p.obs_mirror + base * 12 - 64 + 2 * lane) = pair;   // (e.g. host-mapped memory)
+            if (p.obs_mirror) {   // (e.g. host-mapped memory; with obj_ids: row by row at the caller's index of the object)
+                if (p.obj_ids) *reinterpret_cast<v2d*>(p.obs_mirror + (int64_t)t.Oid[jj] * 12 + r) = pair;
+                else *reinterpret_cast<v2d*>(p.obs_mirror + base * 12 - 64 + 2 * lane) = pair;
+            }
         }
         if (!SSA_SKIP(16) && lane >= 56 && lane < 60) p.status[base - 56 + lane] = t.St[lane - 56];
         if (!SSA_SKIP(8) && lane < 16) {   // metrics [E][4][m]: four 32-byte runs per tile
@@ -272,7 +275,12 @@ SSA_DEV void store_tile(const Tiles& t, const ssa_step_params& p, int lane, int6
         const double* src = sO ? t.Obs : sP ? t.P + 128 : sT ? t.T : t.X;
         const bool skip = sO ? SSA_SKIP(2) : sP ? SSA_SKIP(1) : SSA_SKIP(4);
         if (!skip && i < lim) store16<NT>(dst + 2 * i, src + 2 * i);
-        if (sO && p.obs_mirror && i < lim) store16<false>(p.obs_mirror + base * 12 + 2 * i, src + 2 * i);
+        if (sO && p.obs_mirror && i < lim) {
+            if (p.obj_ids) {
+                const int jj = (i * 43) >> 8;     // i / 6: the object (rows beyond cnt are masked by `lim`)
+                store16<false>(p.obs_mirror + (int64_t)t.Oid[jj] * 12 + (2 * i - 12 * jj), src + 2 * i);
+            } else store16<false>(p.obs_mirror + base * 12 + 2 * i, src + 2 * i);
+        }
     }
     if (!SSA_SKIP(16) && lane >= 12 && lane < 16) {
         const int i = lane - 12;
@@ -853,14 +861,17 @@ SSA_DEV unsigned long long spos_key(double v)
 }
 SSA_DEV double spos_of_key(unsigned long long k) { return __longlong_as_double((long long)k); }
 // first maximum of the tile's `cnt` objects (lane-local: any lane may call it; reads t.Met)
-SSA_DEV void spos_tile_best(const Tiles& t, int cnt, int64_t j0, unsigned long long& key, unsigned long long& idx)
+// (ids: the rows' indices as the CALLER numbers them -- ssa_step_params.obj_ids, a layout that stores the objects in another order: the
+// first maximum is then the one with the lowest such index, whatever row it sits in)
+SSA_DEV void spos_tile_best(const Tiles& t, int cnt, int64_t j0, unsigned long long& key, unsigned long long& idx, bool ids = false)
 {
     key = spos_key(t.Met[2]);
-    idx = (unsigned long long)j0;
+    idx = ids ? (unsigned long long)t.Oid[0] : (unsigned long long)j0;
 #pragma unroll
     for (int g = 1; g < OBJ_PER_WAVE; ++g) {
         const unsigned long long k = spos_key(t.Met[g * 4 + 2]);
-        if (g < cnt && k > key) { key = k; idx = (unsigned long long)(j0 + g); }
+        const unsigned long long ig = ids ? (unsigned long long)t.Oid[g] : (unsigned long long)(j0 + g);
+        if (g < cnt && (k > key || (ids && k == key && ig < idx))) { key = k; idx = ig; }
     }
 }
 // 64-bit wave folds by DPP rotations + readlanes (see the closed loop, which introduced them)
@@ -902,7 +913,7 @@ SSA_DEV void fold_spos_tiles(const unsigned long long* __restrict__ slots, int t
             const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(slots + 2 * (int64_t)tb);
             k = v.x; i = v.y;
         }
-        if (!any || k > key) { key = k; idx = i; any = true; }      // (a lane's tiles come in increasing order: ties keep the earlier one)
+        if (!any || k > key || (k == key && i < idx)) { key = k; idx = i; any = true; }      // (ties: the lower index -- the earlier tile, unless a layout renumbers)
     }
     const unsigned long long top = wave_fold_u64(any ? key : 0ull, OpMax());
     const unsigned long long who = wave_fold_u64((any && key == top) ? idx : ~0ull, OpMin());
@@ -1098,7 +1109,18 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     // wavefront is the longest-living one of the launch, so its inputs (this step's GCRS->ITRS matrix, the measurement noise)
     // leave HBM now and wait in LDS, instead of costing two memory round trips when the update starts
     const bool interval_ok = (C.update_interval <= 1) || (tix % C.update_interval == 0);
-    bool my_update = !ACT::late && valid && act >= 0 && (int64_t)act == j && interval_ok;
+    // ssa_step_params.obj_ids (one env, the per-step kernels): the objects are stored in another order than the caller numbers them; the
+    // action, the failure records, the arg-max of sigma_pos and the host-facing observation rows speak the CALLER's indices
+    int64_t jid = j;
+    if (TILE != 2 && !ACT::late && p.obj_ids) {
+        // (the tile's four indices by ONE wave-uniform 16-byte load -- scalar memory: it does not queue behind the tile's vector loads, which a
+        // per-lane load would, and the update's input prefetch below hangs on `my_update`; the table is padded to whole tiles)
+        const int4 ids = *reinterpret_cast<const int4*>(p.obj_ids + base);
+        const int mine = (g == 0) ? ids.x : (g == 1) ? ids.y : (g == 2) ? ids.z : ids.w;
+        jid = valid ? (int64_t)mine : 0;
+        if (l == 0) t.Oid[g] = mine;
+    }
+    bool my_update = !ACT::late && valid && act >= 0 && (int64_t)act == jid && interval_ok;
     // (ActLate: every row prefetches for its own object)
     const bool may_update = ACT::late ? (valid && interval_ok) : my_update;
     // ... and it issues ahead of its SIMD's other wavefronts from here on: at equal priority its predict runs at a fifth of the
@@ -1565,7 +1587,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
             if ((int)at < p.fail_cap) {
                 double* rec = p.fail_log + (int64_t)at * SSA_FAIL_STRIDE;
                 rec[SSA_FAIL_ENV] = (double)e;
-                rec[SSA_FAIL_OBJ] = (double)(obj - (int64_t)e * p.n_obj);
+                rec[SSA_FAIL_OBJ] = (TILE != 2 && !ACT::late && p.obj_ids) ? (double)t.Oid[g] : (double)(obj - (int64_t)e * p.n_obj);
                 rec[SSA_FAIL_STATUS] = (double)st_new;
                 rec[SSA_FAIL_TIME] = (double)((ACT::late ? p.env_time[0] : env_time_of<INL>(p, e)) + p.time_offset);
                 rec[SSA_FAIL_ERR + 0] = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
@@ -1589,7 +1611,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     // observation mode and the multi-GPU all-gather payload -- from the tiles, so that no second pass over x / P (the
     // former post kernel: 6.7 MB re-read per 20 000 objects plus a launch) is needed
     if (p.aer_out && p.stat_shards) {
-        if (l < 4 && valid) aer_obs_tile<INL>(t, p, C, g, l, e, obj);
+        if (l < 4 && valid) aer_obs_tile<INL>(t, p, C, g, l, e, (TILE != 2 && !ACT::late && p.obj_ids) ? (int64_t)t.Oid[g] : obj);
     }
     wave_lds_sync();
     SSA_TR(7);
@@ -1597,7 +1619,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
 #if !(defined(SSA_ABLATE) && (SSA_ABLATE & 32))
         if (p.spos_tiles && p.stat_shards && lane == 0) {   // the tile's first maximum of sigma_pos (np.argmax for the 'shaped' reward): one slot, no atomics
             unsigned long long key, idx;
-            spos_tile_best(t, cnt, obj - (int64_t)e * p.n_obj, key, idx);
+            spos_tile_best(t, cnt, obj - (int64_t)e * p.n_obj, key, idx, TILE != 2 && p.obj_ids != nullptr);
             unsigned long long* slot = (unsigned long long*)p.spos_tiles + 2 * (int64_t)tile;
             __hip_atomic_store(slot, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (agent scope: SSA_LAUNCH_FOLD_INSIDE reads them in this launch)
             __hip_atomic_store(slot + 1, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -3292,6 +3314,7 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
         (!p->stat_shards || !p->stats || (p->launch_mask & SSA_LAUNCH_DEFER_FOLD))) return SSA_E_INVALID;
     if (p->spos_tiles && !p->stat_shards) return SSA_E_INVALID;
     if (p->fail_log && (!p->fail_count || p->fail_cap <= 0)) return SSA_E_INVALID;
+    if (p->obj_ids && p->n_env != 1) return SSA_E_UNSUPPORTED;
     if ((p->spos_tiles || p->spos_tiles_prev) && p->n_env > 1 && (p->n_obj % OBJ_PER_WAVE) != 0) return SSA_E_UNSUPPORTED;   // whole tiles per env
     if (c->obs_type != SSA_OBS_AER && c->obs_type != SSA_OBS_XYZ) return SSA_E_INVALID;
     if (p->aer_cols != 0 && p->aer_cols != 1 && p->aer_cols != 4) return SSA_E_INVALID;
@@ -3397,6 +3420,7 @@ int ssa_env_rollout_f64(const ssa_consts* c, const ssa_step_params* p, const ssa
     rk.k.p.aer_out = nullptr;
     rk.k.p.spos_tiles = nullptr;
     rk.k.p.spos_tiles_prev = nullptr;
+    if (p->obj_ids) return SSA_E_UNSUPPORTED;       // (a layout table belongs to the per-step launches: the caller restores its own order first)
     rk.r = *r;
     const int64_t ntiles = (total + OBJ_PER_WAVE - 1) / OBJ_PER_WAVE;
     const int64_t slots = (int64_t)device_cu_count() * 4 * SSA_STEP_WAVES;
@@ -3445,7 +3469,7 @@ int ssa_env_closed_loop_f64(const ssa_consts* c, const ssa_step_params* p, const
     if (c->obs_type != SSA_OBS_AER && c->obs_type != SSA_OBS_XYZ) return SSA_E_INVALID;
     if (c->propagator != SSA_PROP_FG && c->propagator != SSA_PROP_ELEMENTS && c->propagator != SSA_PROP_J2_RK4 && c->propagator != SSA_PROP_HYBRID) return SSA_E_INVALID;
     if (c->propagator == SSA_PROP_J2_RK4 && (c->rk4_substeps < 1 || c->rk4_substeps > 4096)) return SSA_E_INVALID;
-    if (p->n_env != 1) return SSA_E_UNSUPPORTED;
+    if (p->n_env != 1 || p->obj_ids) return SSA_E_UNSUPPORTED;     // (a layout table belongs to the per-step launches)
     const int64_t ntiles = (p->n_obj + OBJ_PER_WAVE - 1) / OBJ_PER_WAVE;
     const int64_t cap = closed_loop_capacity(c->propagator);
     const ClLayout L = cl_layout((int)ntiles);

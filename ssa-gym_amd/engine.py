@@ -24,6 +24,11 @@ from . import _lib, device
 f64 = torch.float64
 
 
+class _Snapshot(tuple):
+    """a snapshot's tensors + the storage layout (`order`) they were taken under"""
+    order = None
+
+
 class HotPathEngine:
     def __init__(self, consts, n_obj, n_env, trans, z_noise, history, device_name="cuda",
                  zn_stride_env=None, zn_stride_time=None, zn_stride_obj=3):
@@ -96,6 +101,7 @@ class HotPathEngine:
         self.supports_argmax = self.E == 1 or self.m % 4 == 0
         self._spos_sets = None
         self._actions_ptr = self.actions.data_ptr()
+        self._order = None             # storage layout (set_layout): position -> the caller's index, or None
         self._pcache = {}
         self._cref = C.byref(self.consts)
         self._pref = C.byref(self._p)
@@ -105,6 +111,50 @@ class HotPathEngine:
         self._bx_t, self._bx, self._bP = self.x_true.data_ptr(), self.x_filter.data_ptr(), self.P_filter.data_ptr()
         self._bo, self._bm, self._bs, self._bu = (self.obs.data_ptr(), self.metrics.data_ptr(), self.stats.data_ptr(),
                                                   self.upd.data_ptr())
+
+    # ------------------------------------------------------------------ layout (ssa_step_params.obj_ids)
+    def set_layout(self, order):
+        """Store the objects in another order than the caller numbers them (one env): position i of every state tensor holds the object the
+        caller calls order[i]; None: the caller's order.  Objects of one orbit regime then share wavefronts (catalogue.regime_order) --
+        late in an episode the diverged filters are the LEO objects, and packed they cost a launch 10 % less.
+        The per-step launches speak the caller's indices wherever an index enters or leaves (actions, failure records, arg-max of sigma_pos,
+        the host-facing observation rows: include/ssa_hip.h); the state tensors of this engine (x_true, x_filter, P_filter, obs, metrics,
+        status) are in STORAGE order while a layout is set -- `to_caller_order()` puts them back (the rollout and closed-loop launches do that
+        themselves).  Call before load_state(); the state present is not moved."""
+        self._order = None
+        self._p.obj_ids = 0
+        self._pcache.clear()
+        if order is None:
+            return
+        if self.E != 1:
+            raise _lib.SsaHipError("a storage layout needs one env")
+        order = np.asarray(order, dtype=np.int64).reshape(-1)
+        if order.shape[0] != self.m or not np.array_equal(np.sort(order), np.arange(self.m)):
+            raise _lib.SsaHipError("set_layout: `order` must be a permutation of 0 .. n_obj - 1")
+        ids = np.full(4 * self.ntiles, -1, dtype=np.int32)          # (whole tiles: the kernel reads a tile's four words at once)
+        ids[:self.m] = order
+        self._order = order
+        self._obj_ids = torch.as_tensor(ids).to(self.dev)
+        self._order_idx = torch.as_tensor(order).to(self.dev)                     # storage position -> caller's index
+        self._slot_of = torch.as_tensor(np.argsort(order)).to(self.dev)           # caller's index -> storage position
+        self._p.obj_ids = self._obj_ids.data_ptr()
+
+    def _reorder(self, idx, slots):
+        """every per-object tensor of the given history slots gathered through `idx` (new[i] = old[idx[i]]), and the status words"""
+        for sl in slots:
+            for tns in (self.x_true, self.x_filter, self.P_filter, self.obs):
+                tns[sl].copy_(tns[sl].index_select(0, idx))
+            self.metrics[sl].copy_(self.metrics[sl].index_select(2, idx))
+        self.status.copy_(self.status.index_select(0, idx))
+
+    def to_caller_order(self):
+        """put the state tensors back into the caller's order and drop the layout (asynchronous, in the current stream): for everything that
+        reads them as the caller numbers them -- device-side agents and policies, the rollout and closed-loop launches, inspection"""
+        if self._order is None:
+            return
+        self.flush_stats()
+        self._reorder(self._slot_of, range(self.H))
+        self.set_layout(None)
 
     # ------------------------------------------------------------------ state in
     def load_state(self, slot, x_true, x_filter, P_filter):
@@ -121,6 +171,8 @@ class HotPathEngine:
             device.observe(self.x_true[slot, sl], self.x_filter[slot, sl], self.P_filter[slot, sl],
                            obs=self.obs[slot, sl], metrics=self.metrics[slot, e])
         device.reward_stats(self.metrics[slot], self.status, self.m, self.E, out=self.stats[slot])
+        if self._order is not None:      # (statistics first, in the caller's order -- np.argmax's first maximum -- then into storage order)
+            self._reorder(self._order_idx, [slot])
 
     def load_env_state(self, slot, e, x_true, x_filter, P_filter):
         """reset() of ONE environment of a vectorised batch: overwrite its slice of `slot`."""
@@ -134,13 +186,19 @@ class HotPathEngine:
         device.reward_stats(self.metrics[slot, e:e + 1], self.status[sl], self.m, 1, out=self.stats[slot, e:e + 1])
 
     def snapshot(self, slot):
-        """device-side copy of a history slot (initial state of an episode)."""
-        return (self.x_true[slot].clone(), self.x_filter[slot].clone(), self.P_filter[slot].clone(),
-                self.obs[slot].clone(), self.metrics[slot].clone(), self.stats[slot].clone())
+        """device-side copy of a history slot (initial state of an episode); remembers the storage layout it was taken under."""
+        snap = _Snapshot((self.x_true[slot].clone(), self.x_filter[slot].clone(), self.P_filter[slot].clone(),
+                          self.obs[slot].clone(), self.metrics[slot].clone(), self.stats[slot].clone()))
+        snap.order = None if self._order is None else self._order.copy()
+        return snap
 
     def restore(self, slot, snap):
-        """reset(): device-to-device restore of an episode's initial state, asynchronous."""
-        xt, x, P, obs, met, st = snap
+        """reset(): device-to-device restore of an episode's initial state, asynchronous (and of the layout the snapshot was taken under)."""
+        order = getattr(snap, "order", None)
+        if (order is None) != (self._order is None) or (order is not None and not np.array_equal(order, self._order)):
+            self.flush_stats()
+            self.set_layout(order)
+        xt, x, P, obs, met, st = snap[:6]
         self.x_true[slot].copy_(xt)
         self.x_filter[slot].copy_(x)
         self.P_filter[slot].copy_(P)
@@ -153,10 +211,13 @@ class HotPathEngine:
     def snapshot_state(self, slot):
         """a history slot AND the per-object status words: what a launch that may have to be undone (the persistent closed loop
         when it gives up) restores"""
-        return self.snapshot(slot) + (self.status.clone(), self.fail_count.clone())
+        base = self.snapshot(slot)
+        snap = _Snapshot(tuple(base) + (self.status.clone(), self.fail_count.clone()))
+        snap.order = base.order
+        return snap
 
     def restore_state(self, slot, snap):
-        self.restore(slot, snap[:6])
+        self.restore(slot, snap)
         self.status.copy_(snap[6])
         self.fail_count.copy_(snap[7])
 
@@ -260,6 +321,7 @@ class HotPathEngine:
                 and actions.dim() == 2 and actions.shape[1] == self.E and actions.shape[0] >= 1):
             raise _lib.SsaHipError("rollout: actions must be a contiguous CUDA int32 tensor [K][n_env]")
         s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        self.to_caller_order()           # (a storage layout belongs to the per-step launches)
         self.flush_stats(s)
         K = int(actions.shape[0])
         if getattr(self, "_roll_shards", None) is None or self._roll_shards.shape[0] < K:
@@ -298,6 +360,7 @@ class HotPathEngine:
         the give-up path)."""
         if self.E != 1:
             return False
+        self.to_caller_order()           # (a storage layout belongs to the per-step launches)
         K = int(actions.numel()) - 1
         if K < 1:
             raise _lib.SsaHipError("closed loop: actions must hold K + 1 >= 2 words")

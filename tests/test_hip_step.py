@@ -1378,3 +1378,61 @@ def test_an_objects_arithmetic_does_not_depend_on_its_position(hip, prop):
     assert np.array_equal(st_a[:, k], st_b[:, k], equal_nan=True)
     if prop == "hybrid":
         assert (ident[3] != 0).sum() > 0             # the workload does reach the failure path
+
+
+@pytest.mark.parametrize("prop,m", [("hybrid", 2016), ("hybrid", 2014), ("fg", 2016)])
+def test_storage_layout_speaks_the_callers_indices(hip, prop, m):
+    """ssa_step_params.obj_ids / HotPathEngine.set_layout: the objects stored in another order than the caller numbers them (a random
+    permutation here; the env uses catalogue.regime_order).  Fed the SAME actions, the engine with a layout must hand the caller -- step by
+    step, bit for bit -- the same host-facing observation rows (obs_mirror: at the caller's row), the same 'aer' block, statistics
+    including np.argmax(sigma_pos) (ties between failed filters: the lowest CALLER index), update records and failure records, and after
+    to_caller_order() the same state tensors.  A third of the filters is inflated so that the conic tier, the ladder and the failure path
+    run; 2 014 objects: a ragged last tile."""
+    torch = hip.torch
+    xt, x, P, g = make_batch(m, seed=33)
+    rs = np.random.RandomState(9)
+    P[rs.uniform(size=m) < 0.33] *= 3e4
+    zn = rs.normal(size=(1, 480, m, 3)) * np.array([4.8e-6, 4.8e-6, 1e3])
+    order = rs.permutation(m)
+    consts = hip.host.make_consts(g["Q"], g["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, g["obs_lla"], propagator=prop)
+    n_steps = 70
+    acts = (np.arange(n_steps) * 53 + 7) % m
+
+    def run(layout):
+        eng = hip.engine.HotPathEngine(consts, m, 1, c2t(), zn, history=2)
+        eng.set_layout(layout)
+        eng.load_state(0, xt, x, P)
+        mirror = torch.zeros(m * 12, dtype=torch.float64).pin_memory()
+        aer = torch.zeros(m * 4, dtype=torch.float64).pin_memory()
+        st = torch.zeros(8, dtype=torch.float64).pin_memory()
+        upd = torch.zeros(hip.lib.UPD_STRIDE, dtype=torch.float64).pin_memory()
+        out = []
+        init_stats = eng.stats[0].cpu().numpy().copy()
+        for k, a in enumerate(acts):
+            t = k + 1
+            eng.launch_step((t - 1) % 2, t % 2, t, action=int(a), obs_mirror=mirror.data_ptr() if k % 2 == 0 else 0,
+                            aer_out=aer.data_ptr() if k % 2 == 1 else 0, stats_out=st.data_ptr(), upd_out=upd.data_ptr(),
+                            fast_stats=True, fold_inside=True, argmax_spos=True)
+            torch.cuda.synchronize()
+            out.append((mirror.numpy().copy(), aer.numpy().copy(), st.numpy().copy(), upd.numpy().copy()))
+        nf = int(eng.fail_count.item())
+        fails = sorted((int(r[hip.lib.FAIL_OBJ]), int(r[hip.lib.FAIL_STATUS]), int(r[hip.lib.FAIL_TIME]), tuple(r[hip.lib.FAIL_ERR:hip.lib.FAIL_ERR + 4]))
+                       for r in eng.fail_log[:nf])
+        assert (eng._order is None) == (layout is None)
+        eng.to_caller_order()
+        assert eng._order is None
+        s = n_steps % 2
+        state = (eng.x_true[s].cpu().numpy(), eng.x_filter[s].cpu().numpy(), eng.P_filter[s].cpu().numpy(), eng.obs[s].cpu().numpy(),
+                 eng.metrics[s].cpu().numpy(), eng.status.cpu().numpy())
+        return init_stats, out, fails, state
+    a = run(None)
+    b = run(order)
+    assert np.array_equal(a[0], b[0], equal_nan=True)                     # the reset's statistics (first maximum in the caller's order)
+    for k, (ua, ub) in enumerate(zip(a[1], b[1])):
+        for name, va, vb in zip(("obs rows", "aer block", "statistics", "update record"), ua, ub):
+            assert np.array_equal(va, vb, equal_nan=True), (k, name)
+    assert a[2] == b[2] and (prop != "hybrid" or len(a[2]) > 0)
+    for name, va, vb in zip(("x_true", "x_filter", "P_filter", "obs", "metrics", "status"), a[3], b[3]):
+        assert np.array_equal(va, vb, equal_nan=True), name
+    if prop == "hybrid":     # (the failure path did run)
+        assert int(a[1][-1][2][hip.lib.STAT_N_FAILED]) >= 2
