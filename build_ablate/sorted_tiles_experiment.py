@@ -73,6 +73,14 @@ if STATIC:                                  # episode first (the bound of any st
     eng.load_state(0, pb["x_true"][order], pb["x"][order], np.broadcast_to(pb["P0"], (m, 6, 6)))
     local = parallel.HipLocalStepper(eng, consts, fast_stats=True, defer_fold=True)
     local.load_schedule(np.arange(479) % m)
+if os.environ.get("SORT") == "3":           # the product's form: HotPathEngine.set_layout(catalogue.regime_order(x_true)) -- the caller's arrays, actions and
+    from ssa_gym_amd.catalogue import regime_order     # indices unchanged, the kernels translate at the boundaries (ssa_step_params.obj_ids)
+    SORT = False
+    eng = engine.HotPathEngine(consts, m, 1, pb["trans"], z, history=2)
+    eng.set_layout(regime_order(pb["x_true"]))
+    eng.load_state(0, pb["x_true"], pb["x"], np.broadcast_to(pb["P0"], (m, 6, 6)))
+    local = parallel.HipLocalStepper(eng, consts, fast_stats=True, defer_fold=True)
+    local.load_schedule(np.arange(479) % m)
 rows = []
 for k in range(479):
     if SORT and k >= 180 and k % 30 == 0:

@@ -473,18 +473,33 @@ SSA_DEV void stumpff_tiny(double z, double& c2, double& c3)
     c2 = fma(-fma(-fma(-1.0 / 40320.0, z, 1.0 / 720.0), z, 1.0 / 24.0), z, 0.5);
     c3 = fma(-fma(-fma(-1.0 / 362880.0, z, 1.0 / 5040.0), z, 1.0 / 120.0), z, 1.0 / 6.0);
 }
+// TINY: every lane of the wavefront is in the short series' range by the first-order estimate below (the instance without the long
+// series).  Otherwise each lane still gets the series ITS OWN z asks for, so that a lane's rounding does not depend on who shares its
+// wavefront: until round 4 the whole wavefront took the long series as soon as one lane needed it, the two forms differ by an ulp now and
+// then, and an object's result depended -- in the last bit -- on its neighbours (found when a storage layout, which only changes who shares
+// a wavefront, ended a 20 000-object episode with 776 failed filters instead of 775).  The rule is the series' own range, |z| < 2e-3,
+// taken from the z at hand (nothing to carry along: a flag cost the rollout kernel a spill); a lane whose estimate is below 1.5e-3 stays
+// below 2e-3 throughout -- what the TINY instance relies on for every lane -- so it sees the short series in either instance.
 template <bool TINY>
 SSA_DEV void stumpff_sel(double z, double& c2, double& c3)
 {
     if (TINY) stumpff_tiny(z, c2, c3);
-    else stumpff_small(z, c2, c3);
+    else {
+        stumpff_small(z, c2, c3);
+        const bool tiny_lane = fabs(z) < 2e-3;
+        if (__any(tiny_lane)) {
+            double a, b;
+            stumpff_tiny(z, a, b);
+            if (tiny_lane) { c2 = a; c3 = b; }
+        }
+    }
 }
 template <bool TINY>
 SSA_DEV bool kepler_uv_fast_t(const double* x, double tof, double* out, bool& handled);
 SSA_DEV bool kepler_uv_fast(const double* x, double tof, double* out, bool& handled)
 {
-    // whole-wave choice of the series length from the first-order estimate z ~ alpha (sqrt(mu) tof / r0)^2 (bound 1.5e-3: the
-    // converged z stays below the 2e-3 the short series is good for; a NaN lane takes either)
+    // the first-order estimate z ~ alpha (sqrt(mu) tof / r0)^2 (bound 1.5e-3: the converged z stays below the 2e-3 the short series is good
+    // for; a NaN lane takes either); the wavefront skips the long series when nobody needs it
     const double rr = dot3(x, x), vv = dot3(x + 3, x + 3);
     const double ir = rsqrt_nr(rr);
     const double z0 = (2.0 * ir - vv * (1.0 / MU)) * (MU * tof * tof) * (ir * ir);
