@@ -147,6 +147,11 @@ class HotPathEngine:
             self.metrics[sl].copy_(self.metrics[sl].index_select(2, idx))
         self.status.copy_(self.status.index_select(0, idx))
 
+    def caller_rows(self, tensor):
+        """a per-object tensor of ONE history slot ([n_obj, ...]) as the caller numbers the objects: a gather while a layout is set, the
+        tensor itself otherwise (for the occasional reader that should not cost the layout: the observation a reset returns)"""
+        return tensor if self._order is None else tensor.index_select(0, self._slot_of)
+
     def to_caller_order(self):
         """put the state tensors back into the caller's order and drop the layout (asynchronous, in the current stream): for everything that
         reads them as the caller numbers them -- device-side agents and policies, the rollout and closed-loop launches, inspection"""

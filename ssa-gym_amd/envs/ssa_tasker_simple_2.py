@@ -42,6 +42,7 @@ class _History:
             i += env.n
         if not 0 <= i < env.n:
             raise IndexError(i)
+        env._caller_order()       # (the history arrays are read as the env numbers the objects: a storage layout ends here)
         H = env._engine.H
         if i > env.i or i <= env.i - H:
             if i > env.i:   # not simulated yet: the reference arrays hold zeros there after reset()
@@ -239,9 +240,10 @@ class SSA_Tasker_Env(Env):
         self._consts, _ = kernel_consts(config, self.Q, self.R, self.dt, self.obs_limit, self.obs_lla)
         self._engine = None
         self._device_rng = bool(config.get('device_rng', False))
-        self._layout = config.get('layout')          # None (the reference's object order) | 'regime' (see reset())
-        if self._layout not in (None, 'regime'):
-            raise ValueError("config['layout'] must be None or 'regime', not %r" % (self._layout,))
+        # config['storage_layout'] = 'regime' (default) | None: how the engine STORES the objects (reset()); invisible but for speed
+        self._storage_layout = config.get('storage_layout', 'regime')
+        if self._storage_layout not in (None, 'regime'):
+            raise ValueError("config['storage_layout'] must be None or 'regime', not %r" % (self._storage_layout,))
         self._obs_buffers = config.get('obs_buffers', 2)
         # step() hands out a FRESH array per call for the 'flatten' and (m, 12) observations, as the reference does (:360-366: `.flatten()` /
         # a row of the history that no later step overwrites) -- a consumer may keep it as long as it likes (replay buffers, sample
@@ -323,17 +325,6 @@ class SSA_Tasker_Env(Env):
             for j in range(m):   # draw order of :206-209: (row, 6 normals) per object ...
                 x_true0[j] = self.orbits[self.np_random.randint(low=0, high=N), :]
                 self.x_noise[j] = self.np_random.normal(size=6) * self.x_sigma
-        # config['layout'] = 'regime' (opt-in, round 4): the SAME draws, stored in another order -- ascending semi-major axis, dealt tile by tile
-        # over the XCDs (catalogue.regime_order) -- so that objects of one regime share wavefronts: late in an episode the diverged filters
-        # are the LEO objects, and an env of 20 000 objects steps 13 % faster with them packed.  It RELABELS the
-        # objects: object j of this env is draw number object_order[j] of the reference's order (actions, observations, histories and
-        # failure ids all speak the env's own labels); results per object are bit-identical.  Default: the reference's order.
-        self.object_order = None
-        if self._layout == 'regime':
-            from ..catalogue import regime_order
-            self.object_order = regime_order(x_true0)
-            x_true0 = np.ascontiguousarray(x_true0[self.object_order])
-            self.x_noise[:] = self.x_noise[self.object_order]
         x_filter0 = x_true0 + self.x_noise
         # ... then n*m*3 normals (:219-221); RandomState.normal keeps its Box-Muller cache across
         # calls, so one bulk draw consumes the stream exactly like the reference's n*m size-3 draws
@@ -344,13 +335,24 @@ class SSA_Tasker_Env(Env):
             self.z_noise = None
         else:
             self.z_noise = self.np_random.normal(size=(n, m, 3)) * self.z_sigma
-            if self.object_order is not None:
-                self.z_noise = np.ascontiguousarray(self.z_noise[:, self.object_order])
             self._z_noise_dev = torch.as_tensor(self.z_noise, dtype=torch.float64).to("cuda")
         if self._engine is None:
             self._build_engine()
         else:
             self._engine.z_noise.copy_(self._z_noise_dev.reshape(self._engine.z_noise.shape))
+        # STORAGE LAYOUT (round 4): the engine keeps objects of one orbit regime in the same wavefronts -- ascending semi-major axis, dealt tile
+        # by tile over the XCDs (catalogue.regime_order) -- because late in an episode the diverged filters are the LEO objects, and packed
+        # they cost a launch 15 % less.  Nothing of it shows: the step kernel speaks the env's own indices wherever an
+        # index enters or leaves it (actions, failure records, arg-max of sigma_pos, the observation rows it writes for the host), an
+        # object's arithmetic does not depend on its position (bit-identical episodes, build_ablate/layout_episode_ab.py), and whatever reads
+        # the device state as the env numbers it -- the history arrays, the device-side agents and policies, rollout / closed loop -- puts
+        # the state back first (_caller_order(): the layout is then off until the next reset()).
+        lay = self._storage_layout == 'regime' and m >= 64 and not self._obs_device
+        if lay:
+            from ..catalogue import regime_order
+            self._engine.set_layout(regime_order(x_true0))
+        else:
+            self._engine.set_layout(None)
         self._engine.load_state(0, x_true0, x_filter0, np.broadcast_to(self.P_0, (m, 6, 6)))
         # tracking variables (:222-231)
         self.actions[:], self.obs_taken[:], self.failed_filters_id, self.visibility = -1, False, [], []
@@ -381,14 +383,20 @@ class SSA_Tasker_Env(Env):
         self._stats = e.stats[slot, 0].cpu().numpy()     # synchronises the stream
         self._argmax_sigma = int(self._stats[_lib.STAT_ARGMAX_SPOS])
 
+    def _caller_order(self):
+        """the device state back in the env's own object order (drops the engine's storage layout until the next reset(); a no-op without)"""
+        if self._engine is not None:
+            self._engine.to_caller_order()
+
     def _obs_out(self, reset=False):
-        """the observation of the current step through the slow path (reset(), rollout(), run_agent()): a device-to-host copy"""
+        """the observation of the current step through the slow path (reset(), rollout(), run_agent()): a device-to-host copy (gathered into
+        the env's object order while a storage layout is set: a reset does not cost the layout)"""
         e, slot = self._engine, self.i % self._engine.H
         if self.obs_returned == 'flatten':
-            return e.obs[slot].cpu().numpy().reshape(-1)
+            return e.caller_rows(e.obs[slot]).cpu().numpy().reshape(-1)
         elif self.obs_returned == 'aer':
             return self.aer_obs(self.observation)
-        return e.obs[slot].cpu().numpy()
+        return e.caller_rows(e.obs[slot]).cpu().numpy()
 
     def step(self, a):
         step_s = time.time()
@@ -499,6 +507,7 @@ class SSA_Tasker_Env(Env):
         chip across the steps, results bit-identical to step()).  Stops at the first `done`.  Returns
         (observation after the last executed step, rewards[k], dones[k], info).  Every reward type ('shaped': the arg-max of
         sigma_pos of every step comes from the rollout's arg-max slots, ssa_rollout_params.spos_tiles)."""
+        self._caller_order()
         import torch
         shaped = self.reward_type == 'shaped'     # (np.argmax(sigma_pos) of every step from the arg-max slots of the rollout)
         actions = np.asarray(actions, dtype=np.int64).ravel()
@@ -562,6 +571,7 @@ class SSA_Tasker_Env(Env):
         Every reward type.  If the persistent launch gives up (a wavefront waited longer than config['closed_loop_wait_ticks'] for a
         decision: something else holds the GPU's wavefront slots) the env restores the state the chunk started from, takes the
         per-step launches for this and every later call, and warns once."""
+        self._caller_order()          # (the agents' kernels and the persistent launch read the state as the env numbers it)
         import torch
         name = agent if isinstance(agent, str) else getattr(agent, "__name__", None)
         if name not in self.AGENT_KINDS:
@@ -796,6 +806,7 @@ class SSA_Tasker_Env(Env):
         greedy ones (those: run_agent, one persistent launch).  Every reward type; a data-dependent `done` ('jones', 'shaped') is
         honoured at the bookkeeping -- the steps launched behind it are discarded (chunks of history - 1 steps, as run_agent).
         Returns (actions[k], rewards[k], dones[k])."""
+        self._caller_order()          # (the policy's views are the env's own object order)
         import torch
         shaped = self.reward_type == 'shaped'
         e = self._engine
@@ -950,6 +961,7 @@ class SSA_Tasker_Env(Env):
     def anees(self):
         """:436-446 -- average normalised estimation error squared over the episode so far: NEES on the device for every
         resident (step, object) of the history (the reference loops n * m numpy inversions); fills self.nees (n, m)."""
+        self._caller_order()
         from .. import device
         s = time.time()
         e = self._engine
@@ -991,6 +1003,7 @@ class SSA_Tasker_Env(Env):
         env with config['history'] = 'full' for that -- with a short ring (history = 2, what 'auto' picks for very large envs) the NEES
         window is the last `history` steps only, and 'nees_steps' in the result says how many it was.
         Returns {'Test 2: NIS chi2': pct, 'Test 4: NEES chi2': pct, counts...}."""
+        self._caller_order()
         import torch
         from .. import device
         e = self._engine
@@ -1029,6 +1042,7 @@ class SSA_Tasker_Env(Env):
     # ------------------------------------------------------------------ visibility (:410-434)
     def _mask(self):
         from .. import device
+        self._caller_order()
         e = self._engine
         M = e.trans[self.i % e.n_time].reshape(3, 3)
         return device.visible_mask(e.x_true[self.i % e.H], M, self._consts).cpu().numpy().astype(bool)
@@ -1054,6 +1068,7 @@ class SSA_Tasker_Env(Env):
     def agent_scores(self):
         """device tensors (scores[4, m], mask[m]) for the heuristic agents (ssa_gym_amd.agents)."""
         from .. import device
+        self._caller_order()
         e = self._engine
         cur, prev = self.i % e.H, (self.i - 1) % e.H
         M = e.trans[self.i % e.n_time].reshape(3, 3)
@@ -1066,7 +1081,7 @@ class SSA_Tasker_Env(Env):
         e = self._engine
         slot = self.i % e.H
         M = e.trans[self.i % e.n_time].reshape(3, 3)
-        out = device.aer_obs(e.x_filter[slot], e.P_filter[slot], M, self._consts).cpu().numpy().reshape(-1)
+        out = e.caller_rows(device.aer_obs(e.x_filter[slot], e.P_filter[slot], M, self._consts).view(self.m, 4)).cpu().numpy().reshape(-1)
         obs[:] = out
         return obs
 

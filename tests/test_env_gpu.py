@@ -912,28 +912,62 @@ print("ok")
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.returncode, out.stderr[-1500:])
 
 
-def test_regime_layout_relabels_the_objects_and_changes_nothing_else(envs):
-    """config['layout'] = 'regime' (opt-in): the same draws stored by regime (catalogue.regime_order) -- object j of that env is draw
-    object_order[j] of the default env.  Fed the relabelled actions it produces, object by object, the same bits: states, covariances,
-    observations, rewards, update records, failure ids."""
+@pytest.mark.parametrize("mode,reward", [('flatten', 'trinary'), ('aer', 'shaped'), ('default', 'jones')])
+def test_storage_layout_is_invisible_through_the_gym_api(envs, mode, reward):
+    """config['storage_layout'] = 'regime' (the default): the engine stores objects of one orbit regime in the same wavefronts; the env's
+    numbering, actions, observations, rewards, histories and failure ids must not show it.  Two envs from the same seed, one with the
+    layout and one without, stepped with the same actions: every returned value equal bit for bit; then the paths that read the device
+    state as the env numbers it (history arrays, visibility, device agents, rollout, run_agent, run_policy) -- they put the state back
+    first -- equal too.  A quarter of the covariances is inflated so that failures, the 'shaped' arg-max and its ties happen."""
+    import torch
     cfg = dict(envs.env_config)
-    cfg.update(rso_count=96, steps=60, reward_type='trinary', obs_returned='flatten', seed=21, history='full')
-    a = envs.make(config=cfg)
-    b = envs.make(config=dict(cfg, layout='regime'))
-    order = b.object_order
-    assert a.object_order is None and sorted(order.tolist()) == list(range(96)) and not np.array_equal(order, np.arange(96))
-    inv = np.empty(96, dtype=int)
-    inv[order] = np.arange(96)
-    assert np.array_equal(np.asarray(a.x_true[0])[order], np.asarray(b.x_true[0]))
+    cfg.update(rso_count=128, steps=120, reward_type=reward, obs_returned=mode, seed=21, history='full', obs_limit=5.0)
+    a = envs.make(config=dict(cfg, storage_layout=None))
+    b = envs.make(config=cfg)
+    assert a._engine._order is None and b._engine._order is not None and not np.array_equal(b._engine._order, np.arange(128))
     rs = np.random.RandomState(3)
-    for k in range(40):
-        act = int(rs.randint(96))
-        oa, ra, da, _ = a.step(act)
-        ob, rb, db, _ = b.step(int(inv[act]))
-        assert ra == rb and da == db and np.array_equal(oa.reshape(96, 12)[order], ob.reshape(96, 12))
+    wild = torch.as_tensor(rs.uniform(size=128) < 0.25).cuda()
+    for env in (a, b):       # (inflate the same OBJECTS in both: positions differ under the layout)
+        e = env._engine
+        pos = wild if e._order is None else wild[e._order_idx]
+        e.P_filter[0, pos] *= 3e4
+    assert np.array_equal(a._obs_out(), b._obs_out())
+    for k in range(60):
+        act = int(rs.randint(128))
+        ra, rb = a.step(act), b.step(act)
+        assert np.array_equal(ra[0], rb[0]) and ra[1] == rb[1] and ra[2] == rb[2], k
+        if ra[2]:
+            break
+    assert b._engine._order is not None                    # step() alone never cost the layout
+    assert a.failed_filters_id == b.failed_filters_id and np.array_equal(a.rewards[:a.i + 1], b.rewards[:b.i + 1])
+    assert np.array_equal(np.asarray(a.z_true[1:a.i + 1]), np.asarray(b.z_true[1:b.i + 1]), equal_nan=True)
+    # ... the readers of the device state in the env's own order
     for name in ("x_true", "x_filter", "P_filter", "delta_pos", "sigma_pos"):
-        assert np.array_equal(np.asarray(getattr(a, name)[40])[order], np.asarray(getattr(b, name)[40])), name
-    assert np.array_equal(inv[a.actions[1:41].astype(int)], b.actions[1:41].astype(int))
-    assert np.array_equal(np.asarray(a.z_true[1:41])[:, order], np.asarray(b.z_true[1:41]), equal_nan=True)
+        assert np.array_equal(np.asarray(getattr(a, name)[a.i]), np.asarray(getattr(b, name)[b.i]), equal_nan=True), name
+    assert b._engine._order is None                        # (reading the history arrays put the state back)
+    assert np.array_equal(a.visible_objects(), b.visible_objects())
+    if not ra[2]:
+        r1, r2 = a.step(5), b.step(5)
+        assert np.array_equal(r1[0], r2[0]) and r1[1] == r2[1]
+    # a fresh episode sets the layout again; the multi-step entry points put the state back themselves
+    for entry in ("rollout", "run_agent", "run_policy"):
+        a.reset(), b.reset()
+        assert b._engine._order is not None
+        for k in range(3):
+            assert np.array_equal(a.step(k)[0], b.step(k)[0])
+        if entry == "rollout":
+            ua, ub = a.rollout([7, 8, 9, 10]), b.rollout([7, 8, 9, 10])
+        elif entry == "run_agent":
+            ua, ub = a.run_agent('agent_visible_greedy', 6), b.run_agent('agent_visible_greedy', 6)
+        else:
+            def pol(view):
+                sc, mask = view.scores()
+                return torch.clamp(view.argmax(sc[0], mask), min=0)
+            ua, ub = a.run_policy(pol, 6), b.run_policy(pol, 6)
+        for u, v in zip(ua, ub):
+            u, v = np.asarray(u), np.asarray(v)
+            assert np.array_equal(u, v, equal_nan=(u.dtype.kind == 'f')), entry
+        assert b._engine._order is None and a.i == b.i
+        assert np.array_equal(np.asarray(a.x_filter[a.i]), np.asarray(b.x_filter[b.i]))
     with pytest.raises(ValueError):
-        envs.make(config=dict(cfg, layout='sorted'))
+        envs.make(config=dict(cfg, storage_layout='sorted'))
