@@ -204,21 +204,20 @@ def episode_failures_oracle():
             "nan": int((st == orc.ST_PREDICT_NAN).sum())}
 
 
-def local_variant_rate(m, K, W, propagator, resample=False, seed=100, regime_sorted=False):
+def local_variant_rate(m, K, W, propagator, resample=False, seed=100, layout=True):
     """the N=1 measurement of `value` for another kernel variant on the same workload: K timed per-step launches (one
     launch per step, deferred statistics fold, episodes of 480 steps with device-side resets) after W warm-up steps"""
     import torch
     from ssa_gym_amd import engine, host, parallel
     pb = build_problem(m, seed=seed)
-    if regime_sorted:       # the same objects in another order: objects of one regime share wavefronts (catalogue.regime_order)
-        from ssa_gym_amd.catalogue import regime_order
-        order = regime_order(pb["x_true"])
-        pb["x_true"], pb["x"] = np.ascontiguousarray(pb["x_true"][order]), np.ascontiguousarray(pb["x"][order])
     consts = host.make_consts(pb["Q"], pb["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, pb["obs_lla"], obs_type='aer',
                               propagator=propagator, resample=resample)
     gen = torch.Generator(device="cuda").manual_seed(1)
     zn = torch.randn((1, 480, m, 3), dtype=torch.float64, device="cuda", generator=gen) * torch.as_tensor(pb["z_sigma"], device="cuda")
     eng = engine.HotPathEngine(consts, m, 1, pb["trans"], zn, history=2)
+    if layout:       # the engine's storage layout (objects of one orbit regime share wavefronts; invisible to the caller: see `caller_order`)
+        from ssa_gym_amd.catalogue import regime_order
+        eng.set_layout(regime_order(pb["x_true"]))
     eng.load_state(0, pb["x_true"], pb["x"], np.broadcast_to(pb["P0"], (m, 6, 6)))
     local = parallel.HipLocalStepper(eng, consts, fast_stats=True, defer_fold=True)
     local.load_schedule(list(np.arange(W + K) % m))
@@ -611,6 +610,15 @@ def main():
     z_noise = torch.randn((1, n_time, m, 3), dtype=torch.float64, device="cuda", generator=gen) * \
         torch.as_tensor(pb["z_sigma"], device="cuda")
     eng = engine.HotPathEngine(consts, m, 1, pb["trans"], z_noise, history=2)
+    # the engine's storage layout (HotPathEngine.set_layout / ssa_step_params.obj_ids: objects of one orbit regime share wavefronts; the
+    # kernels speak the caller's indices at every boundary, whole episodes are bit-identical to the caller's order) -- the un-sharded path; a
+    # rank of a sharded run stores its shard as it comes.  An ENGINE-level option: the gym-API legs do not use it (step() writes the
+    # observation for the host, whose rows would then leave the kernel one by one: 73 -> 84 us per 'flatten' step)
+    storage_layout = None
+    if not use_dist and m >= 64:
+        from ssa_gym_amd.catalogue import regime_order
+        eng.set_layout(regime_order(pb["x_true"]))
+        storage_layout = ("regime: objects stored by ascending semi-major axis, dealt tile by tile over the XCDs (catalogue.regime_order; HotPathEngine.set_layout -- an engine-level option, results bit-identical to the caller's order; `caller_order` is the same run without it)")
     eng.load_state(0, pb["x_true"], pb["x"], np.broadcast_to(pb["P0"], (m, 6, 6)))
 
     plan = parallel.ShardPlan(m * world, world, rank)
@@ -862,12 +870,13 @@ def main():
             if name == args.propagator:
                 continue
             legs[name] = local_variant_rate(m, Kl, Wl, **kw)
-        legs["regime_sorted"] = local_variant_rate(m, Kl, Wl, propagator=args.propagator, regime_sorted=True)
-        legs["regime_sorted"].update(note="the SAME objects, filter states and propagator as `value`, stored in another order: ascending semi-major axis, "
-                                          "dealt tile by tile over the XCDs (catalogue.regime_order).  An object's arithmetic does not depend on its "
-                                          "position; what changes is which objects share a wavefront -- late in an episode the diverged filters are the LEO "
-                                          "objects, and in catalogue order 76 % of the wavefronts hold at least one.  A layout hint for callers who can "
-                                          "choose their catalogue's order; `value` is measured in catalogue order")
+        legs["caller_order"] = local_variant_rate(m, Kl, Wl, propagator=args.propagator, layout=False)
+        legs["caller_order"].update(note="the same launches with the objects STORED as the caller numbers them (rounds 1-3; what the gym-API legs run). "
+                                         "`value` and the other engine-level per-step legs run with the engine's storage layout: ascending semi-major axis, dealt "
+                                         "tile by tile over the XCDs (catalogue.regime_order; HotPathEngine.set_layout) -- late in an episode the diverged "
+                                         "filters are the LEO objects, and in catalogue order 76 % of the wavefronts hold at least one.  The kernels speak "
+                                         "the caller's indices at every boundary and an object's arithmetic does not depend on its position: whole "
+                                         "episodes are bit-identical either way (build_ablate/layout_episode_ab.py)")
         if "j2" in legs:
             legs["j2"].update(note="EXTENSION without reference counterpart (SURVEY section 0): two-body + J2, RK4, 4 sub-steps")
         legs["resample"].update(note="predict() redraws the sigma points from the prior (SSA_FLAG_RESAMPLE); `value` keeps the "
@@ -933,6 +942,7 @@ def main():
                        "catalogue": "synthetic, drawn by the reference's recipe (envs/orbit_gen.py:30-70: regime probabilities and the visibility "
                                     "acceptance rule; ssa-gym_amd/catalogue.py): 6 806 LEO / 2 162 equatorial / 1 149 circular rows of 20 000 "
                                     "(the reference's file: 6 755 / 2 231 / 1 135), ecc <= 0.737",
+                       "storage_layout": storage_layout,
                        "propagator": args.propagator, "parallelism": "object-shard x%d" % world,
                        "allgather": (("comm-stream (overlapped with the next step)" if state["overlap"] else "in-stream")
                                      if use_dist else None),

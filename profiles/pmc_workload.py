@@ -22,6 +22,9 @@ pb = bench.build_problem(m, seed=100)
 consts = host.make_consts(pb["Q"], pb["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, pb["obs_lla"], obs_type='aer', propagator=os.environ.get('PROP', 'hybrid'))
 z = torch.zeros((1, 480, m, 3), dtype=torch.float64, device='cuda')
 eng = engine.HotPathEngine(consts, m, 1, pb["trans"], z, history=2)
+if os.environ.get('LAYOUT', '1') == '1':      # the env's default storage layout, as bench.py's `value` (LAYOUT=0: the caller's order)
+    from ssa_gym_amd.catalogue import regime_order
+    eng.set_layout(regime_order(pb["x_true"]))
 eng.load_state(0, pb["x_true"], pb["x"], np.broadcast_to(pb["P0"], (m, 6, 6)))
 local = parallel.HipLocalStepper(eng, consts, fast_stats=True)
 local.load_schedule(np.arange(400) % m)

@@ -240,8 +240,8 @@ class SSA_Tasker_Env(Env):
         self._consts, _ = kernel_consts(config, self.Q, self.R, self.dt, self.obs_limit, self.obs_lla)
         self._engine = None
         self._device_rng = bool(config.get('device_rng', False))
-        # config['storage_layout'] = 'regime' (default) | None: how the engine STORES the objects (reset()); invisible but for speed
-        self._storage_layout = config.get('storage_layout', 'regime')
+        # config['storage_layout'] = None (default) | 'regime': how the engine STORES the objects (reset()); invisible but for speed
+        self._storage_layout = config.get('storage_layout', None)
         if self._storage_layout not in (None, 'regime'):
             raise ValueError("config['storage_layout'] must be None or 'regime', not %r" % (self._storage_layout,))
         self._obs_buffers = config.get('obs_buffers', 2)
@@ -340,13 +340,17 @@ class SSA_Tasker_Env(Env):
             self._build_engine()
         else:
             self._engine.z_noise.copy_(self._z_noise_dev.reshape(self._engine.z_noise.shape))
-        # STORAGE LAYOUT (round 4): the engine keeps objects of one orbit regime in the same wavefronts -- ascending semi-major axis, dealt tile
-        # by tile over the XCDs (catalogue.regime_order) -- because late in an episode the diverged filters are the LEO objects, and packed
-        # they cost a launch 15 % less.  Nothing of it shows: the step kernel speaks the env's own indices wherever an
-        # index enters or leaves it (actions, failure records, arg-max of sigma_pos, the observation rows it writes for the host), an
-        # object's arithmetic does not depend on its position (bit-identical episodes, build_ablate/layout_episode_ab.py), and whatever reads
-        # the device state as the env numbers it -- the history arrays, the device-side agents and policies, rollout / closed loop -- puts
-        # the state back first (_caller_order(): the layout is then off until the next reset()).
+        # STORAGE LAYOUT (round 4, config['storage_layout'] = 'regime'; default off): the engine keeps objects of one orbit regime in the same
+        # wavefronts -- ascending semi-major axis, dealt tile by tile over the XCDs (catalogue.regime_order) -- because late in an episode
+        # the diverged filters are the LEO objects, and packed they cost a launch 15 % less.  Nothing of it shows: the
+        # step kernel speaks the env's own indices wherever an index enters or leaves it (actions, failure records, arg-max of sigma_pos, the
+        # observation rows it writes for the host), an object's arithmetic does not depend on its position (bit-identical episodes,
+        # build_ablate/layout_episode_ab.py), and whatever reads the device state as the env numbers it -- the history arrays, the device-side
+        # agents and policies, rollout / closed loop -- puts the state back first (_caller_order(): the layout is then off until the next
+        # reset()).  OFF by default HERE: what step() gains in the kernel (2-5 us late in an episode) it loses on the way to the host -- the
+        # observation rows leave the kernel row by row at the env's indices instead of tile by tile (1.9 MB over PCIe in 96-byte pieces: 'flatten'
+        # 73 -> 84 us per step at 20 000 objects).  It pays for launch sequences that keep the observations on the device: the engine-level
+        # loops (HotPathEngine.set_layout; bench.py's `value`), C-ABI callers (ssa_step_params.obj_ids).
         lay = self._storage_layout == 'regime' and m >= 64 and not self._obs_device
         if lay:
             from ..catalogue import regime_order

@@ -914,7 +914,7 @@ print("ok")
 
 @pytest.mark.parametrize("mode,reward", [('flatten', 'trinary'), ('aer', 'shaped'), ('default', 'jones')])
 def test_storage_layout_is_invisible_through_the_gym_api(envs, mode, reward):
-    """config['storage_layout'] = 'regime' (the default): the engine stores objects of one orbit regime in the same wavefronts; the env's
+    """config['storage_layout'] = 'regime' (opt-in): the engine stores objects of one orbit regime in the same wavefronts; the env's
     numbering, actions, observations, rewards, histories and failure ids must not show it.  Two envs from the same seed, one with the
     layout and one without, stepped with the same actions: every returned value equal bit for bit; then the paths that read the device
     state as the env numbers it (history arrays, visibility, device agents, rollout, run_agent, run_policy) -- they put the state back
@@ -922,8 +922,8 @@ def test_storage_layout_is_invisible_through_the_gym_api(envs, mode, reward):
     import torch
     cfg = dict(envs.env_config)
     cfg.update(rso_count=128, steps=120, reward_type=reward, obs_returned=mode, seed=21, history='full', obs_limit=5.0)
-    a = envs.make(config=dict(cfg, storage_layout=None))
-    b = envs.make(config=cfg)
+    a = envs.make(config=cfg)
+    b = envs.make(config=dict(cfg, storage_layout='regime'))
     assert a._engine._order is None and b._engine._order is not None and not np.array_equal(b._engine._order, np.arange(128))
     rs = np.random.RandomState(3)
     wild = torch.as_tensor(rs.uniform(size=128) < 0.25).cuda()
