@@ -840,12 +840,19 @@ def main():
     roll = None
     if rank == 0 and world == 1 and not use_dist and args.rollout > 0:
         R = args.rollout
+        # (the rollout kernels keep their tiles in the caller's order: this leg's episodes start from a snapshot WITHOUT the storage layout --
+        # restoring the per-step legs' snapshot would set the layout again and the next rollout would gather the state back, every episode)
+        local.reset_episode(snap, ep_len)
+        state["i"] = 0
+        eng.to_caller_order()
+        torch.cuda.synchronize()
+        snap_roll = eng.snapshot(local.tick % eng.H)
 
         def roll_steps(n):
             done = 0
             while done < n:
                 if state["i"] == ep_len - 1:
-                    local.reset_episode(snap, ep_len)
+                    local.reset_episode(snap_roll, ep_len)
                     state["i"] = 0
                 kk = min(R, n - done, ep_len - 1 - state["i"])
                 local.rollout(kk)
