@@ -611,11 +611,11 @@ def main():
         torch.as_tensor(pb["z_sigma"], device="cuda")
     eng = engine.HotPathEngine(consts, m, 1, pb["trans"], z_noise, history=2)
     # the engine's storage layout (HotPathEngine.set_layout / ssa_step_params.obj_ids: objects of one orbit regime share wavefronts; the
-    # kernels speak the caller's indices at every boundary, whole episodes are bit-identical to the caller's order) -- the un-sharded path; a
-    # rank of a sharded run stores its shard as it comes.  An ENGINE-level option: the gym-API legs do not use it (step() writes the
+    # kernels speak the caller's indices at every boundary, whole episodes are bit-identical to the caller's order); a rank of a sharded run
+    # lays out its own shard (the all-gather payload is written at the caller's rows).  An ENGINE-level option: the gym-API legs do not use it (step() writes the
     # observation for the host, whose rows would then leave the kernel one by one: 73 -> 84 us per 'flatten' step)
     storage_layout = None
-    if not use_dist and m >= 64:
+    if m >= 64 and os.environ.get("SSA_BENCH_LAYOUT", "1") == "1":      # (every rank lays out its own shard; SSA_BENCH_LAYOUT=0: the caller's order)
         from ssa_gym_amd.catalogue import regime_order
         eng.set_layout(regime_order(pb["x_true"]))
         storage_layout = ("regime: objects stored by ascending semi-major axis, dealt tile by tile over the XCDs (catalogue.regime_order; HotPathEngine.set_layout -- an engine-level option, results bit-identical to the caller's order; `caller_order` is the same run without it)")
@@ -840,19 +840,12 @@ def main():
     roll = None
     if rank == 0 and world == 1 and not use_dist and args.rollout > 0:
         R = args.rollout
-        # (the rollout kernels keep their tiles in the caller's order: this leg's episodes start from a snapshot WITHOUT the storage layout --
-        # restoring the per-step legs' snapshot would set the layout again and the next rollout would gather the state back, every episode)
-        local.reset_episode(snap, ep_len)
-        state["i"] = 0
-        eng.to_caller_order()
-        torch.cuda.synchronize()
-        snap_roll = eng.snapshot(local.tick % eng.H)
 
-        def roll_steps(n):
+        def roll_steps(n):      # (the rollout launches keep the engine's storage layout)
             done = 0
             while done < n:
                 if state["i"] == ep_len - 1:
-                    local.reset_episode(snap_roll, ep_len)
+                    local.reset_episode(snap, ep_len)
                     state["i"] = 0
                 kk = min(R, n - done, ep_len - 1 - state["i"])
                 local.rollout(kk)

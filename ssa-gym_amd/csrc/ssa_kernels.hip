@@ -1112,7 +1112,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     // ssa_step_params.obj_ids (one env, the per-step kernels): the objects are stored in another order than the caller numbers them; the
     // action, the failure records, the arg-max of sigma_pos and the host-facing observation rows speak the CALLER's indices
     int64_t jid = j;
-    if (TILE != 2 && !ACT::late && p.obj_ids) {
+    if (!ACT::late && p.obj_ids) {
         // (the tile's four indices by ONE wave-uniform 16-byte load -- scalar memory: it does not queue behind the tile's vector loads, which a
         // per-lane load would, and the update's input prefetch below hangs on `my_update`; the table is padded to whole tiles)
         const int4 ids = *reinterpret_cast<const int4*>(p.obj_ids + base);
@@ -1587,7 +1587,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
             if ((int)at < p.fail_cap) {
                 double* rec = p.fail_log + (int64_t)at * SSA_FAIL_STRIDE;
                 rec[SSA_FAIL_ENV] = (double)e;
-                rec[SSA_FAIL_OBJ] = (TILE != 2 && !ACT::late && p.obj_ids) ? (double)t.Oid[g] : (double)(obj - (int64_t)e * p.n_obj);
+                rec[SSA_FAIL_OBJ] = (!ACT::late && p.obj_ids) ? (double)t.Oid[g] : (double)(obj - (int64_t)e * p.n_obj);
                 rec[SSA_FAIL_STATUS] = (double)st_new;
                 rec[SSA_FAIL_TIME] = (double)((ACT::late ? p.env_time[0] : env_time_of<INL>(p, e)) + p.time_offset);
                 rec[SSA_FAIL_ERR + 0] = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
@@ -1611,7 +1611,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     // observation mode and the multi-GPU all-gather payload -- from the tiles, so that no second pass over x / P (the
     // former post kernel: 6.7 MB re-read per 20 000 objects plus a launch) is needed
     if (p.aer_out && p.stat_shards) {
-        if (l < 4 && valid) aer_obs_tile<INL>(t, p, C, g, l, e, (TILE != 2 && !ACT::late && p.obj_ids) ? (int64_t)t.Oid[g] : obj);
+        if (l < 4 && valid) aer_obs_tile<INL>(t, p, C, g, l, e, (!ACT::late && p.obj_ids) ? (int64_t)t.Oid[g] : obj);
     }
     wave_lds_sync();
     SSA_TR(7);
@@ -1619,7 +1619,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
 #if !(defined(SSA_ABLATE) && (SSA_ABLATE & 32))
         if (p.spos_tiles && p.stat_shards && lane == 0) {   // the tile's first maximum of sigma_pos (np.argmax for the 'shaped' reward): one slot, no atomics
             unsigned long long key, idx;
-            spos_tile_best(t, cnt, obj - (int64_t)e * p.n_obj, key, idx, TILE != 2 && p.obj_ids != nullptr);
+            spos_tile_best(t, cnt, obj - (int64_t)e * p.n_obj, key, idx, p.obj_ids != nullptr);
             unsigned long long* slot = (unsigned long long*)p.spos_tiles + 2 * (int64_t)tile;
             __hip_atomic_store(slot, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (agent scope: SSA_LAUNCH_FOLD_INSIDE reads them in this launch)
             __hip_atomic_store(slot + 1, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -3314,7 +3314,8 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
         (!p->stat_shards || !p->stats || (p->launch_mask & SSA_LAUNCH_DEFER_FOLD))) return SSA_E_INVALID;
     if (p->spos_tiles && !p->stat_shards) return SSA_E_INVALID;
     if (p->fail_log && (!p->fail_count || p->fail_cap <= 0)) return SSA_E_INVALID;
-    if (p->obj_ids && p->n_env != 1) return SSA_E_UNSUPPORTED;
+    if (p->obj_ids && (p->n_env != 1 || !p->stat_shards)) return SSA_E_UNSUPPORTED;   // (one env; the statistics of the one-launch paths: the post
+                                                                                        // kernel's arg-max would speak storage positions)
     if ((p->spos_tiles || p->spos_tiles_prev) && p->n_env > 1 && (p->n_obj % OBJ_PER_WAVE) != 0) return SSA_E_UNSUPPORTED;   // whole tiles per env
     if (c->obs_type != SSA_OBS_AER && c->obs_type != SSA_OBS_XYZ) return SSA_E_INVALID;
     if (p->aer_cols != 0 && p->aer_cols != 1 && p->aer_cols != 4) return SSA_E_INVALID;
@@ -3420,7 +3421,7 @@ int ssa_env_rollout_f64(const ssa_consts* c, const ssa_step_params* p, const ssa
     rk.k.p.aer_out = nullptr;
     rk.k.p.spos_tiles = nullptr;
     rk.k.p.spos_tiles_prev = nullptr;
-    if (p->obj_ids) return SSA_E_UNSUPPORTED;       // (a layout table belongs to the per-step launches: the caller restores its own order first)
+    if (p->obj_ids && p->n_env != 1) return SSA_E_UNSUPPORTED;
     rk.r = *r;
     const int64_t ntiles = (total + OBJ_PER_WAVE - 1) / OBJ_PER_WAVE;
     const int64_t slots = (int64_t)device_cu_count() * 4 * SSA_STEP_WAVES;

@@ -119,8 +119,8 @@ class HotPathEngine:
         late in an episode the diverged filters are the LEO objects, and packed they cost a launch 10 % less.
         The per-step launches speak the caller's indices wherever an index enters or leaves (actions, failure records, arg-max of sigma_pos,
         the host-facing observation rows: include/ssa_hip.h); the state tensors of this engine (x_true, x_filter, P_filter, obs, metrics,
-        status) are in STORAGE order while a layout is set -- `to_caller_order()` puts them back (the rollout and closed-loop launches do that
-        themselves).  Call before load_state(); the state present is not moved."""
+        status) are in STORAGE order while a layout is set -- `to_caller_order()` puts them back (the closed-loop launch does that itself; the
+        rollout keeps the layout).  Call before load_state(); the state present is not moved."""
         self._order = None
         self._p.obj_ids = 0
         self._pcache.clear()
@@ -326,7 +326,6 @@ class HotPathEngine:
                 and actions.dim() == 2 and actions.shape[1] == self.E and actions.shape[0] >= 1):
             raise _lib.SsaHipError("rollout: actions must be a contiguous CUDA int32 tensor [K][n_env]")
         s = torch.cuda.current_stream().cuda_stream if stream is None else stream
-        self.to_caller_order()           # (a storage layout belongs to the per-step launches)
         self.flush_stats(s)
         K = int(actions.shape[0])
         if getattr(self, "_roll_shards", None) is None or self._roll_shards.shape[0] < K:

@@ -1415,13 +1415,19 @@ def test_storage_layout_speaks_the_callers_indices(hip, prop, m):
                             fast_stats=True, fold_inside=True, argmax_spos=True)
             torch.cuda.synchronize()
             out.append((mirror.numpy().copy(), aer.numpy().copy(), st.numpy().copy(), upd.numpy().copy()))
+        # ... and five more steps as ONE rollout launch (ssa_env_rollout_f64 keeps the layout: actions, failure records and the per-step
+        # arg-max slots speak the caller's indices there too)
+        ra = torch.as_tensor(((np.arange(5) * 31 + 11) % m).astype(np.int32)).cuda().view(5, 1)
+        eng.launch_rollout(n_steps % 2, n_steps + 1, ra, argmax_spos=True)
+        torch.cuda.synchronize()
+        out.append((eng.stats.cpu().numpy().copy(), eng.upd.cpu().numpy().copy(), np.zeros(1), np.zeros(1)))
         nf = int(eng.fail_count.item())
         fails = sorted((int(r[hip.lib.FAIL_OBJ]), int(r[hip.lib.FAIL_STATUS]), int(r[hip.lib.FAIL_TIME]), tuple(r[hip.lib.FAIL_ERR:hip.lib.FAIL_ERR + 4]))
                        for r in eng.fail_log[:nf])
         assert (eng._order is None) == (layout is None)
         eng.to_caller_order()
         assert eng._order is None
-        s = n_steps % 2
+        s = (n_steps + 5) % 2
         state = (eng.x_true[s].cpu().numpy(), eng.x_filter[s].cpu().numpy(), eng.P_filter[s].cpu().numpy(), eng.obs[s].cpu().numpy(),
                  eng.metrics[s].cpu().numpy(), eng.status.cpu().numpy())
         return init_stats, out, fails, state
@@ -1435,4 +1441,4 @@ def test_storage_layout_speaks_the_callers_indices(hip, prop, m):
     for name, va, vb in zip(("x_true", "x_filter", "P_filter", "obs", "metrics", "status"), a[3], b[3]):
         assert np.array_equal(va, vb, equal_nan=True), name
     if prop == "hybrid":     # (the failure path did run)
-        assert int(a[1][-1][2][hip.lib.STAT_N_FAILED]) >= 2
+        assert int(a[1][-2][2][hip.lib.STAT_N_FAILED]) >= 2

@@ -199,6 +199,8 @@ def _hip_worker(rank, world, port, q, m, actions, cols, exchange="rccl", unit=0)
         sl = slice(plan.lo, plan.hi)
         consts = host.make_consts(g["Q"], g["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, g["obs_lla"])
         eng = engine.HotPathEngine(consts, plan.m_local, 1, c2t, np.ascontiguousarray(zn[:, :, sl]), history=2)
+        if exchange == "peer":      # (these cases also run with a storage layout of the rank's shard: HotPathEngine.set_layout -- the all-gather
+            eng.set_layout(np.random.RandomState(40 + rank).permutation(plan.m_local))    # payload must come out in the caller's order all the same)
         eng.load_state(0, xt[sl], x[sl], P[sl])
         local = parallel.HipLocalStepper(eng, consts, fast_stats=True)
         sh = parallel.ShardedStepper(plan, local, obs_cols=cols, exchange=exchange)
@@ -225,6 +227,7 @@ def _hip_worker(rank, world, port, q, m, actions, cols, exchange="rccl", unit=0)
             for k, a in enumerate(actions):
                 sh.step(a, overlap=(k % 3 == 2))
                 record()
+        eng.to_caller_order()
         t = local.tick % 2
         state = (eng.x_true[t].cpu().numpy(), eng.x_filter[t].cpu().numpy(), eng.P_filter[t].cpu().numpy(), eng.status.cpu().numpy())
         q.put((rank, outs if rank == 0 else None, state))
