@@ -20,6 +20,9 @@ consts = host.make_consts(pb["Q"], pb["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, pb[
                           propagator=os.environ.get("PROP", "fg"))
 z = torch.zeros((1, 480, m, 3), dtype=torch.float64, device='cuda')
 eng = engine.HotPathEngine(consts, m, 1, pb["trans"], z, history=2)
+if os.environ.get("LAYOUT") == "1":      # the engine's storage layout (objects of one orbit regime share wavefronts)
+    from ssa_gym_amd.catalogue import regime_order
+    eng.set_layout(regime_order(pb["x_true"]))
 eng.load_state(0, pb["x_true"], pb["x"], np.broadcast_to(pb["P0"], (m, 6, 6)))
 local = parallel.HipLocalStepper(eng, consts, fast_stats=True)
 local.load_schedule(np.arange(4000) % m)
@@ -53,6 +56,14 @@ for lab, sel in (("waves started < 1 us", early), ("waves started >= 1 us", ~ear
     print("%s: n=%d  lifetime %.2f us" % (lab, sel.sum(), life[sel].mean()))
     for k, nme in enumerate(names):
         print("    %-8s %6.2f us (p90 %6.2f)" % (nme, d[:, k].mean(), np.percentile(d[:, k], 90)))
+slow = (np.diff(t, axis=1)[:, 2] / 1e3) > 3.5      # the propagation stage ran the conic chain
+for lab, sel in (("waves whose propagation stage took > 3.5 us", slow), ("the others", ~slow)):
+    if sel.sum() == 0:
+        continue
+    d = np.diff(t[sel], axis=1) / 1e3
+    print("%s: n=%d  lifetime %.2f us (p90 %.2f)  start %.2f  end %.2f (p99 %.2f)" % (lab, sel.sum(), life[sel].mean(), np.percentile(life[sel], 90), st[sel].mean(),
+                                                                                    en[sel].mean(), np.percentile(en[sel], 99)))
+    print("    " + "  ".join("%s %.2f" % (nme, d[:, k].mean()) for k, nme in enumerate(names)))
 # which branch of the out-of-line propagation the wavefront's lanes took (bit 1 hyperbolic, 2 near-parabolic band, 4 elliptic beyond the
 # series) and their longest hyperbolic Newton run -- words 13 / 14 of the -DSSA_TRACE build
 br, it = tr[:, 13] & 7, tr[:, 14]
