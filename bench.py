@@ -616,9 +616,9 @@ def main():
     # observation for the host, whose rows would then leave the kernel one by one: 73 -> 84 us per 'flatten' step)
     storage_layout = None
     # (every rank lays out its own shard; SSA_BENCH_LAYOUT=0: the caller's order.  Launches of more than 20 480 objects -- a wavefront then walks
-    # several tiles, stride = the number of wavefronts -- keep the caller's order: grouped by regime, some wavefronts would walk ONLY slow tiles
-    # (160 000 objects: 119 us per step with the layout against 111 without))
-    if 64 <= m <= 20480 and os.environ.get("SSA_BENCH_LAYOUT", "1") == "1":
+    # several tiles, stride = the number of wavefronts -- take the plain sort: every wavefront's walk then runs through the same mix of regimes
+    # (160 000 objects: 96 us per step; 113 in the caller's order; 119 with the one-tile dealing, where some wavefronts walk ONLY slow tiles))
+    if m >= 64 and os.environ.get("SSA_BENCH_LAYOUT", "1") == "1":
         from ssa_gym_amd.catalogue import regime_order
         eng.set_layout(regime_order(pb["x_true"]))
         storage_layout = ("regime: objects stored by ascending semi-major axis, dealt tile by tile over the XCDs (catalogue.regime_order; HotPathEngine.set_layout -- an engine-level option, results bit-identical to the caller's order; `caller_order` is the same run without it)")

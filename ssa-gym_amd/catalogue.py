@@ -133,20 +133,22 @@ def synthetic_catalogue(n=20000, seed=0, visibility=True):
     return out.copy()
 
 
-def regime_order(x, tile=4, n_xcd=8):
+def regime_order(x, tile=4, n_xcd=8, one_tile_limit=20480):
     """a permutation of the objects (rows of x: GCRS states) that puts objects of the same regime into the same wavefronts: ascending
     semi-major axis, the sorted list dealt in chunks of one tile (4 objects = one wavefront) round-robin over the 8 XCDs' runs of tiles, so
     that every XCD gets the same share of every regime.  Why it matters (round 4, profiles/r04_sorted_tiles_experiment.txt): with the
     behaviour-faithful propagator the filters that leave the strong-elliptic regime late in an episode are the LEO objects (6 795 of 6 806;
     0 of the 13 194 others); in catalogue order they are spread over 76 % of the wavefronts, each of which then runs the conic chain
     and the jitter ladder for one or two of its four objects.  Returns order[m]: new position -> original row (m a multiple of tile * n_xcd;
-    otherwise the plain sort)."""
+    otherwise -- and beyond 20 480 objects, where a wavefront walks several tiles -- the plain sort)."""
     x = np.asarray(x)
     a = 1.0 / (2.0 / np.linalg.norm(x[:, :3], axis=1) - np.sum(x[:, 3:] ** 2, axis=1) / MU)
     L = np.argsort(a, kind="stable")
     m = len(L)
     nt = m // tile
-    if m % (tile * n_xcd):
+    if m % (tile * n_xcd) or m > one_tile_limit:
+        # (more than 20 480 objects: a wavefront walks several tiles, stride = the number of wavefronts -- in plain sorted order every wavefront's
+        # walk then runs from the slowest regime to the fastest, the same mix for all of them)
         return L
     q = nt // n_xcd
     order = np.empty(m, dtype=np.int64)

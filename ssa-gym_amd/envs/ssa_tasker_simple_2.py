@@ -351,7 +351,7 @@ class SSA_Tasker_Env(Env):
         # observation rows leave the kernel row by row at the env's indices instead of tile by tile (1.9 MB over PCIe in 96-byte pieces: 'flatten'
         # 73 -> 84 us per step at 20 000 objects).  It pays for launch sequences that keep the observations on the device: the engine-level
         # loops (HotPathEngine.set_layout; bench.py's `value`), C-ABI callers (ssa_step_params.obj_ids).
-        lay = self._storage_layout == 'regime' and 64 <= m <= 20480 and not self._obs_device     # (one tile per wavefront: beyond, grouping unbalances the walk)
+        lay = self._storage_layout == 'regime' and m >= 64 and not self._obs_device
         if lay:
             from ..catalogue import regime_order
             self._engine.set_layout(regime_order(x_true0))
