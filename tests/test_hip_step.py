@@ -1336,7 +1336,7 @@ def test_resample_variant_fails_in_the_predict_that_draws_the_points(hip, oracle
 
 @pytest.mark.parametrize("prop", ["hybrid", "fg"])
 def test_an_objects_arithmetic_does_not_depend_on_its_position(hip, prop):
-    """The layout hint of round 4 (catalogue.regime_order: objects of one regime share wavefronts; bench leg `regime_sorted`) rests on this:
+    """The storage layout of round 4 (catalogue.regime_order + HotPathEngine.set_layout: objects of one regime share wavefronts) rests on this:
     the same objects, filter states and noise stored in another order give, object by object, the SAME BITS -- states, covariances, truth,
     status, observation rows, statistics -- over 40 steps with an update in every step, with a third of the filters inflated so far that their
     sigma points leave the strong-elliptic regime (conic tier, jitter ladder, failures included).  2 016 objects (whole tiles per XCD run)."""
