@@ -15,7 +15,7 @@ import numpy as np
 class ObsPool:
     def __init__(self, n_doubles, shape, cap=64):
         self.n, self.shape, self.cap = int(n_doubles), tuple(shape), int(cap)
-        self._bufs, self.ptrs, self._free = [], [], []
+        self._bufs, self._np, self.ptrs, self._free = [], [], [], []
         self.handed_out = 0            # (diagnostic: arrays given out / buffers ever allocated)
 
     def acquire(self):
@@ -26,6 +26,7 @@ class ObsPool:
             import torch
             t = torch.zeros(self.n, dtype=torch.float64).pin_memory()
             self._bufs.append(t)
+            self._np.append(t.numpy())
             self.ptrs.append(t.data_ptr())
             return len(self._bufs) - 1
         return None
@@ -36,7 +37,9 @@ class ObsPool:
     def hand_out(self, k):
         """a FRESH ndarray over buffer k (its memory is pinned, host-mapped, just written by the kernel); buffer k is free again when this
         array and every view of it have been dropped"""
-        c = (ctypes.c_double * self.n).from_address(self.ptrs[k])
+        # (from_buffer, not from_address: the ctypes object then OWNS a reference to the pinned tensor's array -- an observation a consumer still
+        # holds keeps its memory alive even when the env that handed it out is gone)
+        c = (ctypes.c_double * self.n).from_buffer(self._np[k])
         weakref.finalize(c, self._free.append, k)
         self.handed_out += 1
         return np.frombuffer(c, dtype=np.float64).reshape(self.shape)

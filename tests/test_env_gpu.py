@@ -553,6 +553,13 @@ def test_step_hands_out_observations_a_consumer_may_keep(envs):
     assert len(pool) == 5 and np.array_equal(view, snap1[12:24])
     del view
     assert len(pool._free) == 5
+    o, _, _, _ = env.step(12)                           # an observation outlives the env that handed it out (it owns its pinned buffer)
+    snap = o.copy()
+    del env, pool
+    gc.collect()
+    filler = [np.random.rand(30 * 12) for _ in range(8)]
+    assert np.array_equal(o, snap)
+    del filler
     small = envs.make(config=dict(cfg, obs_pool=2))     # a consumer that hoards: copies beyond the cap, still never overwritten
     hoard = []
     for k in range(6):
