@@ -537,6 +537,25 @@ SSA_DEV bool kepler_conic_lean(const double* x, double tof, double* out)
     const bool lean = (HYPER_ONLY ? (ecc > 1.0 + 1e-2) : (ecc >= 1e-8)) && (h[2] * h[2] < hh * (1.0 - 4e-15)) && (hh <= 1.79769313486231570e308) &&
                       (ecc <= 1.79769313486231570e308) && (rn > 0.0);
     if (!lean) return false;                 // (lane-divergent from here on: only the lanes that take this tier run its loops)
+#ifndef SSA_HYBRID_REFERENCE_BANDS
+    // TAG 1 = SSA_PROP_HYBRID: the BANDS -- near-parabolic |ecc - 1| <= 1e-2, parabolic, elliptic beyond the series solver's domain -- go
+    // through the universal-variable solver (kepler_uv_general: SSA_PROP_FG's, 1e-15 on every conic) instead of the reference's
+    // near-parabolic machinery (farnocchia.py:876-908, 975-1000).  What makes the hybrid behaviour-faithful is the strong-hyperbolic
+    // chain below -- its F <-> nu round trips are the reference's propagation error on far-out states, and that error shapes the failure
+    // statistics; in the bands the reference is itself accurate to its Newton tolerance, the two solvers agree to
+    // ~1e-12, and the gate (tests/test_episode_failures.py) does not tell them apart.  But 2.7 % of the late-episode wavefronts hold such a
+    // sigma point next to hyperbolic ones, ran this tier's hyperbolic branch AND ~1 500 dependent instructions of band arithmetic one after
+    // the other, and ended every late launch 3 us behind the 99th percentile (profiles/r04_wave_timeline_hybrid_step330_layout.txt).
+    // SSA_PROP_ELEMENTS (TAG 2) and the operator kernels (TAG 0) keep the reference's bands; -DSSA_HYBRID_REFERENCE_BANDS: the hybrid too.
+    if (TAG == 1 && !HYPER_ONLY && !(ecc > 1.0 + 1e-2)) {
+        SSA_KEP_DBG_BRANCH(ecc >= 1.0 - 1e-2 ? 2 : 4);
+        if (!kepler_uv_general(x, tof, out)) {       // (no convergence in 16 iterations: NaN, as the reference's newton() gives up -- farnocchia.py:353)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) out[c] = __builtin_nan("");
+        }
+        return true;
+    }
+#endif
     const double a = div_fast(p, 1.0 - ecc * ecc);
     const double ka = MU * a;
     const double e_c = rn * vv * inv_mu - 1.0;                                                   // e cos E | e cosh F
