@@ -66,9 +66,15 @@ extern "C" {
 
 #define SSA_PROP_HYBRID 3   /* the behaviour-faithful variant at speed: the universal-variable series solver of SSA_PROP_FG on
                                strong-elliptic states (ecc < 1 - 1e-2, farnocchia.py:871: there the reference's chain agrees with it
-                               to 1e-14), the reference's own formulas -- branch by branch, NaN by NaN -- on every other state, which
-                               is where its filters go wrong.  With SSA_FLAG_REFERENCE_COV the same episode-level failure statistics
-                               as SSA_PROP_ELEMENTS and the oracle (tests/test_episode_failures.py) */
+                               to 1e-14); the reference's own STRONG-HYPERBOLIC chain (ecc > 1 + 1e-2, farnocchia.py:909-912,
+                               1001-1004: F from the elements, F -> nu -> F, the hyperbolic Newton solve, F -> nu) -- operation by
+                               operation, NaN by NaN -- on the states where its filters go wrong: a diverged filter's sigma points, which
+                               that chain propagates metres to kilometres off; and (round 4) the universal-variable solver again on
+                               the bands in between (|ecc - 1| <= 1e-2, elliptic orbits beyond the series' range), where the reference
+                               is accurate to its Newton tolerance and the two agree to ~1e-12.  rv2coe's special orientations
+                               (circular, equatorial) take the complete restatement.  With SSA_FLAG_REFERENCE_COV the same
+                               episode-level failure statistics as SSA_PROP_ELEMENTS and the oracle (tests/test_episode_failures.py:
+                               pooled counts, failed-set overlap, first-failure-step distributions over five workloads) */
 
 /* flags of ssa_step_params.flags */
 #define SSA_FLAG_RESAMPLE 1u /* predict() ends by redrawing the sigma points from the prior, for every filter (the
