@@ -617,7 +617,7 @@ def main():
     storage_layout = None
     # (every rank lays out its own shard; SSA_BENCH_LAYOUT=0: the caller's order.  Launches of more than 20 480 objects -- a wavefront then walks
     # several tiles, stride = the number of wavefronts -- take the plain sort: every wavefront's walk then runs through the same mix of regimes
-    # (160 000 objects: 96 us per step; 113 in the caller's order; 119 with the one-tile dealing, where some wavefronts walk ONLY slow tiles))
+    # (160 000 objects: 93 us per step against 113 in the caller's order; the one-tile dealing, where some wavefronts walk ONLY slow tiles, is slower than either))
     if m >= 64 and os.environ.get("SSA_BENCH_LAYOUT", "1") == "1":
         from ssa_gym_amd.catalogue import regime_order
         eng.set_layout(regime_order(pb["x_true"]))
@@ -965,8 +965,11 @@ def main():
                                      "failures (see `episode_failures`; the behaviour-faithful variants are `hybrid` -- the env default -- and `elements`)" % args.propagator
                                      if args.propagator in ("fg", "j2") else
                                      "%s: the BEHAVIOUR-FAITHFUL variant%s -- per-step parity within the north_star tolerance AND the reference's episode-level "
-                                     "filter failures (`episode_failures`, tests/test_episode_failures.py over five workloads)"
-                                     % (args.propagator, " and the env default (what `fx_xyz_farnocchia` resolves to)" if args.propagator == "hybrid" else ""))},
+                                     "filter failures (`episode_failures`, tests/test_episode_failures.py over five workloads)%s"
+                                     % (args.propagator, " and the env default (what `fx_xyz_farnocchia` resolves to)" if args.propagator == "hybrid" else "",
+                                        ": the universal-variable series solver on strong-elliptic states, the reference's own strong-hyperbolic chain on "
+                                        "diverged sigma points (the branch whose propagation error shapes the failures), universal variables on the "
+                                        "near-parabolic bands in between, the prior covariance in the reference's arithmetic" if args.propagator == "hybrid" else ""))},
             "object_steps_per_sec": round(steps_per_s * m * world, 1),
             "failed_filters": n_failed,
             "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "episode_failures": ep_fail, "rollout": roll,
