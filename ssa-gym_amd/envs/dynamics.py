@@ -179,7 +179,8 @@ class _FxCowell(_FxFarnocchia):
 
 
 # `fx_xyz_farnocchia` -- the env default, what the reference's own token resolves to -- is the BEHAVIOUR-FAITHFUL variant: the series
-# solver on strong-elliptic states, the reference's conic branches elsewhere, the reference's covariance arithmetic (SSA_PROP_HYBRID +
+# solver on strong-elliptic states, the reference's strong-hyperbolic chain on diverged sigma points, universal variables on the bands in
+# between, the reference's covariance arithmetic (SSA_PROP_HYBRID +
 # SSA_FLAG_REFERENCE_COV): an episode loses filters the way the reference's does (tests/test_episode_failures.py).  Until round 4 the
 # default was the universal-variable form (`fx_xyz_farnocchia_fg` now): more accurate than the reference on diverged states, its filters
 # survive where the reference's fail -- the explicitly named accuracy / speed option.

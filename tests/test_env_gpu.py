@@ -364,7 +364,7 @@ def test_vector_env_honours_the_fx_token(envs, fx_name, prop):
         assert np.array_equal(vec.x_true(0), one.x_true[k])                      # truth: the propagator alone
         never = np.array([j not in [kk % 9 for kk in range(1, k + 1)] for j in range(9)])
         assert np.array_equal(vec.x_filter(0)[never], one.x_filter[k][never])    # predict-only objects: bit-identical
-    # the default token means the behaviour-faithful variant (series solver + the reference's conic branches + the reference's covariance
+    # the default token means the behaviour-faithful variant (series solver + the reference's strong-hyperbolic chain + the reference's covariance
     # arithmetic), for both classes; the universal-variable form is the explicitly named option
     cfg['fx'] = D.fx_xyz_farnocchia
     for env_ in (SSA_Tasker_VecEnv(cfg, 1, seed=5), envs.make(config=cfg)):
