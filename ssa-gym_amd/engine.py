@@ -121,6 +121,8 @@ class HotPathEngine:
         the host-facing observation rows: include/ssa_hip.h); the state tensors of this engine (x_true, x_filter, P_filter, obs, metrics,
         status) are in STORAGE order while a layout is set -- `to_caller_order()` puts them back (the closed-loop launch does that itself; the
         rollout keeps the layout).  Call before load_state(); the state present is not moved."""
+        if order is None and self._order is None:
+            return
         self._order = None
         self._p.obj_ids = 0
         self._pcache.clear()
