@@ -257,7 +257,7 @@ def local_variant_rate(m, K, W, propagator, resample=False, seed=100, layout=Tru
     return out
 
 
-def closed_loop_rate(m, K, W, seed=100, persistent=True, chunk=120, agent=None, propagator='hybrid'):
+def closed_loop_rate(m, K, W, seed=100, persistent=True, chunk=120, agent=None, propagator='hybrid', layout=True):
     """closed loop WITHOUT the host: the reference's agent_visible_greedy (agents.py:36: arg-max of trace(P) over the visible
     objects) chooses every step's action on the device.  persistent: ssa_env_closed_loop_f64 -- `chunk` steps and their decisions
     per launch, the wavefronts agree on the next action among themselves while the next predicts already run; else the
@@ -270,6 +270,9 @@ def closed_loop_rate(m, K, W, seed=100, persistent=True, chunk=120, agent=None, 
     gen = torch.Generator(device="cuda").manual_seed(1)
     zn = torch.randn((1, 480, m, 3), dtype=torch.float64, device="cuda", generator=gen) * torch.as_tensor(pb["z_sigma"], device="cuda")
     eng = engine.HotPathEngine(consts, m, 1, pb["trans"], zn, history=2)
+    if layout:      # the engine's storage layout (objects of one orbit regime share wavefronts; the agent kernels and the persistent launch take the table)
+        from ssa_gym_amd.catalogue import regime_order
+        eng.set_layout(regime_order(pb["x_true"]))
     eng.load_state(0, pb["x_true"], pb["x"], np.broadcast_to(pb["P0"], (m, 6, 6)))
     snap = eng.snapshot(0)
     word = torch.zeros(1, dtype=torch.int32, device="cuda")

@@ -215,8 +215,8 @@ typedef struct ssa_step_params {
     uint32_t *fail_count;      /* device word: records appended so far (the caller zeroes it when it resets its episode); NULL with fail_log NULL */
     int32_t fail_cap;          /* capacity of fail_log in records (a record beyond it is counted but not written) */
     int32_t reserved1;
-    const int32_t *obj_ids;    /* [4 ceil(m / 4)] device words or NULL (one env, stat_shards given; ssa_env_step_f64 and ssa_env_rollout_f64:
-                                  ssa_env_closed_loop_f64 returns SSA_E_UNSUPPORTED with it).  A LAYOUT: the caller stores its objects in another order than it numbers them --
+    const int32_t *obj_ids;    /* [4 ceil(m / 4)] device words or NULL (one env; ssa_env_step_f64 with stat_shards, ssa_env_rollout_f64,
+                                  ssa_env_closed_loop_f64 together with ssa_closed_loop_params.slot_of).  A LAYOUT: the caller stores its objects in another order than it numbers them --
                                   position i of every array of this struct holds the object the caller calls obj_ids[i] (round 4: objects of one orbit
                                   regime share wavefronts; late in an episode the diverged filters are the LEO objects, and packed they cost the launch
                                   10 % less: DESIGN.md section 6).  The kernel then speaks the CALLER's indices wherever an index leaves it or enters it:
@@ -396,6 +396,13 @@ int ssa_agent_select_f64(const ssa_consts *c_host, int32_t kind, const double *x
                          const double *P_cur, const double *P_prev, const double *trans, const int32_t *env_time,
                          int32_t time_offset, int32_t n_time, const int32_t *fallback, void *workspace,
                          int32_t *action_out, int64_t *pick_out, int64_t n_obj, int32_t n_env, void *stream);
+/* the same with a storage layout (ssa_step_params.obj_ids, one env): the state tensors are in storage order, the action word and the pick
+ * name the object as the CALLER numbers it, and the first maximum is the candidate with the lowest such index.  obj_ids NULL: identical to
+ * ssa_agent_select_f64. */
+int ssa_agent_select_ids_f64(const ssa_consts *c_host, int32_t kind, const double *x_true, const double *x_cur,
+                             const double *P_cur, const double *P_prev, const double *trans, const int32_t *env_time,
+                             int32_t time_offset, int32_t n_time, const int32_t *fallback, void *workspace,
+                             int32_t *action_out, int64_t *pick_out, int64_t n_obj, int32_t n_env, const int32_t *obj_ids, void *stream);
 int64_t ssa_agent_select_workspace_bytes(int64_t n_obj, int32_t n_env);
 
 /* ------------------------------------------------ consistency diagnostics
@@ -446,6 +453,10 @@ typedef struct ssa_closed_loop_params {
                                   that waits longer for a decision publishes the abort generation, every wavefront leaves, `error` is set */
     uint32_t flags;            /* SSA_LOOP_* */
     uint32_t reserved;
+    const int32_t *slot_of;    /* with ssa_step_params.obj_ids (a storage layout): [m] device words, slot_of[j] = the position at which the object the
+                                  caller calls j is stored (the inverse of obj_ids) -- the wavefronts agree through it on whose tile holds the selected
+                                  object; NULL without a layout.  Actions, picks, failure records and the arg-max of sigma_pos speak the caller's
+                                  indices (first maximum = the lowest such index), as in the per-step launches */
 } ssa_closed_loop_params;
 #define SSA_LOOP_ARGMAX_SPOS 1u   /* stats_out[k][SSA_STAT_ARGMAX_SPOS / SSA_STAT_MAX_SPOS] = np.argmax / np.max of sigma_pos after step k (the
                                      'shaped' reward): two more words per wavefront in the exchange */

@@ -55,7 +55,7 @@ class ssa_closed_loop_params(C.Structure):
         ("x_true_ring", c_dp), ("x_ring", c_dp), ("P_ring", c_dp), ("obs_ring", c_dp), ("metrics_ring", c_dp),
         ("upd_out", c_dp), ("stats_out", c_dp), ("actions", c_dp), ("fallback", c_dp), ("picks", c_dp), ("error", c_dp),
         ("workspace", c_dp), ("workspace_bytes", C.c_int64),
-        ("wait_ticks", C.c_int64), ("flags", C.c_uint32), ("reserved", C.c_uint32),
+        ("wait_ticks", C.c_int64), ("flags", C.c_uint32), ("reserved", C.c_uint32), ("slot_of", c_dp),
     ]
 
 
@@ -118,6 +118,8 @@ SIGNATURES = {
     "ssa_aer_obs_f64": (C.c_int, [c_dp, c_dp, c_dp, C.POINTER(ssa_consts), c_dp, C.c_int64, c_dp]),
     "ssa_agent_select_f64": (C.c_int, [C.POINTER(ssa_consts), C.c_int32, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int32, C.c_int32,
                                        c_dp, c_dp, c_dp, c_dp, C.c_int64, C.c_int32, c_dp]),
+    "ssa_agent_select_ids_f64": (C.c_int, [C.POINTER(ssa_consts), C.c_int32, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int32, C.c_int32,
+                                           c_dp, c_dp, c_dp, c_dp, C.c_int64, C.c_int32, c_dp, c_dp]),
     "ssa_agent_select_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
     "ssa_nees_f64": (C.c_int, [c_dp, c_dp, c_dp, c_dp, C.c_int64, c_dp]),
     "ssa_nis_f64": (C.c_int, [c_dp, c_dp, c_dp, C.c_int64, c_dp]),

@@ -1112,7 +1112,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     // ssa_step_params.obj_ids (one env, the per-step kernels): the objects are stored in another order than the caller numbers them; the
     // action, the failure records, the arg-max of sigma_pos and the host-facing observation rows speak the CALLER's indices
     int64_t jid = j;
-    if (!ACT::late && p.obj_ids) {
+    if (p.obj_ids) {
         // (the tile's four indices by ONE wave-uniform 16-byte load -- scalar memory: it does not queue behind the tile's vector loads, which a
         // per-lane load would, and the update's input prefetch below hangs on `my_update`; the table is padded to whole tiles)
         const int4 ids = *reinterpret_cast<const int4*>(p.obj_ids + base);
@@ -1130,7 +1130,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     double upd_in = 0.0;
     if (may_update && l < 12) {
         tmod = time_row(tix, p.n_time);
-        const int64_t aobj = ACT::late ? j : (int64_t)act;
+        const int64_t aobj = ACT::late ? jid : (int64_t)act;   // (the measurement noise is indexed as the caller numbers the objects)
         const double* src = (l < 9) ? p.trans + (int64_t)tmod * 9 + l
                                     : p.z_noise + (int64_t)e * p.zn_stride_env + (int64_t)tmod * p.zn_stride_time + aobj * p.zn_stride_obj + (l - 9);
         upd_in = *src;
@@ -1339,7 +1339,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     if (ACT::late) {   // the closed loop's decision for this step: needed from here on, and normally made long ago
         asrc.before_wait(t, lane, cnt);
         act = asrc.get();
-        my_update = valid && act >= 0 && (int64_t)act == obj && interval_ok;   // (one env: the object index IS the index in the env)
+        my_update = valid && act >= 0 && (int64_t)act == (p.obj_ids ? (int64_t)t.Oid[g] : obj) && interval_ok;   // (one env: the object index IS the index in the env)
         if (__any(my_update)) __builtin_amdgcn_s_setprio(3);
     }
     if (__any(my_update)) {   // whole-wave branch: a wavefront without a selected object skips the block, its variables included
@@ -1588,7 +1588,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
             if ((int)at < p.fail_cap) {
                 double* rec = p.fail_log + (int64_t)at * SSA_FAIL_STRIDE;
                 rec[SSA_FAIL_ENV] = (double)e;
-                rec[SSA_FAIL_OBJ] = (!ACT::late && p.obj_ids) ? (double)t.Oid[g] : (double)(obj - (int64_t)e * p.n_obj);
+                rec[SSA_FAIL_OBJ] = p.obj_ids ? (double)t.Oid[g] : (double)(obj - (int64_t)e * p.n_obj);
                 rec[SSA_FAIL_STATUS] = (double)st_new;
                 rec[SSA_FAIL_TIME] = (double)((ACT::late ? p.env_time[0] : env_time_of<INL>(p, e)) + p.time_offset);
                 rec[SSA_FAIL_ERR + 0] = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
@@ -1612,7 +1612,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     // observation mode and the multi-GPU all-gather payload -- from the tiles, so that no second pass over x / P (the
     // former post kernel: 6.7 MB re-read per 20 000 objects plus a launch) is needed
     if (p.aer_out && p.stat_shards) {
-        if (l < 4 && valid) aer_obs_tile<INL>(t, p, C, g, l, e, (!ACT::late && p.obj_ids) ? (int64_t)t.Oid[g] : obj);
+        if (l < 4 && valid) aer_obs_tile<INL>(t, p, C, g, l, e, p.obj_ids ? (int64_t)t.Oid[g] : obj);
     }
     wave_lds_sync();
     SSA_TR(7);
@@ -2459,8 +2459,10 @@ __global__ void __launch_bounds__(AGENT_T) agent_partial_kernel(const double* __
                                                                 const double* __restrict__ Pc, const double* __restrict__ Pp,
                                                                 const double* __restrict__ trans, const int32_t* __restrict__ env_time,
                                                                 int32_t time_offset, int32_t n_time, GeoK g,
-                                                                AgentPart* __restrict__ parts, int64_t n)
+                                                                AgentPart* __restrict__ parts, int64_t n, const int32_t* __restrict__ ids)
 {
+    // (ids: a storage layout's table -- ssa_step_params.obj_ids -- or NULL: the candidate is named as the CALLER numbers it, and the first
+    // maximum is the one with the lowest such index)
     const int e = blockIdx.y, t = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * AGENT_T + t;
     double best = 0.0;
@@ -2474,7 +2476,7 @@ __global__ void __launch_bounds__(AGENT_T) agent_partial_kernel(const double* __
         constexpr int WANT = (ROW == 0 ? 1 : ROW == 1 ? 2 : 12) | (KIND == SSA_AGENT_NAIVE_GREEDY ? 0 : 16);
         const bool vis = agent_score_rows<WANT>(xt, x, Pc, Pp, M, g, obj, sc);
         const double v = sc[ROW];
-        if (vis && v == v) { best = v; arg = i; }
+        if (vis && v == v) { best = v; arg = ids ? (long long)ids[i] : (long long)i; }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -2653,7 +2655,12 @@ SSA_DEV void closed_loop_prescore(ActLate& a, Tiles& t, int lane, int cnt)
 // have): it hands it to the deciding wavefront DIRECTLY instead of through its group's fold -- one exchange level less on the
 // path decision -> update -> decision.  Who that is follows from the action alone, so everybody agrees on it: the tile of the
 // selected object, or tile 0 when the action selects nobody.
-SSA_DEV int closer_tile(int act, int64_t total) { return (act >= 0 && (int64_t)act < total) ? (act >> 2) : 0; }
+// (slot_of: with a storage layout -- ssa_step_params.obj_ids -- the position of the object the caller calls `act`; NULL: the identity)
+SSA_DEV int closer_tile(int act, int64_t total, const int32_t* __restrict__ slot_of = nullptr)
+{
+    if (!(act >= 0 && (int64_t)act < total)) return 0;
+    return (slot_of ? slot_of[act] : act) >> 2;
+}
 SSA_DEV int block_of_tile(int tile, int n)   // inverse of xcd_tile()
 {
     const int q = n >> 3, r = n & 7;
@@ -2744,7 +2751,7 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) closed_loop_kernel(const L
                 __builtin_amdgcn_s_setprio(0);
                 const int act = asrc.get();
                 if (asrc.aborted) return;
-                const int cw = block_of_tile(closer_tile(act, total), nwork);
+                const int cw = block_of_tile(closer_tile(act, total, a.c.slot_of), nwork);
                 target += (unsigned long long)(gsize - ((cw >> 6) == G ? 1 : 0));
                 if (!cl_service_wait(ws + L.gcount + (int64_t)G * 16, target, asrc)) return;
                 const int q = kk & 1;
@@ -2884,7 +2891,7 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) closed_loop_kernel(const L
         process_wave<PROP, 2>(t, k.c, pk, lane, base + (lane >> 4), (lane >> 4) < cnt, base, cnt, pf, 0, 0, tile, asrc);
         wave_lds_sync();
         if (asrc.aborted) return;
-        boost = tile == closer_tile(asrc.last, total);           // the update ran here (or would have)
+        boost = tile == closer_tile(asrc.last, total, r.slot_of);           // the update ran here (or would have)
 #ifdef SSA_CL_TRACE
         if (trc) { trp[1] = asrc.t_wait; trp[2] = asrc.t_seen; }
         if (boost) SSA_CLF(1ull);
@@ -2922,11 +2929,12 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) closed_loop_kernel(const L
                         case SSA_AGENT_POS_ERROR: agent_score_core<12>(xt, x, A, 0.0, nullptr, geo, sc, nullptr); v = sc[2]; break;
                         default: agent_score_core<12>(xt, x, A, 0.0, nullptr, geo, sc, nullptr); v = sc[3]; break;
                     }
-                    if (vis && v == v) { me.best = v; me.arg = base + g; }
+                    const long long gid = k.p.obj_ids ? (long long)t.Oid[g] : (long long)(base + g);
+                    if (vis && v == v) { me.best = v; me.arg = gid; }
                     const double dp = t.Met[g * 4 + 0];
                     me.mx = (unsigned long long)__double_as_longlong(dp) & 0x7fffffffffffffffull;   // (ordered bits; NaN on top: np.max)
                     me.cnt = (unsigned long long)(dp < 1e4) | ((unsigned long long)(dp < 1e7) << 21) | ((unsigned long long)(t.St[g] != 0) << 42);
-                    if (wide) { me.skey = spos_key(t.Met[g * 4 + 2]); me.sarg = (unsigned long long)(base + g); }
+                    if (wide) { me.skey = spos_key(t.Met[g * 4 + 2]); me.sarg = (unsigned long long)gid; }
                 }
                 rowpart[g] = me;
             }
@@ -2942,7 +2950,7 @@ __global__ void __launch_bounds__(64, SSA_STEP_WAVES) closed_loop_kernel(const L
             cl_merge(me, rowpart[1]);
             cl_merge(me, rowpart[2]);
             cl_merge(me, rowpart[3]);
-            const bool closer = tile == closer_tile(asrc.last, total);
+            const bool closer = tile == closer_tile(asrc.last, total, r.slot_of);
             cl_store(closer ? ws + L.cparts + (int64_t)(kk & 1) * CL_PART_WORDS : ws + L.parts + ((int64_t)(kk & 1) * nwork + w) * CL_PART_WORDS, me, wide);
             cl_stores_done();
             __hip_atomic_fetch_add(closer ? ws + L.fcount : ws + L.gcount + (int64_t)G * 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (nobody waits for it here)
@@ -3471,7 +3479,8 @@ int ssa_env_closed_loop_f64(const ssa_consts* c, const ssa_step_params* p, const
     if (c->obs_type != SSA_OBS_AER && c->obs_type != SSA_OBS_XYZ) return SSA_E_INVALID;
     if (c->propagator != SSA_PROP_FG && c->propagator != SSA_PROP_ELEMENTS && c->propagator != SSA_PROP_J2_RK4 && c->propagator != SSA_PROP_HYBRID) return SSA_E_INVALID;
     if (c->propagator == SSA_PROP_J2_RK4 && (c->rk4_substeps < 1 || c->rk4_substeps > 4096)) return SSA_E_INVALID;
-    if (p->n_env != 1 || p->obj_ids) return SSA_E_UNSUPPORTED;     // (a layout table belongs to the per-step launches)
+    if (p->n_env != 1) return SSA_E_UNSUPPORTED;
+    if ((p->obj_ids != nullptr) != (r->slot_of != nullptr)) return SSA_E_INVALID;     // (a storage layout comes with its inverse table)
     const int64_t ntiles = (p->n_obj + OBJ_PER_WAVE - 1) / OBJ_PER_WAVE;
     const int64_t cap = closed_loop_capacity(c->propagator);
     const ClLayout L = cl_layout((int)ntiles);
@@ -3726,15 +3735,24 @@ int ssa_agent_select_f64(const ssa_consts* c, int32_t kind, const double* x_true
                          const int32_t* fallback, void* workspace, int32_t* action_out, int64_t* pick_out, int64_t n_obj,
                          int32_t n_env, void* stream)
 {
+    return ssa_agent_select_ids_f64(c, kind, x_true, x_cur, P_cur, P_prev, trans, env_time, time_offset, n_time, fallback, workspace, action_out,
+                                    pick_out, n_obj, n_env, nullptr, stream);
+}
+int ssa_agent_select_ids_f64(const ssa_consts* c, int32_t kind, const double* x_true, const double* x_cur, const double* P_cur,
+                             const double* P_prev, const double* trans, const int32_t* env_time, int32_t time_offset, int32_t n_time,
+                             const int32_t* fallback, void* workspace, int32_t* action_out, int64_t* pick_out, int64_t n_obj,
+                             int32_t n_env, const int32_t* obj_ids, void* stream)
+{
     if (!c || !x_true || !x_cur || !P_cur || !trans || !env_time || !workspace || !action_out || n_obj <= 0 || n_env <= 0)
         return SSA_E_INVALID;
+    if (obj_ids && n_env != 1) return SSA_E_UNSUPPORTED;
     const int nparts = (int)((n_obj + AGENT_T - 1) / AGENT_T);
     const dim3 grid(nparts, n_env), block(AGENT_T);
     hipStream_t s = (hipStream_t)stream;
     AgentPart* parts = (AgentPart*)workspace;
     const GeoK g = make_geo(c);
 #define SSA_AGENT_LAUNCH(K) hipLaunchKernelGGL(agent_partial_kernel<K>, grid, block, 0, s, x_true, x_cur, P_cur, P_prev, trans, env_time, \
-                                               time_offset, n_time, g, parts, n_obj)
+                                               time_offset, n_time, g, parts, n_obj, obj_ids)
     switch (kind) {
         case SSA_AGENT_NAIVE_GREEDY: SSA_AGENT_LAUNCH(SSA_AGENT_NAIVE_GREEDY); break;
         case SSA_AGENT_VISIBLE_GREEDY: SSA_AGENT_LAUNCH(SSA_AGENT_VISIBLE_GREEDY); break;

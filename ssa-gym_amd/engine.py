@@ -119,8 +119,8 @@ class HotPathEngine:
         late in an episode the diverged filters are the LEO objects, and packed they cost a launch 10 % less.
         The per-step launches speak the caller's indices wherever an index enters or leaves (actions, failure records, arg-max of sigma_pos,
         the host-facing observation rows: include/ssa_hip.h); the state tensors of this engine (x_true, x_filter, P_filter, obs, metrics,
-        status) are in STORAGE order while a layout is set -- `to_caller_order()` puts them back (the closed-loop launch does that itself; the
-        rollout keeps the layout).  Call before load_state(); the state present is not moved."""
+        status) are in STORAGE order while a layout is set -- `to_caller_order()` puts them back (the rollout and closed-loop launches keep the
+        layout).  Call before load_state(); the state present is not moved."""
         if order is None and self._order is None:
             return
         self._order = None
@@ -139,6 +139,7 @@ class HotPathEngine:
         self._obj_ids = torch.as_tensor(ids).to(self.dev)
         self._order_idx = torch.as_tensor(order).to(self.dev)                     # storage position -> caller's index
         self._slot_of = torch.as_tensor(np.argsort(order)).to(self.dev)           # caller's index -> storage position
+        self._slot_of32 = self._slot_of.to(torch.int32)                           # (the closed loop's inverse table: ssa_closed_loop_params.slot_of)
         self._p.obj_ids = self._obj_ids.data_ptr()
 
     def _reorder(self, idx, slots):
@@ -366,7 +367,6 @@ class HotPathEngine:
         the give-up path)."""
         if self.E != 1:
             return False
-        self.to_caller_order()           # (a storage layout belongs to the per-step launches)
         K = int(actions.numel()) - 1
         if K < 1:
             raise _lib.SsaHipError("closed loop: actions must hold K + 1 >= 2 words")
@@ -399,6 +399,7 @@ class HotPathEngine:
         r.workspace, r.workspace_bytes = self._loop_ws.data_ptr(), self._loop_ws.numel() * 8
         r.wait_ticks = int(wait_ticks)
         r.flags = (_lib.LOOP_ARGMAX_SPOS if argmax_spos else 0) | (_lib.LOOP_DEBUG_WITHHOLD if debug_withhold else 0)
+        r.slot_of = self._slot_of32.data_ptr() if self._order is not None else 0     # (a storage layout: its inverse table)
         p = self._p
         p.time_offset = int(time_offset)
         p.launch_mask, p.stat_shards_prev, p.stats_prev, p.aer_out = 0, 0, 0, 0
@@ -420,10 +421,12 @@ class HotPathEngine:
         s = torch.cuda.current_stream().cuda_stream if stream is None else stream
         sc = int(slot_cur) % self.H
         sp = (sc + self.H - 1) % self.H
-        rc = self._lib.ssa_agent_select_f64(self._cref, int(kind), self._bx_t + sc * self._sx, self._bx + sc * self._sx,
-                                            self._bP + sc * self._sP, (self._bP + sp * self._sP) if have_prev else 0, self.trans.data_ptr(),
-                                            self.env_time0.data_ptr(), int(time_offset), self.n_time, fallback_ptr,
-                                            self._agent_ws.data_ptr(), action_ptr, pick_ptr, self.m, self.E, s)
+        # (with a storage layout the candidates are named as the caller numbers them: ssa_agent_select_ids_f64)
+        rc = self._lib.ssa_agent_select_ids_f64(self._cref, int(kind), self._bx_t + sc * self._sx, self._bx + sc * self._sx,
+                                                self._bP + sc * self._sP, (self._bP + sp * self._sP) if have_prev else 0, self.trans.data_ptr(),
+                                                self.env_time0.data_ptr(), int(time_offset), self.n_time, fallback_ptr,
+                                                self._agent_ws.data_ptr(), action_ptr, pick_ptr, self.m, self.E,
+                                                self._obj_ids.data_ptr() if self._order is not None else 0, s)
         if rc:
             raise _lib.SsaHipError("ssa_agent_select_f64 failed with code %d" % rc)
 

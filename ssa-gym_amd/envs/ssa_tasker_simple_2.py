@@ -346,8 +346,8 @@ class SSA_Tasker_Env(Env):
         # step kernel speaks the env's own indices wherever an index enters or leaves it (actions, failure records, arg-max of sigma_pos, the
         # observation rows it writes for the host), an object's arithmetic does not depend on its position (bit-identical episodes,
         # build_ablate/layout_episode_ab.py), and whatever reads the device state as the env numbers it -- the history arrays, the device-side
-        # agents and policies, rollout / closed loop -- puts the state back first (_caller_order(): the layout is then off until the next
-        # reset()).  OFF by default HERE: what step() gains in the kernel (2-5 us late in an episode) it loses on the way to the host -- the
+        # agents' scores and policies' views, rollout -- puts the state back first (_caller_order(): the layout is then off until the next
+        # reset(); run_agent keeps it: its kernels take the table).  OFF by default HERE: what step() gains in the kernel (2-5 us late in an episode) it loses on the way to the host -- the
         # observation rows leave the kernel row by row at the env's indices instead of tile by tile (1.9 MB over PCIe in 96-byte pieces: 'flatten'
         # 73 -> 84 us per step at 20 000 objects).  It pays for launch sequences that keep the observations on the device: the engine-level
         # loops (HotPathEngine.set_layout; bench.py's `value`), C-ABI callers (ssa_step_params.obj_ids).
@@ -575,7 +575,6 @@ class SSA_Tasker_Env(Env):
         Every reward type.  If the persistent launch gives up (a wavefront waited longer than config['closed_loop_wait_ticks'] for a
         decision: something else holds the GPU's wavefront slots) the env restores the state the chunk started from, takes the
         per-step launches for this and every later call, and warns once."""
-        self._caller_order()          # (the agents' kernels and the persistent launch read the state as the env numbers it)
         import torch
         name = agent if isinstance(agent, str) else getattr(agent, "__name__", None)
         if name not in self.AGENT_KINDS:
@@ -666,12 +665,12 @@ class SSA_Tasker_Env(Env):
             from .. import device
             M = e.trans[self.i % e.n_time].reshape(3, 3)
             device.aer_obs(e.x_filter[slot], e.P_filter[slot], M, self._consts, out=self._aer_dev.view(self.m, 4))
-            self.observation[:] = self._aer_dev.cpu().numpy()
+            self.observation[:] = e.caller_rows(self._aer_dev.view(self.m, 4)).cpu().numpy().reshape(-1)     # (a storage layout is kept here)
             obs = self.observation
         elif self.obs_returned == 'flatten':
-            obs = e.obs[slot].cpu().numpy().reshape(-1)
+            obs = e.caller_rows(e.obs[slot]).cpu().numpy().reshape(-1)
         else:
-            obs = e.obs[slot].cpu().numpy()
+            obs = e.caller_rows(e.obs[slot]).cpu().numpy()
         return obs, np.asarray(actions, dtype=int), np.asarray(rewards), np.asarray(dones, dtype=bool)
 
     # ------------------------------------------------------------------ closed loop with ANY policy that lives on the GPU

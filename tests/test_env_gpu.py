@@ -974,7 +974,15 @@ def test_storage_layout_is_invisible_through_the_gym_api(envs, mode, reward):
         for u, v in zip(ua, ub):
             u, v = np.asarray(u), np.asarray(v)
             assert np.array_equal(u, v, equal_nan=(u.dtype.kind == 'f')), entry
-        assert b._engine._order is None and a.i == b.i
+        # (run_agent keeps the layout: the agent kernels and the persistent closed-loop launch take the table; the others put the state back)
+        assert (b._engine._order is None) == (entry != "run_agent") and a.i == b.i
+        if entry == "run_agent":      # ... in both of its forms: the per-step launches too
+            a._closed_loop_persistent = b._closed_loop_persistent = False
+            ua, ub = a.run_agent('agent_shannon', 5), b.run_agent('agent_shannon', 5)
+            for u, v in zip(ua, ub):
+                u, v = np.asarray(u), np.asarray(v)
+                assert np.array_equal(u, v, equal_nan=(u.dtype.kind == 'f')), "run_agent, per-step launches"
+            assert b._engine._order is not None
         assert np.array_equal(np.asarray(a.x_filter[a.i]), np.asarray(b.x_filter[b.i]))
     with pytest.raises(ValueError):
         envs.make(config=dict(cfg, storage_layout='sorted'))
