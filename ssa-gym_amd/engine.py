@@ -157,7 +157,7 @@ class HotPathEngine:
 
     def to_caller_order(self):
         """put the state tensors back into the caller's order and drop the layout (asynchronous, in the current stream): for everything that
-        reads them as the caller numbers them -- device-side agents and policies, the rollout and closed-loop launches, inspection"""
+        reads them as the caller numbers them -- a policy's views of the state, the operator entry points, inspection"""
         if self._order is None:
             return
         self.flush_stats()
