@@ -338,14 +338,14 @@ def closed_loop_rate(m, K, W, seed=100, persistent=True, chunk=120, agent=None, 
                     "closed loop on the device: step launch + ssa_agent_select_f64 (2 launches) per step, no host round trip"}
 
 
-def gym_api_rate(m, mode, n=200, obs_device=False, zero_copy=False, obs_pool=64):
+def gym_api_rate(m, mode, n=200, obs_device=False, zero_copy=False, obs_pool=64, f32=False):
     """env.step() through the gym API (host in the loop: action in, launch, one sync, statistics + observation out over
     PCIe): the closed-loop rate an unmodified agents.py / RLlib worker sees.  Never `value`.  zero_copy: config['obs_zero_copy'] --
     step() hands out a view of the host-mapped ring instead of a fresh copy (the default, as the reference)."""
     from ssa_gym_amd.envs import env_config, make
     cfg = dict(env_config)
     cfg.update(rso_count=m, steps=480, reward_type='trinary', obs_returned=mode, seed=0, history=2, device_rng=True, obs_device=obs_device,
-               obs_zero_copy=zero_copy, obs_pool=obs_pool)
+               obs_zero_copy=zero_copy, obs_pool=obs_pool, obs_dtype=np.float32 if f32 else np.float64)
     env = make(config=cfg)
     for k in range(20):
         env.step(k % m)
@@ -362,7 +362,7 @@ def gym_api_rate(m, mode, n=200, obs_device=False, zero_copy=False, obs_pool=64)
     el, lo, hi, reps = timed_repeats(block, lambda: None, prepare=prepare)
     dt = el / n
     return {"value": round(1.0 / dt * (m / 20000.0), 2), "ms_per_step": round(1e3 * dt, 5), **spread(n, m / 20000.0, el, lo, hi, reps),
-            "obs_bytes_per_step": 0 if obs_device else m * (12 if mode == 'flatten' else 4) * 8}
+            "obs_bytes_per_step": 0 if obs_device else m * (12 if mode == 'flatten' else 4) * (4 if f32 else 8)}
 
 
 def torch_policy_rate(m, n=192):
@@ -435,7 +435,7 @@ def torch_policy_rate(m, n=192):
                     "advances on the device; the host books chunk c while the GPU runs chunk c + 1" % (n, n // 32)}
 
 
-def vec_env_rate(m, E=8, n=60, obs_device=False, zero_copy=False):
+def vec_env_rate(m, E=8, n=60, obs_device=False, zero_copy=False, f32=False):
     """BASELINE config 5's per-GPU load through the vector-env API: E envs of m objects advanced by ONE launch per
     SSA_Tasker_VecEnv.step() (per-env actions and time indices, auto-reset), host in the loop, the E 'aer' observation
     vectors returned over PCIe.  Reported in 20 000-object env-steps per second (E per call).  Never `value`."""
@@ -443,7 +443,7 @@ def vec_env_rate(m, E=8, n=60, obs_device=False, zero_copy=False):
     from ssa_gym_amd.envs.vector_env import SSA_Tasker_VecEnv
     cfg = dict(env_config)
     cfg.update(rso_count=m, steps=480, reward_type='trinary', obs_returned='aer', seed=0, device_rng=True, obs_device=obs_device,
-               obs_zero_copy=zero_copy)
+               obs_zero_copy=zero_copy, obs_dtype=np.float32 if f32 else np.float64)
     env = SSA_Tasker_VecEnv(cfg, num_envs=E, seed=0)
     acts = lambda k: [(k * 7 + 13 * e) % m for e in range(E)]    # noqa: E731
     for k in range(10):
@@ -466,7 +466,7 @@ def vec_env_rate(m, E=8, n=60, obs_device=False, zero_copy=False):
     dt = el / n
     return {"value": round(E / dt * (m / 20000.0), 2), "ms_per_vector_step": round(1e3 * dt, 5), "envs": E,
             **spread(n, E * m / 20000.0, el, lo, hi, reps),
-            "obs_bytes_per_step": 0 if obs_device else E * m * 4 * 8,
+            "obs_bytes_per_step": 0 if obs_device else E * m * 4 * (4 if f32 else 8),
             "note": ("SSA_Tasker_VecEnv.step() with config['obs_device']: %d envs x %d objects per launch, host in the loop; the observations stay "
                      "on the GPU (CUDA tensor returned, for policies that live there), rewards / dones cross PCIe" % (E, m)) if obs_device else
                     "SSA_Tasker_VecEnv.step(): %d envs x %d objects per launch, host in the loop, PCIe inclusive" % (E, m)}
@@ -900,11 +900,14 @@ def main():
         legs["gym_api"] = {"flatten": gym_api_rate(m, 'flatten'), "aer": gym_api_rate(m, 'aer'),
                            "flatten_zero_copy": gym_api_rate(m, 'flatten', zero_copy=True),
                            "flatten_copy": gym_api_rate(m, 'flatten', obs_pool=0),
+                           "flatten_f32": gym_api_rate(m, 'flatten', f32=True), "aer_f32": gym_api_rate(m, 'aer', f32=True),
                            "flatten_device_obs": gym_api_rate(m, 'flatten', obs_device=True),
                            "note": "SSA_Tasker_Env.step() per call, host in the loop, PCIe + one sync inclusive (20 000 objects).  flatten: the default "
                                    "-- a FRESH observation array per step, as the reference, WITHOUT a copy: a pinned buffer nobody holds, written by the "
                                    "kernel, taken back when the consumer drops the array (envs/_obspool.py); flatten_copy: what a consumer that keeps more "
                                    "than config['obs_pool'] = 64 observations alive gets (a 1.92 MB host copy per step; obs_pool = 0 here); "
+                                   "flatten_f32 / aer_f32: config['obs_dtype'] = float32 (EXTENSION: the reference's observations are float64) -- the kernel "
+                                   "writes the host-facing copy in single precision, half the bytes over PCIe; "
                                    "flatten_zero_copy: config['obs_zero_copy'] "
                                    "-- a view of the two-deep host-mapped ring the kernel writes; aer: the reference's one persistent array; "
                                    "flatten_device_obs: config['obs_device'] -- the observation stays on the GPU as a CUDA tensor (a policy that "
@@ -913,6 +916,8 @@ def main():
         if m == 20000:
             legs["vec_env"] = vec_env_rate(m)
             legs["vec_env_zero_copy"] = vec_env_rate(m, zero_copy=True)
+            legs["vec_env_f32"] = vec_env_rate(m, f32=True)
+            legs["vec_env_f32"]["note"] += "; config['obs_dtype'] = float32 (EXTENSION): 2.56 MB of observations per vector step instead of 5.12"
             legs["vec_env_device_obs"] = vec_env_rate(m, obs_device=True)
 
     cpu, cpu_all, ep_fail = None, None, None

@@ -256,6 +256,10 @@ int ssa_env_step_f64(const ssa_consts *c_host, const ssa_step_params *p_host, vo
                                         statistics available when it completes -- for callers that read them on the host after every step.
                                         Launches with more than one tile per wavefront (> 20 480 objects in all) get the fold kernel behind
                                         the step instead: counting a tile costs such a wavefront a memory round trip per tile */
+#define SSA_LAUNCH_MIRROR_F32 128u    /* EXTENSION (round 4; the reference's observations are float64): the HOST-FACING copies of the observation -- obs_mirror
+                                         rows and, on the one-launch statistics path, aer_out rows -- are written in SINGLE precision (obs_mirror / aer_out
+                                         then point at float arrays of the same shape): half the bytes over PCIe for consumers that cast to float32
+                                         anyway (every RL framework does).  `obs` (the device-resident rows) stays double. */
 #define SSA_LAUNCH_INLINE_ENVS 64u   /* time indices and actions of all envs are ssa_step_params.inline_time / inline_action (n_env <= 8);
                                         time_offset is still added */
 int ssa_env_step_profiled_f64(const ssa_consts *c_host, const ssa_step_params *p_host, void *stream, int32_t slot);

@@ -75,6 +75,7 @@ LAUNCH_DEFER_FOLD = 8
 LAUNCH_INLINE_ACTION = 16
 LAUNCH_FOLD_INSIDE = 32
 LAUNCH_INLINE_ENVS = 64
+LAUNCH_MIRROR_F32 = 128
 INLINE_ENVS = 8
 LOOP_ARGMAX_SPOS, LOOP_DEBUG_WITHHOLD = 1, 2
 FAIL_STRIDE, FAIL_ENV, FAIL_OBJ, FAIL_STATUS, FAIL_TIME, FAIL_ERR = 8, 0, 1, 2, 3, 4

@@ -247,8 +247,10 @@ SSA_DEV void store_tile(const Tiles& t, const ssa_step_params& p, int lane, int6
             if (NT) __builtin_nontemporal_store(pair, reinterpret_cast<v2d*>(dst));
             else *reinterpret_cast<v2d*>(dst) = pair;
             if (p.obs_mirror) {   // (e.g. host-mapped memory; with obj_ids: row by row at the caller's index of the object)
-                if (p.obj_ids) *reinterpret_cast<v2d*>(p.obs_mirror + (int64_t)t.Oid[jj] * 12 + r) = pair;
-                else *reinterpret_cast<v2d*>(p.obs_mirror + base * 12 - 64 + 2 * lane) = pair;
+                const int64_t at = p.obj_ids ? (int64_t)t.Oid[jj] * 12 + r : base * 12 - 64 + 2 * lane;      // (in observation entries)
+                if (p.launch_mask & SSA_LAUNCH_MIRROR_F32)      // the host-facing copy in single precision: half the bytes over PCIe
+                    *reinterpret_cast<float2*>(reinterpret_cast<float*>(p.obs_mirror) + at) = make_float2((float)pair.x, (float)pair.y);
+                else *reinterpret_cast<v2d*>(p.obs_mirror + at) = pair;
             }
         }
         if (!SSA_SKIP(16) && lane >= 56 && lane < 60) p.status[base - 56 + lane] = t.St[lane - 56];
@@ -276,10 +278,11 @@ SSA_DEV void store_tile(const Tiles& t, const ssa_step_params& p, int lane, int6
         const bool skip = sO ? SSA_SKIP(2) : sP ? SSA_SKIP(1) : SSA_SKIP(4);
         if (!skip && i < lim) store16<NT>(dst + 2 * i, src + 2 * i);
         if (sO && p.obs_mirror && i < lim) {
-            if (p.obj_ids) {
-                const int jj = (i * 43) >> 8;     // i / 6: the object (rows beyond cnt are masked by `lim`)
-                store16<false>(p.obs_mirror + (int64_t)t.Oid[jj] * 12 + (2 * i - 12 * jj), src + 2 * i);
-            } else store16<false>(p.obs_mirror + base * 12 + 2 * i, src + 2 * i);
+            const int jj = (i * 43) >> 8;     // i / 6: the object (rows beyond cnt are masked by `lim`)
+            const int64_t at = p.obj_ids ? (int64_t)t.Oid[jj] * 12 + (2 * i - 12 * jj) : base * 12 + 2 * i;
+            if (p.launch_mask & SSA_LAUNCH_MIRROR_F32)
+                *reinterpret_cast<float2*>(reinterpret_cast<float*>(p.obs_mirror) + at) = make_float2((float)src[2 * i], (float)src[2 * i + 1]);
+            else store16<false>(p.obs_mirror + at, src + 2 * i);
         }
     }
     if (!SSA_SKIP(16) && lane >= 12 && lane < 16) {
@@ -790,7 +793,9 @@ SSA_DEV void aer_obs_tile_at(const Tiles& t, const ssa_step_params& p, const ssa
     if (l == 0 && a < 0.0) a += TWO_PI;
     const double tr = P[0] + P[7] + P[14] + P[21] + P[28] + P[35];
     const double v = (l < 2) ? a : (l == 2) ? rt : tr;
-    p.aer_out[obj * 4 + l] = (fabs(v) <= 1.79769313486231570e308) ? v : 0.001;
+    const double w = (fabs(v) <= 1.79769313486231570e308) ? v : 0.001;
+    if (p.launch_mask & SSA_LAUNCH_MIRROR_F32) reinterpret_cast<float*>(p.aer_out)[obj * 4 + l] = (float)w;
+    else p.aer_out[obj * 4 + l] = w;
 }
 template <bool INL>
 SSA_DEV void aer_obs_tile(const Tiles& t, const ssa_step_params& p, const ssa_consts& C, int g, int l, int e, int64_t obj)
@@ -799,7 +804,9 @@ SSA_DEV void aer_obs_tile(const Tiles& t, const ssa_step_params& p, const ssa_co
         if (l == 0) {
             const double* P = &t.P[g * 36];
             const double tr = P[0] + P[7] + P[14] + P[21] + P[28] + P[35];
-            p.aer_out[obj] = (fabs(tr) <= 1.79769313486231570e308) ? tr : 0.001;
+            const double w = (fabs(tr) <= 1.79769313486231570e308) ? tr : 0.001;
+            if (p.launch_mask & SSA_LAUNCH_MIRROR_F32) reinterpret_cast<float*>(p.aer_out)[obj] = (float)w;
+            else p.aer_out[obj] = w;
         }
         return;
     }
@@ -3323,6 +3330,7 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
         (!p->stat_shards || !p->stats || (p->launch_mask & SSA_LAUNCH_DEFER_FOLD))) return SSA_E_INVALID;
     if (p->spos_tiles && !p->stat_shards) return SSA_E_INVALID;
     if (p->fail_log && (!p->fail_count || p->fail_cap <= 0)) return SSA_E_INVALID;
+    if ((p->launch_mask & SSA_LAUNCH_MIRROR_F32) && !p->stat_shards) return SSA_E_UNSUPPORTED;   // (the post kernel writes aer_out in double)
     if (p->obj_ids && (p->n_env != 1 || !p->stat_shards)) return SSA_E_UNSUPPORTED;   // (one env; the statistics of the one-launch paths: the post
                                                                                         // kernel's arg-max would speak storage positions)
     if ((p->spos_tiles || p->spos_tiles_prev) && p->n_env > 1 && (p->n_obj % OBJ_PER_WAVE) != 0) return SSA_E_UNSUPPORTED;   // whole tiles per env

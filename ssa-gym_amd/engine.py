@@ -270,7 +270,7 @@ class HotPathEngine:
 
     def launch_step(self, slot_in, slot_out, time_offset, actions_ptr=None, stream=None, aer_out=0, stats_out=0, upd_out=0,
                     fast_stats=False, defer_fold=False, profile_slot=None, shards_out=0, shards_clear=0, aer_cols=4, action=None,
-                    obs_mirror=0, fold_inside=False, env_words=None, argmax_spos=False):
+                    obs_mirror=0, fold_inside=False, env_words=None, argmax_spos=False, mirror_f32=False):
         """enqueue the step; asynchronous, no host sync.  fast_stats: statistics by the step kernel's atomics (two
         launches, no arg-max of sigma_pos).  defer_fold (with fast_stats): ONE launch -- this step's
         statistics are folded by extra wavefronts of the NEXT deferred step, or by flush_stats().  action (one env): the
@@ -292,15 +292,15 @@ class HotPathEngine:
                                                shards_out, shards_clear, aer_cols, obs_mirror, argmax)
         p.time_offset = int(time_offset)
         p.actions = self._actions_ptr if actions_ptr is None else actions_ptr
-        inline = 0
+        inline = _lib.LAUNCH_MIRROR_F32 if mirror_f32 else 0      # (obs_mirror / aer_out are float arrays: the host-facing copy in single precision)
         if env_words is not None:
             if self.E > _lib.INLINE_ENVS:
                 raise _lib.SsaHipError("env_words: at most %d envs travel in the parameter block" % _lib.INLINE_ENVS)
             p.inline_time[:self.E] = env_words[0]
             p.inline_action[:self.E] = env_words[1]
-            inline = _lib.LAUNCH_INLINE_ENVS
+            inline |= _lib.LAUNCH_INLINE_ENVS
         elif action is not None:
-            p.action0, inline = int(action), _lib.LAUNCH_INLINE_ACTION
+            p.action0, inline = int(action), inline | _lib.LAUNCH_INLINE_ACTION
         if fold_inside and fast_stats and not defer and not shards_out:
             inline |= _lib.LAUNCH_FOLD_INSIDE      # (the step kernel's last wavefront folds the statistics: no fold launch)
         if defer and self._fold_pending is not None:

@@ -13,8 +13,10 @@ import numpy as np
 
 
 class ObsPool:
-    def __init__(self, n_doubles, shape, cap=64):
+    def __init__(self, n_doubles, shape, cap=64, dtype=np.float64):
         self.n, self.shape, self.cap = int(n_doubles), tuple(shape), int(cap)
+        self.dtype = np.dtype(dtype)         # float64 (the reference's), or float32 (config['obs_dtype']: the kernel writes the host copy in single)
+        self._ctype = ctypes.c_float if self.dtype == np.float32 else ctypes.c_double
         self._bufs, self._np, self.ptrs, self._free = [], [], [], []
         self.handed_out = 0            # (diagnostic: arrays given out / buffers ever allocated)
 
@@ -24,7 +26,7 @@ class ObsPool:
             return self._free.pop()
         if len(self._bufs) < self.cap:
             import torch
-            t = torch.zeros(self.n, dtype=torch.float64).pin_memory()
+            t = torch.zeros(self.n, dtype=torch.float32 if self.dtype == np.float32 else torch.float64).pin_memory()
             self._bufs.append(t)
             self._np.append(t.numpy())
             self.ptrs.append(t.data_ptr())
@@ -39,10 +41,10 @@ class ObsPool:
         array and every view of it have been dropped"""
         # (from_buffer, not from_address: the ctypes object then OWNS a reference to the pinned tensor's array -- an observation a consumer still
         # holds keeps its memory alive even when the env that handed it out is gone)
-        c = (ctypes.c_double * self.n).from_buffer(self._np[k])
+        c = (self._ctype * self.n).from_buffer(self._np[k])
         weakref.finalize(c, self._free.append, k)
         self.handed_out += 1
-        return np.frombuffer(c, dtype=np.float64).reshape(self.shape)
+        return np.frombuffer(c, dtype=self.dtype).reshape(self.shape)
 
     def __len__(self):
         return len(self._bufs)

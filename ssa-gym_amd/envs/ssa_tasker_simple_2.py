@@ -230,7 +230,13 @@ class SSA_Tasker_Env(Env):
             self.observation = np.zeros(self.m * 4)
         else:
             shp = (self.m, 12)
-        self.observation_space = spaces.Box(low=np.full(shp, -np.inf), high=np.full(shp, np.inf), dtype=np.float64)
+        # config['obs_dtype'] = 'float64' (default, the reference's) | 'float32' (EXTENSION): the observation handed to the host in single
+        # precision -- the step kernel writes its host-facing copy that way (SSA_LAUNCH_MIRROR_F32): half the bytes over PCIe, for consumers
+        # that cast to float32 anyway (every RL framework does).  The device-resident history and everything computed stay float64.
+        self._obs_f32 = np.dtype(config.get('obs_dtype', np.float64)) == np.float32
+        if np.dtype(config.get('obs_dtype', np.float64)) not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise ValueError("config['obs_dtype'] must be float64 or float32")
+        self.observation_space = spaces.Box(low=np.full(shp, -np.inf), high=np.full(shp, np.inf), dtype=np.float32 if self._obs_f32 else np.float64)
         # ---- device engine
         hist = config.get('history', 'auto')
         bytes_per_step = self.m * (6 + 6 + 36 + 12 + 4) * 8
@@ -292,7 +298,9 @@ class SSA_Tasker_Env(Env):
         aer = self.obs_returned == 'aer'
         nobs = self.m * (4 if aer else 12)
         nbuf = 1 if aer else max(2, int(self._obs_buffers))
-        self._obs_ring = [torch.zeros(nobs, dtype=torch.float64).pin_memory() for _ in range(nbuf)]
+        f32 = self._obs_f32 and not self._obs_device        # (obs_device hands out the float64 device tensors themselves)
+        self._mirror_f32 = f32
+        self._obs_ring = [torch.zeros(nobs, dtype=torch.float32 if f32 else torch.float64).pin_memory() for _ in range(nbuf)]
         shape = (nobs,) if self.obs_returned in ('aer', 'flatten') else (self.m, 12)
         self._obs_ring_np = [b.numpy().reshape(shape) for b in self._obs_ring]
         self._obs_ring_ptr = [b.data_ptr() for b in self._obs_ring]
@@ -304,7 +312,8 @@ class SSA_Tasker_Env(Env):
         # default hand-out of the 'flatten' / (m, 12) observation: a buffer nobody holds, written by the kernel, returned as a fresh array,
         # taken back when the consumer lets go of it (envs/_obspool.py) -- the reference's semantics without the copy
         from ._obspool import ObsPool
-        self._obs_pool = None if (aer or self._obs_zero_copy or self._obs_device) else ObsPool(nobs, shape, cap=int(self._obs_pool_cap))
+        self._obs_pool = None if (aer or self._obs_zero_copy or self._obs_device) else ObsPool(nobs, shape, cap=int(self._obs_pool_cap),
+                                                                                               dtype=np.float32 if f32 else np.float64)
         self.x_true = _History(self, e.x_true, self.m, (6,))
         self.x_filter = _History(self, e.x_filter, self.m, (6,))
         self.P_filter = _History(self, e.P_filter, self.m, (6, 6))
@@ -392,15 +401,19 @@ class SSA_Tasker_Env(Env):
         if self._engine is not None:
             self._engine.to_caller_order()
 
+    def _host_obs(self, arr):
+        """an observation that reached the host through a device-to-host copy, in the dtype step() hands out (config['obs_dtype'])"""
+        return arr.astype(np.float32) if getattr(self, "_mirror_f32", False) else arr
+
     def _obs_out(self, reset=False):
         """the observation of the current step through the slow path (reset(), rollout(), run_agent()): a device-to-host copy (gathered into
         the env's object order while a storage layout is set: a reset does not cost the layout)"""
         e, slot = self._engine, self.i % self._engine.H
         if self.obs_returned == 'flatten':
-            return e.caller_rows(e.obs[slot]).cpu().numpy().reshape(-1)
+            return self._host_obs(e.caller_rows(e.obs[slot]).cpu().numpy().reshape(-1))
         elif self.obs_returned == 'aer':
             return self.aer_obs(self.observation)
-        return e.caller_rows(e.obs[slot]).cpu().numpy()
+        return self._host_obs(e.caller_rows(e.obs[slot]).cpu().numpy())
 
     def step(self, a):
         step_s = time.time()
@@ -433,7 +446,7 @@ class SSA_Tasker_Env(Env):
                           aer_out=self._obs_ring_ptr[0] if aer else 0,
                           obs_mirror=0 if aer else (pool.ptrs[kp] if kp is not None else self._obs_ring_ptr[k]),
                           stats_out=self._stats_ptr, upd_out=self._upd_ptr, stream=cur.cuda_stream,
-                          fast_stats=True, fold_inside=True, argmax_spos=shaped)
+                          fast_stats=True, fold_inside=True, argmax_spos=shaped, mirror_f32=self._mirror_f32)
             obs_np = self._obs_ring_np[k]
         cur.synchronize()
         rec = self._upd_np
@@ -555,9 +568,9 @@ class SSA_Tasker_Env(Env):
             self.observation[:] = self._aer_dev.cpu().numpy()
             obs = self.observation
         elif self.obs_returned == 'flatten':
-            obs = e.obs[slot].cpu().numpy().reshape(-1)
+            obs = self._host_obs(e.obs[slot].cpu().numpy().reshape(-1))
         else:
-            obs = e.obs[slot].cpu().numpy()
+            obs = self._host_obs(e.obs[slot].cpu().numpy())
         return obs, np.asarray(rewards), np.asarray(dones, dtype=bool), {}
 
     AGENT_KINDS = {'agent_naive_greedy': _lib.AGENT_NAIVE_GREEDY, 'agent_visible_greedy': _lib.AGENT_VISIBLE_GREEDY,
@@ -668,9 +681,9 @@ class SSA_Tasker_Env(Env):
             self.observation[:] = e.caller_rows(self._aer_dev.view(self.m, 4)).cpu().numpy().reshape(-1)     # (a storage layout is kept here)
             obs = self.observation
         elif self.obs_returned == 'flatten':
-            obs = e.caller_rows(e.obs[slot]).cpu().numpy().reshape(-1)
+            obs = self._host_obs(e.caller_rows(e.obs[slot]).cpu().numpy().reshape(-1))
         else:
-            obs = e.caller_rows(e.obs[slot]).cpu().numpy()
+            obs = self._host_obs(e.caller_rows(e.obs[slot]).cpu().numpy())
         return obs, np.asarray(actions, dtype=int), np.asarray(rewards), np.asarray(dones, dtype=bool)
 
     # ------------------------------------------------------------------ closed loop with ANY policy that lives on the GPU

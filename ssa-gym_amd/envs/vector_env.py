@@ -68,13 +68,19 @@ class SSA_Tasker_VecEnv:
         self._stats_np = self._stats_host.numpy()
         per = self.m * (4 if self.obs_returned == 'aer' else 12)
         oshape = (self.E, self.m, 12) if self.obs_returned not in ('aer', 'flatten') else (self.E, per)
-        self._obs_ring = [torch.zeros(self.E * per, dtype=torch.float64).pin_memory() for _ in range(2)]
+        # config['obs_dtype'] = 'float32' (EXTENSION; default float64, the reference's): the host-facing observations in single precision,
+        # written that way by the step kernel (SSA_LAUNCH_MIRROR_F32) -- half of the 5 MB a vector step sends over PCIe
+        self._mirror_f32 = np.dtype(config.get('obs_dtype', np.float64)) == np.float32 and not self._obs_device
+        if self._mirror_f32 and self.reward_type == 'shaped' and not self._eng.supports_argmax:
+            raise ValueError("obs_dtype float32 with the 'shaped' reward needs rso_count % 4 == 0 (the one-launch statistics path)")
+        self._obs_ring = [torch.zeros(self.E * per, dtype=torch.float32 if self._mirror_f32 else torch.float64).pin_memory() for _ in range(2)]
         self._obs_ring_np = [b.numpy().reshape(oshape) for b in self._obs_ring]
         self._obs_ring_ptr = [b.data_ptr() for b in self._obs_ring]
         # default hand-out: a buffer nobody holds, written by the kernel, returned as a fresh array and taken back when the consumer lets go
         # of it (envs/_obspool.py) -- fresh-array semantics without the 5 MB copy per step
         from ._obspool import ObsPool
-        self._obs_pool = None if (self._obs_zero_copy or self._obs_device) else ObsPool(self.E * per, oshape, cap=int(config.get('obs_pool', 16)))
+        self._obs_pool = None if (self._obs_zero_copy or self._obs_device) else ObsPool(self.E * per, oshape, cap=int(config.get('obs_pool', 16)),
+                                                                                            dtype=np.float32 if self._mirror_f32 else np.float64)
         self.i = np.zeros(self.E, dtype=np.int64)       # per-env step index
         self.tick = 0
         self.rewards_sum = np.zeros(self.E)
@@ -122,13 +128,14 @@ class SSA_Tasker_VecEnv:
                     self._aer_reset_rows()
                 return self._aer.view(self.E, self.m * 4)
             return e.obs[slot].view(self.E, self.m * 12) if self.obs_returned == 'flatten' else e.obs[slot].view(self.E, self.m, 12)
+        cast = (lambda a: a.astype(np.float32)) if self._mirror_f32 else (lambda a: a)
         if self.obs_returned == 'flatten':
-            return e.obs[slot].cpu().numpy().reshape(self.E, self.m * 12)
+            return cast(e.obs[slot].cpu().numpy().reshape(self.E, self.m * 12))
         if self.obs_returned == 'aer':
             if reset:
                 self._aer_reset_rows()
-            return self._aer.cpu().numpy().reshape(self.E, self.m * 4)
-        return e.obs[slot].cpu().numpy().reshape(self.E, self.m, 12)
+            return cast(self._aer.cpu().numpy().reshape(self.E, self.m * 4))
+        return cast(e.obs[slot].cpu().numpy().reshape(self.E, self.m, 12))
 
     def _aer_reset_rows(self):
         """the 'aer' block of the CURRENT state of every env (reset time only: a step's block is the step kernel's epilogue)"""
@@ -163,14 +170,15 @@ class SSA_Tasker_VecEnv:
         if self._inline:
             cur = self._stream
             e.launch_step(sin, sout, 0, aer_out=aer_out, obs_mirror=mirror, stats_out=self._stats_host.data_ptr(), stream=cur.cuda_stream,
-                          fast_stats=fast, fold_inside=True, env_words=(self.i.tolist(), actions.tolist()), argmax_spos=shaped and fast)
+                          fast_stats=fast, fold_inside=True, env_words=(self.i.tolist(), actions.tolist()), argmax_spos=shaped and fast,
+                          mirror_f32=self._mirror_f32 and fast)
         else:
             self._time_np[:] = self.i
             self._act_np[:] = actions
             e.time_actions.copy_(self._ta_host, non_blocking=True)
             cur = torch.cuda.current_stream()     # (the stream the time / action copy above was enqueued in)
             e.launch_step(sin, sout, 0, aer_out=aer_out, obs_mirror=mirror, stats_out=self._stats_host.data_ptr(), stream=cur.cuda_stream,
-                          fast_stats=fast, fold_inside=True, argmax_spos=shaped and fast)
+                          fast_stats=fast, fold_inside=True, argmax_spos=shaped and fast, mirror_f32=self._mirror_f32 and fast)
         cur.synchronize()
         st = self._stats_np            # (host-mapped: the step kernel's folds wrote it; stable until the next launch)
         if shaped:

@@ -986,3 +986,32 @@ def test_storage_layout_is_invisible_through_the_gym_api(envs, mode, reward):
         assert np.array_equal(np.asarray(a.x_filter[a.i]), np.asarray(b.x_filter[b.i]))
     with pytest.raises(ValueError):
         envs.make(config=dict(cfg, storage_layout='sorted'))
+
+
+@pytest.mark.parametrize("mode", ['flatten', 'aer', 'default'])
+def test_float32_observations_are_the_float64_ones_rounded(envs, mode):
+    """config['obs_dtype'] = np.float32 (EXTENSION; the reference's observations are float64): the step kernel writes its host-facing copy
+    of the observation in single precision (SSA_LAUNCH_MIRROR_F32: half the bytes over PCIe).  Everything computed stays float64, so the
+    float32 observation must be exactly the float64 one rounded to nearest -- every step, every mode, the vector env too -- and rewards,
+    dones and the device state identical."""
+    from ssa_gym_amd.envs.vector_env import SSA_Tasker_VecEnv
+    cfg = dict(envs.env_config)
+    cfg.update(rso_count=37, steps=40, reward_type='trinary', obs_returned=mode, seed=5, history='full')
+    a, b = envs.make(config=cfg), envs.make(config=dict(cfg, obs_dtype=np.float32))
+    assert b.observation_space.dtype == np.float32 and a.observation_space.dtype == np.float64
+    oa, ob = a.reset(), b.reset()
+    assert ob.dtype == np.float32 and np.array_equal(oa.astype(np.float32), ob)
+    for k in range(12):
+        ra, rb = a.step(k % 37), b.step(k % 37)
+        assert rb[0].dtype == np.float32 and rb[0].shape == ra[0].shape
+        assert np.array_equal(ra[0].astype(np.float32), rb[0]) and ra[1] == rb[1] and ra[2] == rb[2], k
+    assert np.array_equal(np.asarray(a.x_filter[12]), np.asarray(b.x_filter[12])) and np.asarray(b.x_filter[12]).dtype == np.float64
+    ua, ub = a.rollout([1, 2, 3]), b.rollout([1, 2, 3])
+    assert ub[0].dtype == np.float32 and np.array_equal(ua[0].astype(np.float32), ub[0])
+    va = SSA_Tasker_VecEnv(dict(cfg), num_envs=3, seed=2)
+    vb = SSA_Tasker_VecEnv(dict(cfg, obs_dtype=np.float32), num_envs=3, seed=2)
+    for k in range(6):
+        ra, rb = va.step([k, k + 1, k + 2]), vb.step([k, k + 1, k + 2])
+        assert rb[0].dtype == np.float32 and np.array_equal(ra[0].astype(np.float32), rb[0]) and np.array_equal(ra[1], rb[1])
+    with pytest.raises(ValueError):
+        envs.make(config=dict(cfg, obs_dtype=np.int32))
