@@ -435,7 +435,7 @@ def torch_policy_rate(m, n=192):
                     "advances on the device; the host books chunk c while the GPU runs chunk c + 1" % (n, n // 32)}
 
 
-def vec_env_rate(m, E=8, n=60, obs_device=False, zero_copy=False, f32=False):
+def vec_env_rate(m, E=8, n=68, obs_device=False, zero_copy=False, f32=False, layout=False):
     """BASELINE config 5's per-GPU load through the vector-env API: E envs of m objects advanced by ONE launch per
     SSA_Tasker_VecEnv.step() (per-env actions and time indices, auto-reset), host in the loop, the E 'aer' observation
     vectors returned over PCIe.  Reported in 20 000-object env-steps per second (E per call).  Never `value`."""
@@ -443,11 +443,12 @@ def vec_env_rate(m, E=8, n=60, obs_device=False, zero_copy=False, f32=False):
     from ssa_gym_amd.envs.vector_env import SSA_Tasker_VecEnv
     cfg = dict(env_config)
     cfg.update(rso_count=m, steps=480, reward_type='trinary', obs_returned='aer', seed=0, device_rng=True, obs_device=obs_device,
-               obs_zero_copy=zero_copy, obs_dtype=np.float32 if f32 else np.float64)
+               obs_zero_copy=zero_copy, obs_dtype=np.float32 if f32 else np.float64, storage_layout='regime' if layout else None)
     env = SSA_Tasker_VecEnv(cfg, num_envs=E, seed=0)
     acts = lambda k: [(k * 7 + 13 * e) % m for e in range(E)]    # noqa: E731
     for k in range(10):
         env.step(acts(k))
+    env.reset()                 # (the timed blocks start with an episode: seven 68-step blocks span one, steps 1-476 of 479)
     cnt = {"k": 10}
 
     def block():
@@ -462,9 +463,12 @@ def vec_env_rate(m, E=8, n=60, obs_device=False, zero_copy=False, f32=False):
         # gym-API legs do.)
         if int(env.i.max()) + n >= env.n - 1:
             env.reset()
-    el, lo, hi, reps = timed_repeats(block, lambda: None, prepare=prepare)
+    # (whole episodes, as `value`: with the behaviour-faithful default a late block is 1.5 x slower than an early one where the kernel
+    # dominates -- obs_device -- and the median BLOCK, the statistic of these legs until round 4's last build, was an early one)
+    el, lo, hi, reps = timed_repeats(block, lambda: None, prepare=prepare, group=(env.n - 1) // n)
     dt = el / n
     return {"value": round(E / dt * (m / 20000.0), 2), "ms_per_vector_step": round(1e3 * dt, 5), "envs": E,
+            "timing": "median over whole episodes (%d blocks of %d vector steps each) of the mean block" % ((env.n - 1) // n, n),
             **spread(n, E * m / 20000.0, el, lo, hi, reps),
             "obs_bytes_per_step": 0 if obs_device else E * m * 4 * (4 if f32 else 8),
             "note": ("SSA_Tasker_VecEnv.step() with config['obs_device']: %d envs x %d objects per launch, host in the loop; the observations stay "
@@ -918,7 +922,11 @@ def main():
             legs["vec_env_zero_copy"] = vec_env_rate(m, zero_copy=True)
             legs["vec_env_f32"] = vec_env_rate(m, f32=True)
             legs["vec_env_f32"]["note"] += "; config['obs_dtype'] = float32 (EXTENSION): 2.56 MB of observations per vector step instead of 5.12"
-            legs["vec_env_device_obs"] = vec_env_rate(m, obs_device=True)
+            legs["vec_env_device_obs"] = vec_env_rate(m, obs_device=True, layout=True)
+            legs["vec_env_device_obs"]["note"] += ("; config['storage_layout'] = 'regime' (every env's objects stored by orbit regime, one permutation per env -- "
+                                                   "HotPathEngine.set_layout([n_env][n_obj]); observations, actions and rewards in the env's own numbering, "
+                                                   "bit-identical); `caller_order`: without it")
+            legs["vec_env_device_obs"]["caller_order"] = vec_env_rate(m, obs_device=True)["value"]
 
     cpu, cpu_all, ep_fail = None, None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N=1 only

@@ -90,6 +90,35 @@ u, c = np.unique(key, return_counts=True)
 print("distinct (xcc,se,cu,simd): %d ; waves per SIMD min/mean/max: %d / %.2f / %d" % (len(u), c.min(), c.mean(), c.max()))
 ucu, ccu = np.unique(xcc * 10000 + se * 1000 + cu * 10, return_counts=True)
 print("distinct CUs: %d ; waves per CU min/mean/max: %d / %.2f / %d" % (len(ucu), ccu.min(), ccu.mean(), ccu.max()))
+if os.environ.get("SIMD_MAP") == "1":
+    # how the dispatcher spread the launch: tile -> (xcc, se, cu, simd), and what each SIMD had to run.  (tile = the XCD's contiguous block:
+    # position i of XCD x is tile x * per + i, dispatched as workgroup 8 i + x)
+    per = (nb + 7) // 8
+    pos = np.arange(nb) % per if nb % 8 == 0 else np.arange(nb) - (np.arange(nb) // per) * per
+    x0 = xcc == xcc[0]
+    print("XCD of tile 0: positions 0..39 -> (se, cu, simd, slot):", [(int(se[i]), int(cu[i]), int(simd[i]), int(wave[i])) for i in np.nonzero(x0)[0][:40]])
+    kst = np.diff(t, axis=1)[:, 2] / 1e3
+    slow_w = kst > 3.5
+    work = np.diff(t, axis=1)[:, 1:9].sum(axis=1) / 1e3
+    ids, inv = np.unique(key, return_inverse=True)
+    n_slow = np.bincount(inv, weights=slow_w.astype(float))
+    n_all = np.bincount(inv)
+    end_simd = np.zeros(len(ids)); np.maximum.at(end_simd, inv, en)
+    kep_sum = np.bincount(inv, weights=kst)
+    print("slow waves per SIMD (histogram 0..5):", np.bincount(n_slow.astype(int), minlength=6))
+    for k in range(6):
+        sel = n_slow.astype(int) == k
+        if sel.sum():
+            print("   SIMDs with %d slow waves: n=%4d  waves %.2f  last end mean %.2f  p90 %.2f  max %.2f   sum of kepler stages %.2f us" % (
+                k, sel.sum(), n_all[sel].mean(), end_simd[sel].mean(), np.percentile(end_simd[sel], 90), end_simd[sel].max(), kep_sum[sel].mean()))
+    print("correlation(last end of a SIMD, sum of its waves' kepler stages) = %.3f ; (last end, number of slow waves) = %.3f" % (
+        np.corrcoef(end_simd, kep_sum)[0, 1], np.corrcoef(end_simd, n_slow)[0, 1]))
+    print("SIMD last-end percentiles 0/25/50/75/90/99/100:", np.percentile(end_simd, [0, 25, 50, 75, 90, 99, 100]).round(2))
+    # positions (within the XCD's block) of the waves of a few SIMDs: is the spread regular?
+    for kk in ids[:6]:
+        sel = key == kk
+        print("   SIMD %d: positions %s  slow %s" % (kk, sorted(pos[sel].tolist()), slow_w[sel].astype(int).tolist()))
+    np.save(os.environ.get("SIMD_MAP_OUT", "/tmp/simd_map.npy"), np.stack([np.arange(nb), xcc, se, cu, simd, wave, slow_w.astype(np.int64), (kst * 100).astype(np.int64), (en * 100).astype(np.int64), (st * 100).astype(np.int64)], axis=1))
 # concurrency over time
 grid = np.linspace(0, en.max(), 60)
 conc = [(int(((st <= g) & (en > g)).sum())) for g in grid]

@@ -215,8 +215,10 @@ typedef struct ssa_step_params {
     uint32_t *fail_count;      /* device word: records appended so far (the caller zeroes it when it resets its episode); NULL with fail_log NULL */
     int32_t fail_cap;          /* capacity of fail_log in records (a record beyond it is counted but not written) */
     int32_t reserved1;
-    const int32_t *obj_ids;    /* [4 ceil(m / 4)] device words or NULL (one env; ssa_env_step_f64 with stat_shards, ssa_env_rollout_f64,
-                                  ssa_env_closed_loop_f64 together with ssa_closed_loop_params.slot_of).  A LAYOUT: the caller stores its objects in another order than it numbers them --
+    const int32_t *obj_ids;    /* [4 ceil(m / 4)] device words or NULL (one env: ssa_env_step_f64 with stat_shards, ssa_env_rollout_f64,
+                                  ssa_env_closed_loop_f64 together with ssa_closed_loop_params.slot_of; SEVERAL envs, ssa_env_step_f64 only:
+                                  [n_env][m] words, m % 4 == 0, every env its own permutation of 0 .. m - 1 -- indices within the env, as the
+                                  actions are; obs_mirror / aer_out row e m + obj_ids[e][i]).  A LAYOUT: the caller stores its objects in another order than it numbers them --
                                   position i of every array of this struct holds the object the caller calls obj_ids[i] (round 4: objects of one orbit
                                   regime share wavefronts; late in an episode the diverged filters are the LEO objects, and packed they cost the launch
                                   10 % less: DESIGN.md section 6).  The kernel then speaks the CALLER's indices wherever an index leaves it or enters it:

@@ -156,3 +156,17 @@ def regime_order(x, tile=4, n_xcd=8, one_tile_limit=20480):
         t = (c % n_xcd) * q + c // n_xcd
         order[tile * t:tile * t + tile] = L[tile * c:tile * c + tile]
     return order
+
+
+def regime_order_env(x, e, n_env, tile=4):
+    """the layout of env e of a vector env's batch (HotPathEngine.set_layout with several envs): the plain sort by semi-major axis, ROTATED
+    by e / n_env of the env's tiles.  The batch is one launch in which a wavefront walks one tile of every env at the same position (8 envs
+    x 20 000 objects: wavefront w takes tile w of each); sorted alike, a wavefront would meet the slow regime in all of its tiles or in none
+    -- rotated, every walk runs through the same mix (the single env's rule beyond 20 480 objects, regime_order).  Returns order[m]."""
+    x = np.asarray(x)
+    a = 1.0 / (2.0 / np.linalg.norm(x[:, :3], axis=1) - np.sum(x[:, 3:] ** 2, axis=1) / MU)
+    L = np.argsort(a, kind="stable")
+    nt = len(L) // tile
+    if nt < n_env or len(L) % tile:
+        return L
+    return np.roll(L, -tile * ((e * nt) // n_env))

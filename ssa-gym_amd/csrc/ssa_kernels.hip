@@ -211,6 +211,11 @@ SSA_DEV void store16(double* dst, const double* src)
 #endif
 #endif
 }
+// first row of the env a tile belongs to (a storage layout with several envs: whole tiles per env, so the tile has ONE env)
+SSA_DEV int64_t env_row0(const ssa_step_params& p, int64_t base)
+{
+    return p.n_env > 1 ? (int64_t)((uint32_t)base / (uint32_t)p.n_obj) * p.n_obj : 0;
+}
 template <bool NT>
 SSA_DEV void store_tile(const Tiles& t, const ssa_step_params& p, int lane, int64_t base, int cnt)
 {
@@ -247,7 +252,8 @@ SSA_DEV void store_tile(const Tiles& t, const ssa_step_params& p, int lane, int6
             if (NT) __builtin_nontemporal_store(pair, reinterpret_cast<v2d*>(dst));
             else *reinterpret_cast<v2d*>(dst) = pair;
             if (p.obs_mirror) {   // (e.g. host-mapped memory; with obj_ids: row by row at the caller's index of the object)
-                const int64_t at = p.obj_ids ? (int64_t)t.Oid[jj] * 12 + r : base * 12 - 64 + 2 * lane;      // (in observation entries)
+                // (in observation entries; several envs: the table holds indices within the env, whose rows start at env_row0)
+                const int64_t at = p.obj_ids ? (env_row0(p, base) + t.Oid[jj]) * 12 + r : base * 12 - 64 + 2 * lane;
                 if (p.launch_mask & SSA_LAUNCH_MIRROR_F32)      // the host-facing copy in single precision: half the bytes over PCIe
                     *reinterpret_cast<float2*>(reinterpret_cast<float*>(p.obs_mirror) + at) = make_float2((float)pair.x, (float)pair.y);
                 else *reinterpret_cast<v2d*>(p.obs_mirror + at) = pair;
@@ -279,7 +285,7 @@ SSA_DEV void store_tile(const Tiles& t, const ssa_step_params& p, int lane, int6
         if (!skip && i < lim) store16<NT>(dst + 2 * i, src + 2 * i);
         if (sO && p.obs_mirror && i < lim) {
             const int jj = (i * 43) >> 8;     // i / 6: the object (rows beyond cnt are masked by `lim`)
-            const int64_t at = p.obj_ids ? (int64_t)t.Oid[jj] * 12 + (2 * i - 12 * jj) : base * 12 + 2 * i;
+            const int64_t at = p.obj_ids ? (env_row0(p, base) + t.Oid[jj]) * 12 + (2 * i - 12 * jj) : base * 12 + 2 * i;
             if (p.launch_mask & SSA_LAUNCH_MIRROR_F32)
                 *reinterpret_cast<float2*>(reinterpret_cast<float*>(p.obs_mirror) + at) = make_float2((float)src[2 * i], (float)src[2 * i + 1]);
             else store16<false>(p.obs_mirror + at, src + 2 * i);
@@ -1116,7 +1122,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     // wavefront is the longest-living one of the launch, so its inputs (this step's GCRS->ITRS matrix, the measurement noise)
     // leave HBM now and wait in LDS, instead of costing two memory round trips when the update starts
     const bool interval_ok = (C.update_interval <= 1) || (tix % C.update_interval == 0);
-    // ssa_step_params.obj_ids (one env, the per-step kernels): the objects are stored in another order than the caller numbers them; the
+    // ssa_step_params.obj_ids (the per-step kernels; per env, indices within the env): the objects are stored in another order than the caller numbers them; the
     // action, the failure records, the arg-max of sigma_pos and the host-facing observation rows speak the CALLER's indices
     int64_t jid = j;
     if (p.obj_ids) {
@@ -1619,7 +1625,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     // observation mode and the multi-GPU all-gather payload -- from the tiles, so that no second pass over x / P (the
     // former post kernel: 6.7 MB re-read per 20 000 objects plus a launch) is needed
     if (p.aer_out && p.stat_shards) {
-        if (l < 4 && valid) aer_obs_tile<INL>(t, p, C, g, l, e, p.obj_ids ? (int64_t)t.Oid[g] : obj);
+        if (l < 4 && valid) aer_obs_tile<INL>(t, p, C, g, l, e, p.obj_ids ? (int64_t)e * p.n_obj + t.Oid[g] : obj);
     }
     wave_lds_sync();
     SSA_TR(7);
@@ -3331,8 +3337,9 @@ static int step_launch(const ssa_consts* c, const ssa_step_params* p, void* stre
     if (p->spos_tiles && !p->stat_shards) return SSA_E_INVALID;
     if (p->fail_log && (!p->fail_count || p->fail_cap <= 0)) return SSA_E_INVALID;
     if ((p->launch_mask & SSA_LAUNCH_MIRROR_F32) && !p->stat_shards) return SSA_E_UNSUPPORTED;   // (the post kernel writes aer_out in double)
-    if (p->obj_ids && (p->n_env != 1 || !p->stat_shards)) return SSA_E_UNSUPPORTED;   // (one env; the statistics of the one-launch paths: the post
-                                                                                        // kernel's arg-max would speak storage positions)
+    // (the statistics of the one-launch paths: the post kernel's arg-max would speak storage positions; several envs: one table row per env,
+    // indices within the env, whole tiles per env)
+    if (p->obj_ids && (!p->stat_shards || (p->n_env != 1 && (p->n_obj % OBJ_PER_WAVE) != 0))) return SSA_E_UNSUPPORTED;
     if ((p->spos_tiles || p->spos_tiles_prev) && p->n_env > 1 && (p->n_obj % OBJ_PER_WAVE) != 0) return SSA_E_UNSUPPORTED;   // whole tiles per env
     if (c->obs_type != SSA_OBS_AER && c->obs_type != SSA_OBS_XYZ) return SSA_E_INVALID;
     if (p->aer_cols != 0 && p->aer_cols != 1 && p->aer_cols != 4) return SSA_E_INVALID;

@@ -114,13 +114,15 @@ class HotPathEngine:
 
     # ------------------------------------------------------------------ layout (ssa_step_params.obj_ids)
     def set_layout(self, order):
-        """Store the objects in another order than the caller numbers them (one env): position i of every state tensor holds the object the
+        """Store the objects in another order than the caller numbers them: position i of every state tensor holds the object the
         caller calls order[i]; None: the caller's order.  Objects of one orbit regime then share wavefronts (catalogue.regime_order) --
         late in an episode the diverged filters are the LEO objects, and packed they cost a launch 10 % less.
         The per-step launches speak the caller's indices wherever an index enters or leaves (actions, failure records, arg-max of sigma_pos,
         the host-facing observation rows: include/ssa_hip.h); the state tensors of this engine (x_true, x_filter, P_filter, obs, metrics,
         status) are in STORAGE order while a layout is set -- `to_caller_order()` puts them back (the rollout and closed-loop launches keep the
-        layout).  Call before load_state(); the state present is not moved."""
+        layout).  Call before load_state(); the state present is not moved.
+        Several envs (the per-step launch only): `order` is [n_env][n_obj], one permutation per env (indices within the env, as the actions
+        are), n_obj % 4 == 0; `set_env_layout(e, order)` replaces one env's row (a vector env's auto-reset)."""
         if order is None and self._order is None:
             return
         self._order = None
@@ -128,26 +130,46 @@ class HotPathEngine:
         self._pcache.clear()
         if order is None:
             return
-        if self.E != 1:
-            raise _lib.SsaHipError("a storage layout needs one env")
+        order = np.asarray(order, dtype=np.int64)
+        if self.E == 1:
+            order = order.reshape(-1)
+        if order.shape != ((self.m,) if self.E == 1 else (self.E, self.m)) or \
+                not np.array_equal(np.sort(order.reshape(self.E, self.m), axis=1), np.broadcast_to(np.arange(self.m), (self.E, self.m))):
+            raise _lib.SsaHipError("set_layout: `order` must be a permutation of 0 .. n_obj - 1 (one per env)")
+        if self.E > 1 and self.m % 4:
+            raise _lib.SsaHipError("a storage layout with several envs needs n_obj % 4 == 0 (whole tiles per env)")
+        self._order = order.copy()
+        self._obj_ids = torch.full((4 * self.ntiles,), -1, dtype=torch.int32, device=self.dev)   # (whole tiles: the kernel reads a tile's four words at once)
+        self._p.obj_ids = self._obj_ids.data_ptr()
+        self._upload_layout()
+
+    def _upload_layout(self):
+        """the device tables of self._order (in place: the launch parameter blocks keep their pointers)"""
+        N = self.m * self.E
+        rows = (self._order.reshape(self.E, self.m) + (np.arange(self.E, dtype=np.int64) * self.m)[:, None]).reshape(-1)
+        self._obj_ids[:N].copy_(torch.as_tensor(self._order.reshape(-1).astype(np.int32)))
+        self._order_idx = torch.as_tensor(rows).to(self.dev)                      # storage position -> the caller's row
+        self._slot_of = torch.as_tensor(np.argsort(rows)).to(self.dev)            # the caller's row -> storage position
+        self._slot_of32 = self._slot_of.to(torch.int32)                           # (the closed loop's inverse table: ssa_closed_loop_params.slot_of)
+
+    def set_env_layout(self, e, order):
+        """one env's row of a several-env layout replaced (before load_env_state of that env: the state present is not moved)"""
+        if self._order is None or self.E == 1:
+            raise _lib.SsaHipError("set_env_layout: set_layout([n_env][n_obj]) first")
         order = np.asarray(order, dtype=np.int64).reshape(-1)
         if order.shape[0] != self.m or not np.array_equal(np.sort(order), np.arange(self.m)):
-            raise _lib.SsaHipError("set_layout: `order` must be a permutation of 0 .. n_obj - 1")
-        ids = np.full(4 * self.ntiles, -1, dtype=np.int32)          # (whole tiles: the kernel reads a tile's four words at once)
-        ids[:self.m] = order
-        self._order = order
-        self._obj_ids = torch.as_tensor(ids).to(self.dev)
-        self._order_idx = torch.as_tensor(order).to(self.dev)                     # storage position -> caller's index
-        self._slot_of = torch.as_tensor(np.argsort(order)).to(self.dev)           # caller's index -> storage position
-        self._slot_of32 = self._slot_of.to(torch.int32)                           # (the closed loop's inverse table: ssa_closed_loop_params.slot_of)
-        self._p.obj_ids = self._obj_ids.data_ptr()
+            raise _lib.SsaHipError("set_env_layout: `order` must be a permutation of 0 .. n_obj - 1")
+        self._order[e] = order
+        self._upload_layout()
 
     def _reorder(self, idx, slots):
-        """every per-object tensor of the given history slots gathered through `idx` (new[i] = old[idx[i]]), and the status words"""
+        """every per-object tensor of the given history slots gathered through `idx` (new[i] = old[idx[i]], rows of all envs), and the status words"""
+        N = self.m * self.E
         for sl in slots:
             for tns in (self.x_true, self.x_filter, self.P_filter, self.obs):
                 tns[sl].copy_(tns[sl].index_select(0, idx))
-            self.metrics[sl].copy_(self.metrics[sl].index_select(2, idx))
+            mt = self.metrics[sl].reshape(self.E, 4, self.m).permute(1, 0, 2).reshape(4, N).index_select(1, idx)      # [E][4][m]
+            self.metrics[sl].copy_(mt.reshape(4, self.E, self.m).permute(1, 0, 2).reshape(self.metrics[sl].shape))
         self.status.copy_(self.status.index_select(0, idx))
 
     def caller_rows(self, tensor):
@@ -192,6 +214,18 @@ class HotPathEngine:
         device.observe(self.x_true[slot, sl], self.x_filter[slot, sl], self.P_filter[slot, sl],
                        obs=self.obs[slot, sl], metrics=self.metrics[slot, e])
         device.reward_stats(self.metrics[slot, e:e + 1], self.status[sl], self.m, 1, out=self.stats[slot, e:e + 1])
+        if self._order is not None:      # (statistics first, in the caller's order; then the env's rows into storage order)
+            idx = torch.as_tensor(self._order.reshape(self.E, self.m)[e]).to(self.dev)
+            for tns in (self.x_true, self.x_filter, self.P_filter, self.obs):
+                tns[slot, sl].copy_(tns[slot, sl].index_select(0, idx))
+            self.metrics[slot, e].copy_(self.metrics[slot, e].reshape(4, self.m).index_select(1, idx).reshape(self.metrics[slot, e].shape))
+
+    def env_caller_rows(self, e, tensor):
+        """rows of ONE env ([n_obj, ...], storage order) as the caller numbers that env's objects"""
+        if self._order is None:
+            return tensor
+        idx = self._slot_of[e * self.m:(e + 1) * self.m] - e * self.m
+        return tensor.index_select(0, idx)
 
     def snapshot(self, slot):
         """device-side copy of a history slot (initial state of an episode); remembers the storage layout it was taken under."""

@@ -81,6 +81,15 @@ class SSA_Tasker_VecEnv:
         from ._obspool import ObsPool
         self._obs_pool = None if (self._obs_zero_copy or self._obs_device) else ObsPool(self.E * per, oshape, cap=int(config.get('obs_pool', 16)),
                                                                                             dtype=np.float32 if self._mirror_f32 else np.float64)
+        # config['storage_layout'] = 'regime' (opt-in): every env's objects stored sorted by orbit regime (catalogue.regime_order_env;
+        # HotPathEngine.set_layout with one permutation per env) -- actions, rewards and observations stay in the env's own numbering.  It pays
+        # where the observations stay on the GPU (obs_device): host-facing rows would leave the kernel one by one instead of tile by tile
+        self._layout = config.get('storage_layout', None)
+        if self._layout not in (None, 'regime'):
+            raise ValueError("storage_layout: None or 'regime'")
+        if self._layout and self.m % 4:
+            raise ValueError("storage_layout with several envs needs rso_count % 4 == 0")
+        self._obs_dev_rows = None       # (layout + obs_device, 'flatten' / rows: the step kernel's second copy of the observation, at the caller's rows)
         self.i = np.zeros(self.E, dtype=np.int64)       # per-env step index
         self.tick = 0
         self.rewards_sum = np.zeros(self.E)
@@ -100,9 +109,12 @@ class SSA_Tasker_VecEnv:
             noise[j] = rs.normal(size=6) * self.x_sigma
         return xt, xt + noise
 
-    def _reset_env(self, e, slot):
+    def _reset_env(self, e, slot, draw=None):
         import torch
-        xt, xf = self._draw(e)
+        xt, xf = self._draw(e) if draw is None else draw
+        if self._layout and draw is None:        # (reset() of all envs has set the whole table already)
+            from ..catalogue import regime_order_env
+            self._eng.set_env_layout(e, regime_order_env(xt, e, self.E))
         self._eng.load_env_state(slot, e, xt, xf, self.P_0)
         self._eng.z_noise[e].copy_(torch.randn((self.n, 1, 3), dtype=torch.float64, device="cuda", generator=self._gen) * self._zs)
         self.i[e] = 0
@@ -110,8 +122,12 @@ class SSA_Tasker_VecEnv:
 
     def reset(self):
         slot = self.tick % 2
+        draws = [self._draw(e) for e in range(self.E)]
+        if self._layout:
+            from ..catalogue import regime_order_env
+            self._eng.set_layout(np.stack([regime_order_env(draws[e][0], e, self.E) for e in range(self.E)]))
         for e in range(self.E):
-            self._reset_env(e, slot)
+            self._reset_env(e, slot, draw=draws[e])
         self._refresh_stats(slot)
         return self._obs(slot, reset=True)
 
@@ -127,15 +143,23 @@ class SSA_Tasker_VecEnv:
                 if reset:
                     self._aer_reset_rows()
                 return self._aer.view(self.E, self.m * 4)
-            return e.obs[slot].view(self.E, self.m * 12) if self.obs_returned == 'flatten' else e.obs[slot].view(self.E, self.m, 12)
+            rows = e.obs[slot]
+            if self._layout:       # the kernel's second copy, at the caller's rows (a reset: gathered from the state just loaded); one per
+                if self._obs_dev_rows is None:      # history slot, so that what step k returned stays intact until step k + 2
+                    import torch
+                    self._obs_dev_rows = [torch.zeros_like(e.obs[0]) for _ in range(2)]
+                if reset:
+                    self._obs_dev_rows[slot].copy_(e.caller_rows(e.obs[slot]))
+                rows = self._obs_dev_rows[slot]
+            return rows.view(self.E, self.m * 12) if self.obs_returned == 'flatten' else rows.view(self.E, self.m, 12)
         cast = (lambda a: a.astype(np.float32)) if self._mirror_f32 else (lambda a: a)
         if self.obs_returned == 'flatten':
-            return cast(e.obs[slot].cpu().numpy().reshape(self.E, self.m * 12))
+            return cast(e.caller_rows(e.obs[slot]).cpu().numpy().reshape(self.E, self.m * 12))
         if self.obs_returned == 'aer':
             if reset:
                 self._aer_reset_rows()
             return cast(self._aer.cpu().numpy().reshape(self.E, self.m * 4))
-        return cast(e.obs[slot].cpu().numpy().reshape(self.E, self.m, 12))
+        return cast(e.caller_rows(e.obs[slot]).cpu().numpy().reshape(self.E, self.m, 12))
 
     def _aer_reset_rows(self):
         """the 'aer' block of the CURRENT state of every env (reset time only: a step's block is the step kernel's epilogue)"""
@@ -145,6 +169,8 @@ class SSA_Tasker_VecEnv:
             sl = slice(k * self.m, (k + 1) * self.m)
             M = e.trans[int(self.i[k]) % e.n_time].reshape(3, 3)
             device.aer_obs(e.x_filter[slot, sl], e.P_filter[slot, sl], M, self._consts, out=self._aer[sl])
+            if self._layout:
+                self._aer[sl].copy_(e.env_caller_rows(k, self._aer[sl]))
 
     def step(self, actions):
         import torch
@@ -162,7 +188,7 @@ class SSA_Tasker_VecEnv:
         # tiles (rso_count % 4 == 0), through the three-launch exact statistics otherwise
         fast = (not shaped) or e.supports_argmax
         if self._obs_device:
-            aer_out, mirror = (self._aer.data_ptr() if aer else 0), 0
+            aer_out, mirror = (self._aer.data_ptr() if aer else 0), (self._obs_dev_rows[sout].data_ptr() if (self._layout and not aer) else 0)
         else:
             kp = self._obs_pool.acquire() if self._obs_pool is not None else None
             dst = self._obs_pool.ptrs[kp] if kp is not None else self._obs_ring_ptr[k]
@@ -218,17 +244,17 @@ class SSA_Tasker_VecEnv:
                 self._reset_env(int(d), sout)
             st_dev = self._eng.stats[sout].cpu().numpy()          # (the reset wrote the new envs' statistics on the device)
             self._argmax_prev[dones] = st_dev[dones, _lib.STAT_ARGMAX_SPOS].astype(np.int64)
-            obs = self._obs(sout, reset=(self.obs_returned == 'aer'))
+            obs = self._obs(sout, reset=(self.obs_returned == 'aer') or bool(self._layout))
         if self.obs_returned != 'flatten':
             rewards = np.where(np.isfinite(rewards), rewards, 0.5)
         return obs, rewards, dones, infos
 
     # inspection helpers (per env)
     def P_filter(self, e):
-        return self._eng.P_filter[self.tick % 2, e * self.m:(e + 1) * self.m].cpu().numpy()
+        return self._eng.env_caller_rows(e, self._eng.P_filter[self.tick % 2, e * self.m:(e + 1) * self.m]).cpu().numpy()
 
     def x_filter(self, e):
-        return self._eng.x_filter[self.tick % 2, e * self.m:(e + 1) * self.m].cpu().numpy()
+        return self._eng.env_caller_rows(e, self._eng.x_filter[self.tick % 2, e * self.m:(e + 1) * self.m]).cpu().numpy()
 
     def x_true(self, e):
-        return self._eng.x_true[self.tick % 2, e * self.m:(e + 1) * self.m].cpu().numpy()
+        return self._eng.env_caller_rows(e, self._eng.x_true[self.tick % 2, e * self.m:(e + 1) * self.m]).cpu().numpy()

@@ -107,3 +107,21 @@ def test_regime_order_is_a_permutation_sorted_by_semi_major_axis_and_dealt_over_
     assert per_xcd.max() - per_xcd.min() <= 1
     odd = regime_order(cat[:1003])                               # not a multiple of 32: the plain sort
     assert sorted(odd.tolist()) == list(range(1003)) and np.all(np.diff(a[:1003][odd]) >= 0)
+
+
+def test_regime_order_env_rotates_the_sorted_tiles():
+    """catalogue.regime_order_env: env e of a vector env's batch gets the plain sort by semi-major axis rotated by e / n_env of its tiles
+    (a wavefront of the batch's launch walks the same position of every env: rotated, every walk meets the same mix of regimes)"""
+    from ssa_gym_amd.catalogue import regime_order_env, synthetic_catalogue, MU
+    x = synthetic_catalogue(640, seed=3, visibility=False)
+    a = 1.0 / (2.0 / np.linalg.norm(x[:, :3], axis=1) - np.sum(x[:, 3:] ** 2, axis=1) / MU)
+    base = regime_order_env(x, 0, 8)
+    assert np.array_equal(np.sort(base), np.arange(640)) and np.all(np.diff(a[base]) >= 0)
+    for e in range(1, 8):
+        o = regime_order_env(x, e, 8)
+        assert np.array_equal(o, np.roll(base, -4 * ((e * 160) // 8)))
+    # the slow regime (the lowest third of the semi-major axes) over the positions a wavefront walks: one tile per env at the same position
+    slow = a < np.sort(a)[213]
+    per_walk = sum(slow[regime_order_env(x, e, 8)].reshape(160, 4).any(axis=1).astype(int) for e in range(8))
+    assert per_walk.min() >= 2 and per_walk.max() <= 4          # (sorted alike it would be 0 or 8)
+    assert np.array_equal(regime_order_env(x[:10], 1, 8), np.argsort(a[:10], kind="stable"))      # (not whole tiles: the plain sort)

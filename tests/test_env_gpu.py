@@ -988,6 +988,45 @@ def test_storage_layout_is_invisible_through_the_gym_api(envs, mode, reward):
         envs.make(config=dict(cfg, storage_layout='sorted'))
 
 
+@pytest.mark.parametrize("m,E", [(64, 3), (12000, 2)])
+@pytest.mark.parametrize("mode,reward,dev", [('aer', 'trinary', True), ('flatten', 'shaped', True), ('default', 'jones', False)])
+def test_storage_layout_of_a_vector_env(envs, mode, reward, dev, m, E):
+    """config['storage_layout'] = 'regime' for SSA_Tasker_VecEnv: one permutation per env (HotPathEngine.set_layout with [n_env][n_obj],
+    ssa_step_params.obj_ids indices within the env; catalogue.regime_order_env), replaced for one env when it auto-resets.  Two vector envs
+    from the same seeds, one with the layout: observations (device tensors and host arrays), rewards, dones, terminal observations and the
+    per-env state readers equal bit for bit -- through the one-tile launch (3 x 64 objects) and the grid-stride one (2 x 12 000), across an
+    auto-reset (5-step episodes), with inflated covariances so that the 'shaped' arg-max has work."""
+    import torch
+    from ssa_gym_amd.envs.vector_env import SSA_Tasker_VecEnv
+    cfg = dict(envs.env_config)
+    cfg.update(rso_count=m, steps=6, reward_type=reward, obs_returned=mode, device_rng=True, obs_device=dev, obs_limit=5.0)
+    a = SSA_Tasker_VecEnv(dict(cfg), num_envs=E, seed=4)
+    b = SSA_Tasker_VecEnv(dict(cfg, storage_layout='regime'), num_envs=E, seed=4)
+    eb = b._eng
+    assert a._eng._order is None and eb._order.shape == (E, m) and not np.array_equal(eb._order[E - 1], np.arange(m))
+    host = lambda o: o.cpu().numpy() if dev else np.asarray(o)      # noqa: E731
+    rs = np.random.RandomState(8)
+    wild = torch.as_tensor(rs.uniform(size=E * m) < 0.25).cuda()
+    a._eng.P_filter[a.tick % 2, wild] *= 3e4
+    eb.P_filter[b.tick % 2, wild[eb._order_idx]] *= 3e4                # (the same OBJECTS)
+    for k in range(14):                                                # (two auto-resets of every env)
+        acts = rs.randint(m, size=E)
+        oa, ra, da, ia = a.step(acts)
+        ob, rb, db, ib = b.step(acts)
+        assert np.array_equal(host(oa), host(ob), equal_nan=True), k
+        assert np.array_equal(ra, rb) and np.array_equal(da, db), k
+        for x, y in zip(ia, ib):
+            assert ('terminal_observation' in x) == ('terminal_observation' in y)
+            if 'terminal_observation' in x:
+                assert np.array_equal(host(x['terminal_observation']), host(y['terminal_observation']), equal_nan=True)
+        if k in (2, 7):
+            for e in range(E):
+                assert np.array_equal(a.x_filter(e), b.x_filter(e), equal_nan=True) and np.array_equal(a.P_filter(e), b.P_filter(e), equal_nan=True)
+                assert np.array_equal(a.x_true(e), b.x_true(e))
+    with pytest.raises(ValueError):
+        SSA_Tasker_VecEnv(dict(cfg, storage_layout='sorted'), num_envs=E, seed=4)
+
+
 @pytest.mark.parametrize("mode", ['flatten', 'aer', 'default'])
 def test_float32_observations_are_the_float64_ones_rounded(envs, mode):
     """config['obs_dtype'] = np.float32 (EXTENSION; the reference's observations are float64): the step kernel writes its host-facing copy
