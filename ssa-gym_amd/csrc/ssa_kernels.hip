@@ -1085,7 +1085,11 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     constexpr bool INL = (TILE != 2) && !ACT::late;   // (the per-step launches: SSA_LAUNCH_INLINE_ENVS may be set)
     // SSA_LAUNCH_FOLD_INSIDE exists in the one-tile instance only: counting a tile means waiting for its atomics' acknowledgement
     // and for a returning atomic -- once, at the end of a one-tile wavefront's life, but ~1.5 us per tile in the grid-stride
-    // instance (8 x 20 000 objects: 100.7 us per step instead of 89.0); the launcher sends those launches a fold kernel instead
+    // instance (8 x 20 000 objects: 100.7 us per step instead of 89.0); the launcher sends those launches a fold kernel instead.
+    // (Round 4 tried counting once per WAVEFRONT, at the end of its life -- lane i counts the walk's i-th tile, one round trip:
+    // build_ablate/grid_stride_fold_inside_experiment.patch.  Correct, and slower than the 4.3 us fold kernel it replaces: the wavefronts of
+    // a grid-stride launch end together, and the 128 shard-complete increments per env land on ONE word one after the other -- the vector
+    // env's step 123.9 -> 130.4 us although its host side got 4 us shorter.)
     constexpr bool FOLD_OK = (TILE == 0);
     int g = lane >> 4, l = lane & 15;
     int64_t obj = obj_in;

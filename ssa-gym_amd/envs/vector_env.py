@@ -175,7 +175,7 @@ class SSA_Tasker_VecEnv:
     def step(self, actions):
         import torch
         actions = np.asarray(actions, dtype=np.int64).reshape(self.E)
-        assert np.all((actions >= 0) & (actions < self.m)), "invalid action"
+        assert 0 <= int(actions.min()) and int(actions.max()) < self.m, "invalid action"
         e = self._eng
         argmax_prev = self._argmax_prev
         self.i += 1
@@ -245,8 +245,8 @@ class SSA_Tasker_VecEnv:
             st_dev = self._eng.stats[sout].cpu().numpy()          # (the reset wrote the new envs' statistics on the device)
             self._argmax_prev[dones] = st_dev[dones, _lib.STAT_ARGMAX_SPOS].astype(np.int64)
             obs = self._obs(sout, reset=(self.obs_returned == 'aer') or bool(self._layout))
-        if self.obs_returned != 'flatten':
-            rewards = np.where(np.isfinite(rewards), rewards, 0.5)
+        # (ssa_tasker_simple_2.py:365-367 passes the reward of the other modes through nan_to_num(nan=.5, inf=.5): the rewards formed above are
+        # finite by construction -- counts of comparisons, constants -- so there is nothing for it to replace)
         return obs, rewards, dones, infos
 
     # inspection helpers (per env)
