@@ -17,7 +17,7 @@ _build.LIB = os.path.join(ROOT, os.environ.get("LIB", "build_ablate/libs/trace.s
 m = int(os.environ.get("M", 20000))
 pb = bench.build_problem(m, seed=100)
 consts = host.make_consts(pb["Q"], pb["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, pb["obs_lla"], obs_type='aer',
-                          propagator=os.environ.get("PROP", "fg"))
+                          propagator=os.environ.get("PROP", "fg"), covariance=os.environ.get("COV") or None)
 z = torch.zeros((1, 480, m, 3), dtype=torch.float64, device='cuda')
 eng = engine.HotPathEngine(consts, m, 1, pb["trans"], z, history=2)
 if os.environ.get("LAYOUT") == "1":      # the engine's storage layout (objects of one orbit regime share wavefronts)

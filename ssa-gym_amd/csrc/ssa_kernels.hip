@@ -339,6 +339,7 @@ SSA_DEV void observe_rows(Tiles& t, int g, int l, bool stage_obs)
 // A^(mid)[hi][lo], A^(mid)[hi][4 + lo], A^(mid)[4 + hi][4 + lo] and KEEPS them in registers: covariance_finish() below turns
 // them into the entries of P in the same lanes.  Only the column of sums A[a][6] goes to LDS (t.M[mid][a]: the mean needs it).
 struct Moments { double c00, c01, c11; };
+template <bool SUMS_ONLY = false>   // SUMS_ONLY: the column of sums alone (SSA_FLAG_REFERENCE_COV forms its own second moments): block (0,0) is skipped
 SSA_DEV Moments moment_sums_mfma(Tiles& t, int lane)
 {
     const int hi = lane >> 4, mid = (lane >> 2) & 3, lo = lane & 3;
@@ -352,7 +353,7 @@ SSA_DEV Moments moment_sums_mfma(Tiles& t, int lane)
     Moments mo = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int kc = 0; kc < 3; ++kc) {
-        mo.c00 = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[kc], a0[kc], mo.c00, 0, 0, 0);
+        if (!SUMS_ONLY) mo.c00 = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[kc], a0[kc], mo.c00, 0, 0, 0);
         mo.c01 = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[kc], a1[kc], mo.c01, 0, 0, 0);
         mo.c11 = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[kc], a1[kc], mo.c11, 0, 0, 0);
     }
@@ -474,22 +475,32 @@ SSA_DEV void wave_lds_sync()
 // episode.  covariance_finish() above evaluates the same matrix expanded around sigma_0' without that cancellation and
 // such filters survive; this form reproduces the reference's failure behaviour (tests/test_episode_failures.py).
 // The thirteen rows y_i = sigma_i' - x go to LDS (factor tile + D, contiguous and free by now), the matrix unit forms the
-// three 4x4 tiles of sum_i y_i (Wc_i y_i)^T in four k-chunks (the last one holds point 12 alone), the weight enters with
-// the right operand, as in the reference.
+// three 4x4 tiles of sum_i y_i (Wc_i y_i)^T, i = 0 .. 11, in three k-chunks and three vector fmas add point 12; the weight enters
+// with the right operand, as in the reference.  (What the form costs -- every wavefront of a SIMD runs this stage at the same time, so
+// its instructions add up: a vector instruction ~8 ns of a 20 000-object step, a 4x4x4 matrix instruction ~33 ns; 13.0 us per healthy
+// step against 11.9 with covariance_finish: build_ablate/healthy_phase_ab.py.)
 SSA_DEV int ybase(int g) { return g * 104 + (g & 1) * 28 + (g >> 1) * 32; }   // 0, 132, 240, 372: bank slots as dbase()
-SSA_DEV void covariance_reference(Tiles& t, const ssa_consts& C, int lane, const double (&o)[6])
+// (xb_l: lanes 0 .. 5 of a row hold component l of the row's prior mean -- the value they have just written to t.X.  The other lanes take
+// it from there by DPP row broadcasts: the detour through t.X was three dependent LDS round trips in front of the y rows' own)
+SSA_DEV void covariance_reference(Tiles& t, const ssa_consts& C, int lane, const double (&o)[6], double xb_l)
 {
     static_assert(372 + 16 * 8 <= OBJ_PER_WAVE * 36 + 408, "y rows fit the factor tile + D");
     typedef double v2d_t __attribute__((ext_vector_type(2)));
     double* const Y = t.UA;
     {
         const int g = lane >> 4, l = lane & 15;
+#ifdef SSA_COV_MEAN_FROM_LDS   // (diagnostic: the former form)
+        const double* xb = &t.X[g * 6];
+        const double x0 = xb[0], x1 = xb[1], x2 = xb[2], x3 = xb[3], x4 = xb[4], x5 = xb[5];
+#else
+        const double x0 = row_bcast<0>(xb_l), x1 = row_bcast<1>(xb_l), x2 = row_bcast<2>(xb_l), x3 = row_bcast<3>(xb_l),
+                     x4 = row_bcast<4>(xb_l), x5 = row_bcast<5>(xb_l);
+#endif
         if (l <= 12) {
-            const double* xb = &t.X[g * 6];
             v2d_t* dst = reinterpret_cast<v2d_t*>(&Y[ybase(g) + l * 8]);
-            dst[0] = v2d_t{o[0] - xb[0], o[1] - xb[1]};
-            dst[1] = v2d_t{o[2] - xb[2], o[3] - xb[3]};
-            dst[2] = v2d_t{o[4] - xb[4], o[5] - xb[5]};
+            dst[0] = v2d_t{o[0] - x0, o[1] - x1};
+            dst[1] = v2d_t{o[2] - x2, o[3] - x3};
+            dst[2] = v2d_t{o[4] - x4, o[5] - x5};
             dst[3] = v2d_t{0.0, 0.0};
         }
     }
@@ -497,8 +508,13 @@ SSA_DEV void covariance_reference(Tiles& t, const ssa_consts& C, int lane, const
     const int hi = lane >> 4, mid = (lane >> 2) & 3, lo = lane & 3;
     const double* src = &Y[ybase(mid) + hi * 8 + lo];
     Moments mo = {0.0, 0.0, 0.0};
+#ifndef SSA_COV_FOUR_CHUNKS
+    constexpr int NKC = 3;
+#else
+    constexpr int NKC = 4;
+#endif
 #pragma unroll
-    for (int kc = 0; kc < 4; ++kc) {
+    for (int kc = 0; kc < NKC; ++kc) {
         double a0 = src[kc * 32], a1 = src[kc * 32 + 4];
         if (kc == 3 && hi != 0) { a0 = 0.0; a1 = 0.0; }           // rows 13 .. 15 do not exist
         const double w = (kc == 0 && hi == 0) ? C.Wc0 : C.Wi;
@@ -507,6 +523,18 @@ SSA_DEV void covariance_reference(Tiles& t, const ssa_consts& C, int lane, const
         mo.c01 = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, b1, mo.c01, 0, 0, 0);
         mo.c11 = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, b1, mo.c11, 0, 0, 0);
     }
+#ifndef SSA_COV_FOUR_CHUNKS
+    {   // point 12, the last term of the sum, by three vector fmas: the fourth k-chunk held it alone (three matrix instructions that
+        // multiplied three rows of zeros) -- entry (i, j) += y12[i] (Wi y12[j]), the product rounded as the matrix unit's operand was;
+        // whole 20 000-object episodes bit-identical to the four-chunk form (build_ablate/r04_run52.sh), 0.2 us per step less with
+        // the broadcasts above
+        const double* y12 = &Y[ybase(mid) + 12 * 8];
+        const double ai = y12[hi], ai4 = y12[4 + hi], bj = C.Wi * y12[lo], bj4 = C.Wi * y12[4 + lo];
+        mo.c00 = fma(ai, bj, mo.c00);
+        mo.c01 = fma(ai, bj4, mo.c01);
+        mo.c11 = fma(ai4, bj4, mo.c11);
+    }
+#endif
     const int hi1 = hi & 1, lo1 = lo & 1;
     double* P = &t.P[mid * 36];
     const double p00 = mo.c00 + t.Q[hi * 6 + lo];
@@ -1311,6 +1339,10 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     wave_lds_sync();
     Moments mo = {0.0, 0.0, 0.0};
 #if !(defined(SSA_ABLATE) && (SSA_ABLATE & 8))
+#ifndef SSA_COV_FOUR_CHUNKS   // (diagnostic: round 4's first form of the reference covariance -- nine + twelve matrix instructions)
+    if (C.flags & SSA_FLAG_REFERENCE_COV) mo = moment_sums_mfma<true>(t, lane);   // (wave-uniform branch: the sums alone, six matrix instructions)
+    else
+#endif
     mo = moment_sums_mfma(t, lane);
 #endif
     wave_lds_sync();
@@ -1328,7 +1360,7 @@ SSA_DEV void process_wave(Tiles& t, const ssa_consts& C, const ssa_step_params& 
     const bool nan_x = ((__ballot(l < 6 && xb_l != xb_l) >> (g * 16)) & 0xFFFFull) != 0;
     wave_lds_sync();
 #if !(defined(SSA_ABLATE) && (SSA_ABLATE & 4))
-    if (C.flags & SSA_FLAG_REFERENCE_COV) covariance_reference(t, C, lane, o);   // (wave-uniform branch)
+    if (C.flags & SSA_FLAG_REFERENCE_COV) covariance_reference(t, C, lane, o, xb_l);   // (wave-uniform branch)
     else covariance_finish(t, C, lane, mo);
 #endif
     wave_lds_sync();
