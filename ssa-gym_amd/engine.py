@@ -125,19 +125,20 @@ class HotPathEngine:
         are), n_obj % 4 == 0; `set_env_layout(e, order)` replaces one env's row (a vector env's auto-reset)."""
         if order is None and self._order is None:
             return
+        if order is not None:       # (checked before anything changes: a refused table leaves the layout in force as it was)
+            order = np.asarray(order, dtype=np.int64)
+            if self.E == 1:
+                order = order.reshape(-1)
+            if order.shape != ((self.m,) if self.E == 1 else (self.E, self.m)) or \
+                    not np.array_equal(np.sort(order.reshape(self.E, self.m), axis=1), np.broadcast_to(np.arange(self.m), (self.E, self.m))):
+                raise _lib.SsaHipError("set_layout: `order` must be a permutation of 0 .. n_obj - 1 (one per env)")
+            if self.E > 1 and self.m % 4:
+                raise _lib.SsaHipError("a storage layout with several envs needs n_obj % 4 == 0 (whole tiles per env)")
         self._order = None
         self._p.obj_ids = 0
         self._pcache.clear()
         if order is None:
             return
-        order = np.asarray(order, dtype=np.int64)
-        if self.E == 1:
-            order = order.reshape(-1)
-        if order.shape != ((self.m,) if self.E == 1 else (self.E, self.m)) or \
-                not np.array_equal(np.sort(order.reshape(self.E, self.m), axis=1), np.broadcast_to(np.arange(self.m), (self.E, self.m))):
-            raise _lib.SsaHipError("set_layout: `order` must be a permutation of 0 .. n_obj - 1 (one per env)")
-        if self.E > 1 and self.m % 4:
-            raise _lib.SsaHipError("a storage layout with several envs needs n_obj % 4 == 0 (whole tiles per env)")
         self._order = order.copy()
         self._obj_ids = torch.full((4 * self.ntiles,), -1, dtype=torch.int32, device=self.dev)   # (whole tiles: the kernel reads a tile's four words at once)
         self._p.obj_ids = self._obj_ids.data_ptr()

@@ -1025,6 +1025,22 @@ def test_storage_layout_of_a_vector_env(envs, mode, reward, dev, m, E):
                 assert np.array_equal(a.x_true(e), b.x_true(e))
     with pytest.raises(ValueError):
         SSA_Tasker_VecEnv(dict(cfg, storage_layout='sorted'), num_envs=E, seed=4)
+    if m == 64:      # what the several-env table cannot express is refused, loudly
+        from ssa_gym_amd import _lib
+        with pytest.raises(ValueError):
+            SSA_Tasker_VecEnv(dict(cfg, rso_count=66, storage_layout='regime'), num_envs=E, seed=4)      # (whole tiles per env)
+        with pytest.raises(_lib.SsaHipError):
+            eb.set_layout(np.arange(m))                                                                   # (one permutation per env)
+        with pytest.raises(_lib.SsaHipError):
+            eb.set_env_layout(0, np.zeros(m, dtype=np.int64))
+        with pytest.raises(_lib.SsaHipError):
+            a._eng.set_env_layout(0, np.arange(m))                                                        # (no layout set)
+        eb.to_caller_order()                                                                              # the state back in the envs' own order
+        assert eb._order is None
+        for e in range(E):
+            assert np.array_equal(a._eng.x_filter[a.tick % 2, e * m:(e + 1) * m].cpu().numpy(), eb.x_filter[b.tick % 2, e * m:(e + 1) * m].cpu().numpy(), equal_nan=True)
+            assert np.array_equal(a._eng.metrics[a.tick % 2, e].cpu().numpy(), eb.metrics[b.tick % 2, e].cpu().numpy(), equal_nan=True)
+        assert np.array_equal(a._eng.status.cpu().numpy(), eb.status.cpu().numpy())
 
 
 @pytest.mark.parametrize("mode", ['flatten', 'aer', 'default'])
