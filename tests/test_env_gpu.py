@@ -1068,5 +1068,12 @@ def test_float32_observations_are_the_float64_ones_rounded(envs, mode):
     for k in range(6):
         ra, rb = va.step([k, k + 1, k + 2]), vb.step([k, k + 1, k + 2])
         assert rb[0].dtype == np.float32 and np.array_equal(ra[0].astype(np.float32), rb[0]) and np.array_equal(ra[1], rb[1])
+    # ... and together with the per-env storage layout (single-precision rows written at the envs' own indices; whole tiles per env)
+    cfg36 = dict(cfg, rso_count=36)
+    va = SSA_Tasker_VecEnv(dict(cfg36), num_envs=3, seed=2)
+    vc = SSA_Tasker_VecEnv(dict(cfg36, obs_dtype=np.float32, storage_layout='regime'), num_envs=3, seed=2)
+    for k in range(6):
+        ra, rc = va.step([k, k + 1, k + 2]), vc.step([k, k + 1, k + 2])
+        assert rc[0].dtype == np.float32 and np.array_equal(ra[0].astype(np.float32), rc[0]) and np.array_equal(ra[1], rc[1])
     with pytest.raises(ValueError):
         envs.make(config=dict(cfg, obs_dtype=np.int32))
