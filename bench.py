@@ -22,6 +22,7 @@ per-object loop; the reference's numba/filterpy stack is not installable here) o
 """
 import argparse
 import json
+import gc
 import os
 import sys
 import time
@@ -80,7 +81,7 @@ MIN_TIMED_S = 0.05      # every timed block is repeated until the blocks add up 
 MIN_REPEATS, MAX_REPEATS = 3, 400
 
 
-def timed_repeats(block, sync, agree=None, prepare=None, group=1):
+def timed_repeats(block, sync, agree=None, prepare=None, group=1, min_groups=3):
     """`block()` enqueues EXACTLY the K steps of one timed block; `sync()` is the fence on both sides of it.  The block is
     repeated until the timed blocks add up to MIN_TIMED_S (a 20-step block of 14 us steps is 0.3 ms: one sample of it says
     little); returns (typical, min, max, repeats) of the per-block elapsed seconds.
@@ -96,6 +97,11 @@ def timed_repeats(block, sync, agree=None, prepare=None, group=1):
     prepare = prepare or (lambda: None)
     group = max(1, int(group))
     el = []
+    # (the interpreter's cyclic garbage collector: a full collection over everything the set-up allocated is 40-50 ms, and its allocation
+    # counter tripped inside the FIRST timed block of `value`, reproducibly -- one 20-step block of 48 ms in `value_spread`.  Collected now,
+    # and what survives is frozen: later collections look at the few objects the timed loop itself creates.)
+    gc.collect()
+    gc.freeze()
     prepare()
     sync()
     t0 = time.perf_counter()
@@ -104,7 +110,7 @@ def timed_repeats(block, sync, agree=None, prepare=None, group=1):
     el.append(agree(time.perf_counter() - t0))
     reps = int(min(MAX_REPEATS, max(MIN_REPEATS, np.ceil(MIN_TIMED_S / max(el[0], 1e-9)))))
     if group > 1:                        # whole groups, at least three of them
-        reps = group * max(3, -(-reps // group))
+        reps = group * max(min_groups, -(-reps // group))
     for _ in range(reps - 1):
         prepare()
         sync()
@@ -113,7 +119,15 @@ def timed_repeats(block, sync, agree=None, prepare=None, group=1):
         sync()
         el.append(agree(time.perf_counter() - t0))
     samples = np.asarray(el).reshape(-1, group).mean(axis=1)
+    if os.environ.get("SSA_BENCH_BLOCKS"):       # (diagnostic: every block's elapsed time, one line per timed_repeats call)
+        with open(os.environ["SSA_BENCH_BLOCKS"], "a") as fh:
+            fh.write(" ".join("%.6f" % v for v in el) + "\n")
     return float(np.median(samples)), float(min(el)), float(max(el)), len(el)
+
+
+def _drain():
+    import torch
+    torch.cuda.synchronize()
 
 
 def episode_groups(steps_per_block, episode=479):
@@ -354,6 +368,7 @@ def gym_api_rate(m, mode, n=200, obs_device=False, zero_copy=False, obs_pool=64,
     def prepare():
         if env.i + n >= env.n - 1:
             env.reset()
+            _drain()            # (a reset is untimed: none of its uploads / kernels may still be queued when the next timed block starts)
 
     def block():
         for _ in range(n):
@@ -388,6 +403,7 @@ def torch_policy_rate(m, n=192):
     def prepare():
         if env.i + n >= env.n - 1:
             env.reset()
+            _drain()            # (a reset is untimed: none of its uploads / kernels may still be queued when the next timed block starts)
 
     def measure(pol, graph):
         for _ in range(3):          # (untimed: torch's first launches of each expression, the caching allocator, the graph captures)
@@ -449,6 +465,7 @@ def vec_env_rate(m, E=8, n=68, obs_device=False, zero_copy=False, f32=False, lay
     for k in range(10):
         env.step(acts(k))
     env.reset()                 # (the timed blocks start with an episode: seven 68-step blocks span one, steps 1-476 of 479)
+    _drain()
     cnt = {"k": 10}
 
     def block():
@@ -463,9 +480,11 @@ def vec_env_rate(m, E=8, n=68, obs_device=False, zero_copy=False, f32=False, lay
         # gym-API legs do.)
         if int(env.i.max()) + n >= env.n - 1:
             env.reset()
+            _drain()            # (a reset is untimed: none of its uploads / kernels -- the layout's gathers among them -- may still be queued
+            #                      when the next timed block starts)
     # (whole episodes, as `value`: with the behaviour-faithful default a late block is 1.5 x slower than an early one where the kernel
     # dominates -- obs_device -- and the median BLOCK, the statistic of these legs until round 4's last build, was an early one)
-    el, lo, hi, reps = timed_repeats(block, lambda: None, prepare=prepare, group=(env.n - 1) // n)
+    el, lo, hi, reps = timed_repeats(block, lambda: None, prepare=prepare, group=(env.n - 1) // n, min_groups=5)
     dt = el / n
     return {"value": round(E / dt * (m / 20000.0), 2), "ms_per_vector_step": round(1e3 * dt, 5), "envs": E,
             "timing": "median over whole episodes (%d blocks of %d vector steps each) of the mean block" % ((env.n - 1) // n, n),
@@ -780,6 +799,12 @@ def main():
         allgather_probe = None
         for k in range(W):
             one_step(k)
+        # (an episode's end lies inside some timed block: the restore of the snapshot runs once here, untimed, so that its copy kernels are
+        # loaded -- the first use of a kernel in the process costs tens of milliseconds, which showed as one 45-70 ms block in `value_spread`)
+        fence()
+        local.reset_episode(snap, ep_len)
+        state["i"] = 0
+        fence()
     # The timed block: EXACTLY K steps between two fences (barrier + synchronize), MAX over ranks.  The driver's K = 20 makes
     # that block 0.3 ms, so it is repeated (same K, same fences) until the blocks add up to 50 ms and `value` is the MEDIAN
     # block; min / max go into `value_spread`.
@@ -791,6 +816,15 @@ def main():
         return float(t.item())
 
     def timed_block():
+        if os.environ.get("SSA_BENCH_STEPTIMES") and not state.get("dumped"):      # (diagnostic: host time of every enqueue of the FIRST timed block)
+            ts = []
+            for k in range(W, W + K):
+                t1 = time.perf_counter()
+                one_step(k)
+                ts.append(round(1e3 * (time.perf_counter() - t1), 3))
+            state["dumped"] = True
+            sys.stderr.write("steptimes [ms] %s\n" % ts)
+            return
         for k in range(W, W + K):
             one_step(k)
     elapsed, el_min, el_max, repeats = timed_repeats(timed_block_graph if graphed is not None else timed_block, fence, agree=max_over_ranks,
