@@ -29,3 +29,18 @@ for b in range(4):
     t2 = time.perf_counter(); local.flush(); t3 = time.perf_counter(); torch.cuda.synchronize(); t4 = time.perf_counter()
     print("block %d: %.2f ms; enqueue max %.3f ms (step %d), sum %.3f; flush %.3f; synchronize %.3f" % (
         b, 1e3 * (t4 - t0), 1e3 * max(ts), int(np.argmax(ts)), 1e3 * sum(ts), 1e3 * (t3 - t2), 1e3 * (t4 - t3)), flush=True)
+# what the end-of-block flush (the fold kernel of the last deferred step) costs a 20-step block
+for variant in ("flush", "no flush (lower bound of folding the last step inside its own launch)", "flush", "no flush"):
+    el = []
+    for b in range(60):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(20):
+            local.step(-1)
+        if variant.startswith("flush"):
+            local.flush()
+        torch.cuda.synchronize()
+        el.append(time.perf_counter() - t0)
+        if local.tick % 479 > 440:
+            local.reset_episode(snap, 479)
+    print("%-70s 20-step block: median %.1f us = %.2f us per step" % (variant, 1e6 * np.median(el), 1e6 * np.median(el) / 20), flush=True)
