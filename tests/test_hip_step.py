@@ -1442,3 +1442,63 @@ def test_storage_layout_speaks_the_callers_indices(hip, prop, m):
         assert np.array_equal(va, vb, equal_nan=True), name
     if prop == "hybrid":     # (the failure path did run)
         assert int(a[1][-2][2][hip.lib.STAT_N_FAILED]) >= 2
+
+
+@pytest.mark.parametrize("E,m", [(3, 52), (2, 10244)])
+def test_storage_layout_with_several_envs(hip, E, m):
+    """ssa_step_params.obj_ids with several envs (HotPathEngine.set_layout([n_env][n_obj])): one ARBITRARY permutation per env, indices within
+    the env.  Per-env actions, statistics (np.argmax(sigma_pos) included), failure records, the 'aer' block and the second copy of the
+    observation rows (row e m + the caller's index) must equal the engine without a layout step by step, bit for bit; one env's row is
+    replaced in between (set_env_layout + load_env_state: a vector env's auto-reset); to_caller_order() restores every state tensor.
+    3 x 52 objects: the one-tile launch; 2 x 10 244: the grid-stride one (with its fold kernel)."""
+    torch = hip.torch
+    xt, x, P, g = make_batch(E * m, seed=35)
+    rs = np.random.RandomState(12)
+    P[rs.uniform(size=E * m) < 0.33] *= 3e4
+    x[5, 2] = np.nan                  # (a filter of env 0 and one of env 1 fail at their first predict: failure records, status words)
+    x[m + 3, 1] = np.nan
+    consts = hip.host.make_consts(g["Q"], g["R"], 1e-4, 2.0, -3, 20.0, -np.pi / 2, g["obs_lla"], propagator="hybrid")
+    zn = torch.as_tensor(rs.normal(size=(E, 480, 1, 3)) * np.array([4.8e-6, 4.8e-6, 1e3])).cuda()
+    orders = np.stack([rs.permutation(m) for _ in range(E)])
+    new_order = rs.permutation(m)
+    xt2, x2, P2, _ = make_batch(m, seed=36)
+    n_steps = 24
+    acts = rs.randint(m, size=(n_steps, E))
+
+    def run(layout):
+        eng = hip.engine.HotPathEngine(consts, m, E, c2t(), zn, history=2, zn_stride_env=480 * 3, zn_stride_time=3, zn_stride_obj=0)
+        if layout:
+            eng.set_layout(orders)
+        eng.load_state(0, xt, x, P)
+        mirror = torch.zeros(E * m * 12, dtype=torch.float64, device="cuda")
+        aer = torch.zeros(E * m * 4, dtype=torch.float64, device="cuda")
+        st = torch.zeros((E, 8), dtype=torch.float64).pin_memory()
+        out = [eng.stats[0].cpu().numpy().copy()]
+        tix = np.zeros(E, dtype=np.int64)
+        for k in range(n_steps):
+            t = k + 1
+            if k == 11:      # env 1 starts over from another state, under another permutation
+                if layout:
+                    eng.set_env_layout(1, new_order)
+                eng.load_env_state(k % 2, 1, xt2, x2, P2[0])
+                tix[1] = 0
+            tix += 1
+            eng.launch_step((t - 1) % 2, t % 2, 0, aer_out=aer.data_ptr(), obs_mirror=mirror.data_ptr(), stats_out=st.data_ptr(),
+                            fast_stats=True, fold_inside=True, env_words=(tix.tolist(), acts[k].tolist()), argmax_spos=True)
+            torch.cuda.synchronize()
+            out.append((mirror.cpu().numpy().copy(), aer.cpu().numpy().copy(), st.numpy().copy()))
+        nf = int(eng.fail_count.item())
+        fails = sorted((int(r[hip.lib.FAIL_ENV]), int(r[hip.lib.FAIL_OBJ]), int(r[hip.lib.FAIL_STATUS]), int(r[hip.lib.FAIL_TIME])) for r in eng.fail_log[:nf])
+        eng.to_caller_order()
+        s_ = n_steps % 2
+        state = (eng.x_true[s_].cpu().numpy(), eng.x_filter[s_].cpu().numpy(), eng.P_filter[s_].cpu().numpy(), eng.obs[s_].cpu().numpy(),
+                 eng.metrics[s_].cpu().numpy(), eng.status.cpu().numpy())
+        return out, fails, state
+    a, b = run(False), run(True)
+    assert np.array_equal(a[0][0], b[0][0], equal_nan=True)
+    for k in range(1, n_steps + 1):
+        for name, va, vb in zip(("obs rows", "aer block", "statistics"), a[0][k], b[0][k]):
+            assert np.array_equal(va, vb, equal_nan=True), (k, name)
+    assert a[1] == b[1] and len(a[1]) > 0
+    for name, va, vb in zip(("x_true", "x_filter", "P_filter", "obs", "metrics", "status"), a[2], b[2]):
+        assert np.array_equal(va, vb, equal_nan=True), name
